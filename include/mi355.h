@@ -1,0 +1,272 @@
+/*
+ * mi355.h -- C ABI of the MI355X-native path-tracing / Path-Replay-Backprop engine.
+ *
+ * This is the drop-in boundary for ONE hot path of Mitsuba 3 (gitmon/mitsuba3-camera):
+ * the body of Integrator::render / render_backward for the `path` and `prb`
+ * integrators on surface-only RGB scenes.  A Mitsuba-side shim
+ * flattens Scene/Shape/BSDF/Emitter/Sensor objects into the POD records below and
+ * forwards to these entry points.  All paths cited are relative to the reference tree.
+ *
+ *   replaced interface                                   reference location
+ *   ---------------------------------------------------  -------------------------------------------
+ *   Integrator::render(scene,sensor,seed,spp,develop,..)  include/mitsuba/render/integrator.h:74-120,
+ *                                                         src/render/integrator.cpp:120-367 (JIT branch :246-360)
+ *   Integrator::render_backward(scene,params,grad_in,..)  include/mitsuba/render/integrator.h:161-215,
+ *                                                         src/python/python/ad/integrators/common.py:631-796
+ *   PathIntegrator::sample                                src/integrators/path.cpp:95-287
+ *   PRBIntegrator.sample                                  src/python/python/ad/integrators/prb.py:59-257
+ *   Scene::ray_intersect / ray_test                       src/render/scene.cpp:181-210
+ *   Film::prepare / put_block / develop (hdrfilm, RGBW)   src/films/hdrfilm.cpp:245-409
+ *   SceneParameters.update -> parameters_changed          src/python/python/util.py:185-232
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; `void *stream` is a hipStream_t
+ *     (NULL = the default stream); pointers prefixed `d_` are DEVICE pointers owned by
+ *     the caller (e.g. torch tensors), everything else is HOST memory owned by the caller
+ *     and copied during the call.
+ *   - every function returns MI355_OK (0) or a negative error code; the message is
+ *     available through mi355_last_error() (thread-local).
+ *   - matrices are row-major 3x4 affine blocks (float[12]) = the first three rows of
+ *     Mitsuba's Transform4f::matrix.
+ *   - all arithmetic is fp32; indices u32; RNG state u64 (TEA-seeded PCG32 per lane,
+ *     src/render/sampler.cpp:116-135).
+ */
+#ifndef MI355_H
+#define MI355_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1u
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define MI355_OK                 0
+#define MI355_ERR_INVALID       -1   /* bad argument / inconsistent description          */
+#define MI355_ERR_UNSUPPORTED   -2   /* plugin type outside the path's scope             */
+#define MI355_ERR_DEVICE        -3   /* HIP runtime error (message has hipGetErrorString) */
+#define MI355_ERR_NO_DEVICE     -4   /* no gfx950 device visible; there is NO CPU fallback */
+
+/* ---- plugin type tags (names follow the reference's plugin names) -------------------- */
+enum { MI355_SHAPE_RECTANGLE = 0,   /* src/shapes/rectangle.cpp */
+       MI355_SHAPE_MESH      = 1,   /* src/render/mesh.cpp (cube/obj/ply all arrive as meshes) */
+       MI355_SHAPE_SPHERE    = 2 }; /* src/shapes/sphere.cpp */
+
+enum { MI355_BSDF_DIFFUSE        = 0,   /* src/bsdfs/diffuse.cpp */
+       MI355_BSDF_ROUGHCONDUCTOR = 1,   /* src/bsdfs/roughconductor.cpp */
+       MI355_BSDF_DIELECTRIC     = 2 }; /* src/bsdfs/dielectric.cpp */
+
+enum { MI355_EMITTER_AREA = 0 };        /* src/emitters/area.cpp */
+
+enum { MI355_SENSOR_PERSPECTIVE = 0,    /* src/sensors/perspective.cpp */
+       MI355_SENSOR_REALISTICLENS = 1 };/* src/sensors/realisticlens.cpp */
+
+enum { MI355_RFILTER_BOX = 0,           /* src/rfilters/box.cpp      (radius 0.5) */
+       MI355_RFILTER_GAUSSIAN = 1,      /* src/rfilters/gaussian.cpp (radius 4*stddev) */
+       MI355_RFILTER_TENT = 2 };        /* src/rfilters/tent.cpp */
+
+enum { MI355_FILTER_NEAREST = 0, MI355_FILTER_BILINEAR = 1 };           /* bitmap.cpp:154-163 */
+enum { MI355_WRAP_REPEAT = 0, MI355_WRAP_MIRROR = 1, MI355_WRAP_CLAMP = 2 }; /* bitmap.cpp:165-176 */
+
+/* ---- scene description --------------------------------------------------------------- */
+
+/* `bitmap` texture (src/textures/bitmap.cpp): H x W x C float32 tensor, raw=true semantics. */
+typedef struct mi355_texture_desc {
+    uint32_t width, height, channels;   /* channels: 1 or 3 */
+    uint32_t filter;                    /* MI355_FILTER_* */
+    uint32_t wrap;                      /* MI355_WRAP_*   */
+    float    to_uv[6];                  /* row-major 2x3 affine uv transform (bitmap.cpp:701) */
+    const float *data;                  /* host, height*width*channels                        */
+} mi355_texture_desc;
+
+typedef struct mi355_bsdf_desc {
+    uint32_t type;                      /* MI355_BSDF_* */
+    float    reflectance[3];            /* diffuse: `reflectance.value` (srgb.cpp:70-72); conductor: specular_reflectance */
+    int32_t  reflectance_texture;       /* index into textures[] or -1 (constant colour) */
+    float    alpha_u, alpha_v;          /* roughconductor */
+    uint32_t distribution;              /* 0 beckmann, 1 ggx */
+    float    eta[3], k[3];              /* roughconductor complex IOR */
+    float    int_ior, ext_ior;          /* dielectric */
+    uint32_t sample_visible;
+} mi355_bsdf_desc;
+
+typedef struct mi355_emitter_desc {
+    uint32_t type;                      /* MI355_EMITTER_AREA */
+    float    radiance[3];               /* `radiance.value` (area.cpp:78-81) */
+    uint32_t shape;                     /* index of the shape this emitter is attached to */
+} mi355_emitter_desc;
+
+typedef struct mi355_shape_desc {
+    uint32_t type;                      /* MI355_SHAPE_* */
+    uint32_t bsdf;                      /* index into bsdfs[] */
+    int32_t  emitter;                   /* index into emitters[] or -1 */
+    uint32_t flip_normals;
+    float    to_world[12];              /* rectangle / sphere: object->world (rectangle.cpp:115-126) */
+    float    to_object[12];             /* its inverse as held by the shape (m_to_object) */
+    /* mesh only: buffers exactly as Mesh exposes them (include/mitsuba/render/mesh.h:523-527),
+       already in world space (cube.cpp:139-152) */
+    uint32_t vertex_count, face_count;
+    const float    *vertex_positions;   /* 3*vertex_count */
+    const float    *vertex_normals;     /* 3*vertex_count or NULL */
+    const float    *vertex_texcoords;   /* 2*vertex_count or NULL */
+    const uint32_t *faces;              /* 3*face_count */
+} mi355_shape_desc;
+
+typedef struct mi355_sensor_desc {
+    uint32_t type;                      /* MI355_SENSOR_* */
+    float    to_world[12];              /* camera->world, no scale (perspective.cpp:144-145) */
+    float    x_fov;                     /* degrees, after parse_fov (sensor.cpp:149-199) */
+    float    near_clip, far_clip;
+    uint32_t film_width, film_height;   /* Film::size */
+    uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height; /* Film::crop_* */
+    uint32_t rfilter;                   /* MI355_RFILTER_* */
+    float    rfilter_param;             /* gaussian: stddev (default 0.5); tent: radius */
+    /* realistic lens (src/sensors/realisticlens.cpp): sequential interface table */
+    uint32_t lens_count;
+    const float *lens_data;             /* lens_count x 8: curvature_radius, thickness(z offset), eta_d, abbe_V, aperture_radius, conic K, type, reserved */
+    float    film_diagonal;             /* physical film diagonal [m] */
+    float    focus_distance;
+} mi355_sensor_desc;
+
+typedef struct mi355_scene_desc {
+    uint32_t abi_version;               /* MI355_ABI_VERSION */
+    uint32_t n_shapes, n_bsdfs, n_emitters, n_textures;
+    const mi355_shape_desc   *shapes;
+    const mi355_bsdf_desc    *bsdfs;
+    const mi355_emitter_desc *emitters;
+    const mi355_texture_desc *textures;
+    mi355_sensor_desc         sensor;
+} mi355_scene_desc;
+
+/* ---- render parameters ---------------------------------------------------------------- */
+
+#define MI355_FLAG_HIDE_EMITTERS  1u   /* MonteCarloIntegrator::m_hide_emitters */
+#define MI355_FLAG_TIMING         2u   /* bracket the path kernel with HIP events on `stream` */
+
+enum { MI355_MODE_FUSED = 0,           /* one launch per pass, path state lives in registers */
+       MI355_MODE_WAVEFRONT = 1 };     /* SoA ray/hit/state streams + ballot compaction per bounce */
+
+enum { MI355_INTEGRATOR_PATH = 0,      /* src/integrators/path.cpp */
+       MI355_INTEGRATOR_PRB  = 1 };    /* src/python/python/ad/integrators/prb.py (primal estimator differs in RR timing) */
+
+typedef struct mi355_render_params {
+    uint32_t seed;                      /* the `seed` argument of Integrator::render */
+    uint32_t spp;                       /* samples per pixel of the WHOLE job (defines global lane ids) */
+    int32_t  max_depth;                 /* -1 = unbounded (integrator.cpp:510-514) */
+    int32_t  rr_depth;                  /* default 5 */
+    uint32_t flags;                     /* MI355_FLAG_* */
+    uint32_t mode;                      /* MI355_MODE_* */
+    uint32_t integrator;                /* MI355_INTEGRATOR_* (selects which primal estimator is replayed) */
+    /* shard of the sample plane processed by THIS call (one rank of a multi-GPU job).
+       Global lane id = pixel*spp + s  (integrator.cpp:293-305); the shard is the set
+       { pixel in [pixel_begin, pixel_begin+pixel_count) } x { s in [spp_begin, spp_begin+spp_count) }.
+       Zero counts mean "everything". */
+    uint32_t pixel_begin, pixel_count;
+    uint32_t spp_begin, spp_count;
+} mi355_render_params;
+
+/* Per-event device counters behind the algorithmic-byte formula of SURVEY.md 8(d). */
+typedef struct mi355_counters {
+    uint64_t n_gen, n_isect, n_shade, n_shadow, n_splat;
+    float    kernel_ms;                 /* HIP-event duration of the last timed path kernel (MI355_FLAG_TIMING) */
+    uint32_t kernel_launches;           /* launches covered by kernel_ms */
+} mi355_counters;
+
+/* One differentiable parameter (ParamFlags::Differentiable in traverse()). */
+enum { MI355_PARAM_BSDF_REFLECTANCE = 0,   /* 3 floats      diffuse.cpp:97-99 / srgb.cpp:70-72 */
+       MI355_PARAM_TEXTURE_DATA     = 1,   /* H*W*C floats  bitmap.cpp:308-311 */
+       MI355_PARAM_EMITTER_RADIANCE = 2 }; /* 3 floats      area.cpp:78-81 */
+
+typedef struct mi355_param_info {
+    uint32_t kind;                      /* MI355_PARAM_* */
+    uint32_t index;                     /* bsdf / texture / emitter index */
+    uint64_t offset;                    /* offset (in floats) inside the concatenated gradient buffer */
+    uint64_t size;                      /* number of floats */
+} mi355_param_info;
+
+typedef struct mi355_scene mi355_scene;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+const char *mi355_last_error(void);
+uint32_t    mi355_abi_version(void);
+
+/* Flatten + upload a scene replica onto HIP device `device`.  (Scene ctor + accel build,
+   src/render/scene.cpp:30-140) */
+int mi355_scene_create(const mi355_scene_desc *desc, int device, mi355_scene **out);
+int mi355_scene_destroy(mi355_scene *scene);
+
+/* SceneParameters.update for one parameter (util.py:185-232).  `values` is HOST memory. */
+int mi355_scene_set_param(mi355_scene *scene, uint32_t kind, uint32_t index,
+                          const float *values, uint64_t count);
+/* Same, `d_values` is DEVICE memory (optimiser state that already lives in HBM). */
+int mi355_scene_set_param_device(mi355_scene *scene, uint32_t kind, uint32_t index,
+                                 const float *d_values, uint64_t count, void *stream);
+
+/* Layout of the concatenated parameter-gradient buffer.  Returns the number of
+   parameters; fills at most `capacity` entries. */
+int mi355_scene_param_layout(const mi355_scene *scene, mi355_param_info *out, uint32_t capacity,
+                             uint64_t *total_floats);
+
+/* ---- forward path (Integrator::render) ----------------------------------------------------- */
+
+/* Accumulate this shard's samples into the RGBW film accumulator (crop_h x crop_w x 4 fp32,
+   DEVICE).  Equivalent to render_sample + ImageBlock::put for every lane of the shard
+   (integrator.cpp:419-491, imageblock.cpp:418-531).  The accumulator is NOT cleared. */
+int mi355_render_accumulate(mi355_scene *scene, const mi355_render_params *p,
+                            float *d_film_rgbw, void *stream);
+
+/* HDRFilm::develop (hdrfilm.cpp:304-409): rgb / (W==0 ? 1 : W) -> crop_h x crop_w x 3 (DEVICE). */
+int mi355_film_develop(mi355_scene *scene, const float *d_film_rgbw, float *d_image_rgb, void *stream);
+
+/* clear + accumulate + develop in one call: what Integrator::render returns. */
+int mi355_render(mi355_scene *scene, const mi355_render_params *p,
+                 float *d_film_rgbw, float *d_image_rgb, void *stream);
+
+/* ---- PRB adjoint path (RBIntegrator.render_backward) ------------------------------------------- */
+
+/* Step 1a (common.py:741-758): splat weight 1 for every lane of the shard ->
+   d_weight (crop_h x crop_w fp32, DEVICE, accumulated).  Multi-GPU jobs all-reduce this
+   buffer before step 2 so that every rank sees the same W[p]. */
+int mi355_prb_splat_weights(mi355_scene *scene, const mi355_render_params *p,
+                            float *d_weight, void *stream);
+
+/* Steps 1b-3 (common.py:741-796, prb.py:59-257): deltaL = adjoint of splat/develop from
+   d_grad_in (crop_h x crop_w x 3) and d_weight; primal replay; adjoint replay with the same
+   RNG streams; parameter gradients are ACCUMULATED into d_grad_params (layout:
+   mi355_scene_param_layout).  Multi-GPU jobs all-reduce d_grad_params afterwards. */
+int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
+                          const float *d_grad_in, const float *d_weight,
+                          float *d_grad_params, void *stream);
+
+/* ---- introspection -------------------------------------------------------------------------- */
+int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
+
+/* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):
+   d_out = count x 4 (r,g,b,valid).  Used by the lane-exact parity tests
+   (check_vectorization, src/python/python/test/util.py:88-175). */
+int mi355_debug_lane_radiance(mi355_scene *scene, const mi355_render_params *p,
+                              uint32_t lane_begin, uint32_t count, float *d_out, void *stream);
+
+/* Closest-hit / any-hit queries on caller-provided rays (Scene::ray_intersect_preliminary /
+   ray_test, scene.cpp:192-210).  d_rays = n x 8 (o.xyz, d.xyz, maxt, pad);
+   d_hits = n x 8 (t, prim_u, prim_v, prim_index, shape_index, occluded, pad, pad) with the
+   integer fields bit-cast to float. */
+int mi355_debug_ray_intersect(mi355_scene *scene, const float *d_rays, uint32_t n,
+                              float *d_hits, void *stream);
+
+/* ---- host-side pure helpers (no GPU needed; exposed so their KATs run on CPU) ------------------- */
+
+/* perspective_projection (include/mitsuba/render/sensor.h:228-265): 4x4 row-major camera->sample. */
+void mi355_perspective_projection(const int32_t film_size[2], const int32_t crop_size[2],
+                                  const int32_t crop_offset[2], float fov_x,
+                                  float near_clip, float far_clip, float out_matrix[16]);
+/* GaussianFilter coefficient table (gaussian.cpp:59-86): 10 Estrin coefficients in x^2. */
+void mi355_gaussian_coeffs(float stddev, float out_coeff[10]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_H */

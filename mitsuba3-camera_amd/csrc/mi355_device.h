@@ -1,0 +1,697 @@
+// mi355_device.h -- device-side building blocks of the gfx950 path-tracing / PRB engine.
+//
+// Written for CDNA4 only (64-lane waves, scalar unit, LDS).  Design notes:
+//   * scene records (shapes, triangles, BVH nodes) are indexed by WAVE-UNIFORM loop counters,
+//     so the compiler fetches them with s_load into SGPRs and the per-lane work is pure VALU;
+//   * per-lane path state lives in VGPRs for the whole path (fused mode) or in SoA streams
+//     (wavefront mode, mi355_wavefront.hip);
+//   * arithmetic mirrors the reference's Dr.Jit expressions: dot/cross/matrix products are
+//     explicit fma chains and the translation unit is compiled with -ffp-contract=off, so
+//     a lane computes the same numbers as the CPU oracle up to rcp/sqrt/sincos rounding.
+//
+// Reference citations are relative to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355.h"
+
+#define MI_EPS        5.9604644775390625e-8f
+#define MI_RAY_EPS    (MI_EPS * 1500.f)                 // include/mitsuba/core/math.h:17-23
+#define MI_SHADOW_EPS (MI_RAY_EPS * 10.f)
+#define MI_PI         3.14159265358979323846f
+#define MI_INV_PI     0.31830988618379067154f
+#define MI_LARGEST    3.402823466e+38f
+#define MI_INF        __builtin_huge_valf()
+
+#define MI_DEV static __device__ __forceinline__
+
+// -------------------------------------------------------------------------------------------
+// device scene records (host builds them in mi355_engine.hip::build_device_scene)
+// -------------------------------------------------------------------------------------------
+#define DSHAPE_FLIP      1u
+#define DSHAPE_HAS_NRM   2u
+#define DSHAPE_HAS_UV    4u
+
+struct DShape {                      // 176 B, read through the scalar cache
+    uint32_t type, bsdf; int32_t emitter; uint32_t flags;
+    float to_object[12];
+    float to_world[12];
+    float frame_s[3], frame_t[3], frame_n[3]; float inv_area;   // rectangle.cpp:115-126
+    uint32_t tri_offset, tri_count;  // into DScene::tris / faces (mesh)
+    uint32_t vtx_offset;             // into positions/normals/texcoords
+    int32_t  bvh_root;               // -1: scan the triangles linearly
+    float bbox_min[3], bbox_max[3];
+    uint32_t pad[2];
+};
+struct DTri { float p0[3], e1[3], e2[3]; };               // mesh.h:438: e1 = p1-p0, e2 = p2-p0 precomputed (same arithmetic)
+struct DBvhNode {                                          // binary BVH over one mesh's triangles
+    float lo[3]; uint32_t left;                            // inner: children = left, left+1; leaf: first triangle
+    float hi[3]; uint32_t count;                           // 0 = inner node, else number of triangles
+};
+struct DBsdf { uint32_t type; float reflectance[3]; int32_t texture; int32_t grad_slot; uint32_t pad[2]; };
+struct DEmitter { uint32_t type; float radiance[3]; uint32_t shape; int32_t grad_slot; uint32_t pad[2]; };
+struct DTexture { uint32_t w, h, c, filter, wrap; int32_t grad_slot; uint64_t data_offset; uint64_t grad_offset; float to_uv[6]; };
+
+struct DScene {
+    uint32_t n_shapes, n_bsdfs, n_emitters, n_textures;
+    const DShape   *shapes;
+    const DTri     *tris;         // traversal order (BVH leaves are contiguous)
+    const uint32_t *tri_face;     // traversal slot -> original face id (the reference's prim_index)
+    const uint32_t *faces;        // 3 per triangle in ORIGINAL face order, mesh-local vertex ids
+    const float    *positions;    // 3 per vertex (all meshes concatenated)
+    const float    *normals;      // 3 per vertex (zeros when the mesh has none)
+    const float    *texcoords;    // 2 per vertex
+    const DBvhNode *bvh;
+    const DBsdf    *bsdfs;
+    const DEmitter *emitters;
+    const DTexture *textures;
+    const float    *texdata;      // all texture tensors concatenated
+    // sensor + film
+    float sample_to_camera[16];
+    float cam_to_world[12];
+    float near_clip, far_clip;
+    uint32_t crop_w, crop_h, crop_x, crop_y;
+    uint32_t rfilter; float filter_radius; float filter_coeff[10];
+    float inv_emitter_count;
+};
+
+// -------------------------------------------------------------------------------------------
+// small vector math with Dr.Jit's operation order
+// -------------------------------------------------------------------------------------------
+struct v3 { float x, y, z; };
+struct v2 { float x, y; };
+MI_DEV v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+MI_DEV v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MI_DEV v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MI_DEV v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+MI_DEV v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+MI_DEV v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+MI_DEV v3 fma3s(v3 a, float s, v3 c) { return V3(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
+MI_DEV v3 fma3(v3 a, v3 b, v3 c) { return V3(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
+MI_DEV float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+MI_DEV v3 cross3(v3 a, v3 b) {
+    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+MI_DEV float rcp_(float x) { return 1.0f / x; }
+MI_DEV float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+MI_DEV float sqnorm3(v3 a) { return dot3(a, a); }
+MI_DEV float norm3(v3 a) { return sqrtf(dot3(a, a)); }
+MI_DEV v3 normalize3(v3 a) { return a * rsqrt_(sqnorm3(a)); }
+MI_DEV float max3(v3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+MI_DEV float mulsign(float a, float b) {
+    return __uint_as_float(__float_as_uint(a) ^ (__float_as_uint(b) & 0x80000000u));
+}
+MI_DEV v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
+
+// include/mitsuba/core/vector.h:116-136
+MI_DEV void coordinate_system(v3 n, v3 &s, v3 &t) {
+    float sign = copysignf(1.0f, n.z), a = -rcp_(sign + n.z), b = n.x * n.y * a;
+    s = V3(mulsign((n.x * n.x) * a, n.z) + 1.0f, mulsign(b, n.z), mulsign(-n.x, n.z));
+    t = V3(b, fmaf(n.y, n.y * a, sign), -n.y);
+}
+// include/mitsuba/core/transform.h:98-141 (row-major 3x4)
+MI_DEV v3 xf_point(const float *m, v3 p) {
+    v3 r = V3(m[3], m[7], m[11]);
+    r = fma3s(V3(m[0], m[4], m[8]), p.x, r);
+    r = fma3s(V3(m[1], m[5], m[9]), p.y, r);
+    r = fma3s(V3(m[2], m[6], m[10]), p.z, r);
+    return r;
+}
+MI_DEV v3 xf_vector(const float *m, v3 v) {
+    v3 r = V3(m[0], m[4], m[8]) * v.x;
+    r = fma3s(V3(m[1], m[5], m[9]), v.y, r);
+    r = fma3s(V3(m[2], m[6], m[10]), v.z, r);
+    return r;
+}
+
+// -------------------------------------------------------------------------------------------
+// RNG: TEA-seeded PCG32 per lane (random.h:76-91, sampler.cpp:116-135, independent.cpp:88-97)
+// -------------------------------------------------------------------------------------------
+struct Pcg32 { uint64_t state, inc; };
+MI_DEV void tea32(uint32_t &v0, uint32_t &v1) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+}
+MI_DEV uint32_t pcg32_next(Pcg32 &r) {
+    uint64_t old = r.state;
+    r.state = old * 0x5851f42d4c957f2dULL + r.inc;
+    uint32_t xorshift = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t) (old >> 59u);
+    return (xorshift >> rot) | (xorshift << ((~rot + 1u) & 31u));
+}
+MI_DEV void sampler_seed(Pcg32 &r, uint32_t seed, uint32_t lane) {
+    uint32_t v0 = seed, v1 = lane; tea32(v0, v1);
+    r.state = 0; r.inc = ((uint64_t) v1 << 1u) | 1u;
+    pcg32_next(r); r.state += (uint64_t) v0; pcg32_next(r);
+}
+MI_DEV float next_1d(Pcg32 &r) { return __uint_as_float((pcg32_next(r) >> 9) | 0x3f800000u) - 1.0f; }
+
+// -------------------------------------------------------------------------------------------
+// warps and filters
+// -------------------------------------------------------------------------------------------
+// include/mitsuba/core/warp.h:54-90, 412-420
+MI_DEV v3 square_to_cosine_hemisphere(float sx, float sy) {
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    bool is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * MI_PI * rp / r;
+    if (q13) phi = 0.5f * MI_PI - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; sincosf(phi, &sn, &cs);
+    float px = r * cs, py = r * sn;
+    float sq = fmaf(py, py, px * px);
+    return V3(px, py, sqrtf(fmaxf(1.f - sq, 0.f)));
+}
+// Dr.Jit estrin_impl for 10 coefficients; src/rfilters/gaussian.cpp:88-98
+MI_DEV float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]),
+          a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+    float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2);
+    float c0 = fmaf(x4, b1, b0);
+    return fmaf(x8, a4, c0);
+}
+MI_DEV float filter_eval(const DScene &sc, float x) {
+    if (sc.rfilter == MI355_RFILTER_GAUSSIAN) return fmaxf(estrin10(x * x, sc.filter_coeff), 0.f);
+    return fmaxf(0.f, 1.f - fabsf(x * (1.f / sc.filter_radius)));       // tent
+}
+MI_DEV float mis_weight(float a, float b) {                              // path.cpp:300-305
+    a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f;
+}
+
+// -------------------------------------------------------------------------------------------
+// rays, hits
+// -------------------------------------------------------------------------------------------
+struct Ray { v3 o, d; float maxt; };
+struct Hit { float t; float u, v; uint32_t prim, shape; };              // PreliminaryIntersection, interaction.h:570-675
+struct SI {                                                             // SurfaceInteraction, interaction.h:171-492
+    float t; v3 p, n; v2 uv; v3 sh_s, sh_t, sh_n; v3 wi; uint32_t prim; int32_t shape;
+};
+MI_DEV v3 ray_at(const Ray &r, float t) { return fma3s(r.d, t, r.o); }
+
+// Rectangle::ray_intersect_preliminary_impl, rectangle.cpp:446-468
+MI_DEV bool rect_intersect(const DShape &sh, const Ray &ray, float &t, float &u, float &v) {
+    v3 o = xf_point(sh.to_object, ray.o), d = xf_vector(sh.to_object, ray.d);
+    t = -o.z / d.z;
+    u = fmaf(d.x, t, o.x); v = fmaf(d.y, t, o.y);
+    return t >= 0.f && t <= ray.maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
+}
+// Mesh::moeller_trumbore, mesh.h:430-453
+MI_DEV bool tri_intersect(const DTri &tr, const Ray &ray, float &t, float &u, float &v) {
+    v3 p0 = ld3(tr.p0), e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    v3 pvec = cross3(ray.d, e2);
+    float inv_det = rcp_(dot3(e1, pvec));
+    v3 tvec = ray.o - p0;
+    u = dot3(tvec, pvec) * inv_det;
+    v3 qvec = cross3(tvec, e1);
+    v = dot3(ray.d, qvec) * inv_det;
+    t = dot3(e2, qvec) * inv_det;
+    return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= ray.maxt;
+}
+// conservative slab test against a (wave-uniform) box; used only to SKIP work, never to decide a hit
+MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv_d) {
+    float t0x = (lo[0] - ray.o.x) * inv_d.x, t1x = (hi[0] - ray.o.x) * inv_d.x;
+    float t0y = (lo[1] - ray.o.y) * inv_d.y, t1y = (hi[1] - ray.o.y) * inv_d.y;
+    float t0z = (lo[2] - ray.o.z) * inv_d.z, t1z = (hi[2] - ray.o.z) * inv_d.z;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), ray.maxt));
+    return tn <= tf * 1.00001f + 1e-6f;
+}
+
+#define MI_BVH_STACK 24
+// Per-lane BVH traversal of one mesh.  The short stack lives in LDS, laid out [level][lane] so that
+// the 64 lanes of a wave touch 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32);
+// `stk` already points at this lane's column.  Node boxes are re-tested on pop against the
+// current ray.maxt, so a closer hit prunes everything behind it.
+#define MI_STK(i) stk[(i) * 64]
+MI_DEV void mesh_closest(const DScene &sc, const DShape &sh, uint32_t shape_index, Ray &ray, v3 inv_d, Hit &hit,
+                         bool active, uint32_t *stk) {
+    if (sh.bvh_root < 0) {
+        bool in_box = active && box_overlap(sh.bbox_min, sh.bbox_max, ray, inv_d);
+        if (!__any(in_box)) return;
+        for (uint32_t f = 0; f < sh.tri_count; ++f) {
+            float t, u, v;
+            if (in_box && tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v) && t < hit.t) {
+                hit.t = t; hit.u = u; hit.v = v; hit.prim = f; hit.shape = shape_index; ray.maxt = t;
+            }
+        }
+        return;
+    }
+    int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
+    while (have) {
+        DBvhNode nd = sc.bvh[node];
+        bool descend = false;
+        if (box_overlap(nd.lo, nd.hi, ray, inv_d)) {
+            if (nd.count) {
+                for (uint32_t k = 0; k < nd.count; ++k) {
+                    uint32_t f = nd.left + k; float t, u, v;
+                    if (tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v) && t < hit.t) {
+                        hit.t = t; hit.u = u; hit.v = v; hit.prim = f; hit.shape = shape_index; ray.maxt = t;
+                    }
+                }
+            } else if (sp < MI_BVH_STACK) { MI_STK(sp) = nd.left + 1; sp++; node = nd.left; descend = true; }
+        }
+        if (!descend) { if (sp > 0) { --sp; node = MI_STK(sp); } else have = false; }
+    }
+}
+MI_DEV bool mesh_any(const DScene &sc, const DShape &sh, const Ray &ray, v3 inv_d, bool active, uint32_t *stk) {
+    bool occluded = false;
+    if (sh.bvh_root < 0) {
+        bool in_box = active && box_overlap(sh.bbox_min, sh.bbox_max, ray, inv_d);
+        if (!__any(in_box)) return false;
+        for (uint32_t f = 0; f < sh.tri_count; ++f) {
+            float t, u, v;
+            if (in_box && !occluded && tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v)) occluded = true;
+        }
+        return occluded;
+    }
+    int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
+    while (have) {
+        DBvhNode nd = sc.bvh[node];
+        bool descend = false;
+        if (box_overlap(nd.lo, nd.hi, ray, inv_d)) {
+            if (nd.count) {
+                for (uint32_t k = 0; k < nd.count; ++k) {
+                    float t, u, v;
+                    if (tri_intersect(sc.tris[sh.tri_offset + nd.left + k], ray, t, u, v)) occluded = true;
+                }
+                if (occluded) break;
+            } else if (sp < MI_BVH_STACK) { MI_STK(sp) = nd.left + 1; sp++; node = nd.left; descend = true; }
+        }
+        if (!descend) { if (sp > 0) { --sp; node = MI_STK(sp); } else have = false; }
+    }
+    return occluded;
+}
+
+// Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
+MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
+    Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
+    v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+    for (uint32_t i = 0; i < sc.n_shapes; ++i) {
+        const DShape &sh = sc.shapes[i];
+        if (sh.type == MI355_SHAPE_RECTANGLE) {
+            float t, u, v;
+            if (active && rect_intersect(sh, ray, t, u, v) && t < hit.t) {
+                hit.t = t; hit.u = u; hit.v = v; hit.prim = 0; hit.shape = i; ray.maxt = t;
+            }
+        } else mesh_closest(sc, sh, i, ray, inv_d, hit, active, stk);
+    }
+    if (hit.shape != 0xffffffffu && sc.shapes[hit.shape].type == MI355_SHAPE_MESH)
+        hit.prim = sc.tri_face[sc.shapes[hit.shape].tri_offset + hit.prim];
+    return hit;
+}
+// Scene::ray_test (scene.cpp:201-210): any hit.
+MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32_t *stk) {
+    bool occluded = false;
+    v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+    for (uint32_t i = 0; i < sc.n_shapes; ++i) {
+        if (!__any(active && !occluded)) break;
+        const DShape &sh = sc.shapes[i];
+        if (sh.type == MI355_SHAPE_RECTANGLE) {
+            float t, u, v;
+            if (active && !occluded && rect_intersect(sh, ray, t, u, v)) occluded = true;
+        } else occluded = mesh_any(sc, sh, ray, inv_d, active && !occluded, stk) || occluded;
+    }
+    return occluded;
+}
+
+// PreliminaryIntersection::compute_surface_interaction (interaction.h:642-668) ->
+// Rectangle / Mesh::compute_surface_interaction (rectangle.cpp:497-567 IsDiff branch, mesh.cpp:1375-1548)
+// -> finalize_surface_interaction (interaction.h:464-484).  Caller guarantees hit.t != inf.
+MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
+    SI si; si.t = hit.t; si.shape = (int32_t) hit.shape; si.prim = hit.prim;
+    const DShape &sh = sc.shapes[hit.shape];                               // per-lane gather (divergent index)
+    v3 dp_du, dp_dv;
+    if (sh.type == MI355_SHAPE_RECTANGLE) {
+        si.p = ray_at(ray, hit.t);
+        si.n = ld3(sh.frame_n); si.sh_n = si.n; dp_du = ld3(sh.frame_s); dp_dv = ld3(sh.frame_t);
+        si.uv.x = fmaf(hit.u, .5f, .5f); si.uv.y = fmaf(hit.v, .5f, .5f);
+    } else {
+        const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + hit.prim);
+        uint32_t i0 = sh.vtx_offset + fi[0], i1 = sh.vtx_offset + fi[1], i2 = sh.vtx_offset + fi[2];
+        v3 p0 = ld3(sc.positions + 3 * (size_t) i0), p1 = ld3(sc.positions + 3 * (size_t) i1), p2 = ld3(sc.positions + 3 * (size_t) i2);
+        v3 dp0 = p1 - p0, dp1 = p2 - p0;
+        float b1 = hit.u, b2 = hit.v, b0 = 1.f - b1 - b2;
+        si.p = fma3s(p0, b0, fma3s(p1, b1, p2 * b2));
+        si.n = normalize3(cross3(dp0, dp1));
+        si.uv.x = b1; si.uv.y = b2;
+        coordinate_system(si.n, dp_du, dp_dv);
+        if (sh.flags & DSHAPE_HAS_UV) {
+            const float *t0 = sc.texcoords + 2 * (size_t) i0, *t1 = sc.texcoords + 2 * (size_t) i1, *t2 = sc.texcoords + 2 * (size_t) i2;
+            v2 uv0 = { t0[0], t0[1] }, uv1 = { t1[0], t1[1] }, uv2 = { t2[0], t2[1] };
+            si.uv.x = fmaf(uv2.x, b2, fmaf(uv1.x, b1, uv0.x * b0));
+            si.uv.y = fmaf(uv2.y, b2, fmaf(uv1.y, b1, uv0.y * b0));
+            v2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+            float det = fmaf(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcp_(det);
+            if (det != 0.f) {
+                dp_du = V3(fmaf(duv1.y, dp0.x, -(duv0.y * dp1.x)), fmaf(duv1.y, dp0.y, -(duv0.y * dp1.y)), fmaf(duv1.y, dp0.z, -(duv0.y * dp1.z))) * inv_det;
+                dp_dv = V3(fmaf(-duv1.x, dp0.x, duv0.x * dp1.x), fmaf(-duv1.x, dp0.y, duv0.x * dp1.y), fmaf(-duv1.x, dp0.z, duv0.x * dp1.z)) * inv_det;
+            }
+        }
+        if (sh.flags & DSHAPE_HAS_NRM) {
+            v3 n0 = ld3(sc.normals + 3 * (size_t) i0), n1 = ld3(sc.normals + 3 * (size_t) i1), n2 = ld3(sc.normals + 3 * (size_t) i2);
+            v3 n = fma3s(n2, b2, fma3s(n1, b1, n0 * b0));
+            si.sh_n = n * rsqrt_(sqnorm3(n));
+        } else si.sh_n = si.n;
+        if (sh.flags & DSHAPE_FLIP) { si.n = -si.n; si.sh_n = -si.sh_n; }
+    }
+    si.sh_s = normalize3(fma3s(si.sh_n, -dot3(si.sh_n, dp_du), dp_du));   // interaction.h:245-255
+    if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { v3 tt; coordinate_system(si.sh_n, si.sh_s, tt); }
+    si.sh_t = cross3(si.sh_n, si.sh_s);
+    v3 md = -ray.d;
+    si.wi = V3(dot3(md, si.sh_s), dot3(md, si.sh_t), dot3(md, si.sh_n));
+    return si;
+}
+MI_DEV v3 si_to_world(const SI &si, v3 v) { return fma3s(si.sh_n, v.z, fma3s(si.sh_t, v.y, si.sh_s * v.x)); }
+MI_DEV v3 si_to_local(const SI &si, v3 v) { return V3(dot3(v, si.sh_s), dot3(v, si.sh_t), dot3(v, si.sh_n)); }
+MI_DEV v3 offset_p(v3 p, v3 n, v3 d) {                                    // interaction.h:158-162
+    float mag = (1.f + fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z))) * MI_RAY_EPS;
+    mag = mulsign(mag, dot3(n, d));
+    return fma3s(n, mag, p);
+}
+MI_DEV Ray spawn_ray(v3 p, v3 n, v3 d) { Ray r; r.o = offset_p(p, n, d); r.d = d; r.maxt = MI_LARGEST; return r; }
+MI_DEV Ray spawn_ray_to(v3 p, v3 n, v3 target) {                          // interaction.h:138-145
+    Ray r; r.o = offset_p(p, n, target - p);
+    v3 d = target - r.o; float dist = norm3(d);
+    r.d = d * rcp_(dist); r.maxt = dist * (1.f - MI_SHADOW_EPS); return r;
+}
+
+// -------------------------------------------------------------------------------------------
+// textures / BSDF / emitters
+// -------------------------------------------------------------------------------------------
+MI_DEV int32_t wrap_i(int32_t p, int32_t n, uint32_t mode) {
+    if (mode == MI355_WRAP_CLAMP) return p < 0 ? 0 : (p > n - 1 ? n - 1 : p);
+    if (mode == MI355_WRAP_REPEAT) { int32_t m = p % n; return m < 0 ? m + n : m; }
+    int32_t m = p % (2 * n); if (m < 0) m += 2 * n; return m < n ? m : 2 * n - 1 - m;
+}
+struct TexTaps { int32_t idx[4]; float w[4]; };
+// BitmapTexture::interpolate_3, bitmap.cpp:696-710 (dr::Texture2f::eval: pos = uv*res - 0.5, 4-tap lerp)
+MI_DEV v3 texture_eval(const DScene &sc, const DTexture &t, v2 uv_in, TexTaps *taps) {
+    float ux = fmaf(t.to_uv[0], uv_in.x, fmaf(t.to_uv[1], uv_in.y, t.to_uv[2]));
+    float uy = fmaf(t.to_uv[3], uv_in.x, fmaf(t.to_uv[4], uv_in.y, t.to_uv[5]));
+    int32_t W = (int32_t) t.w, H = (int32_t) t.h, C = (int32_t) t.c;
+    const float *data = sc.texdata + t.data_offset;
+    float out[3];
+    if (t.filter == MI355_FILTER_NEAREST) {
+        int32_t x = wrap_i((int32_t) floorf(ux * (float) W), W, t.wrap), y = wrap_i((int32_t) floorf(uy * (float) H), H, t.wrap);
+        for (int c = 0; c < 3; ++c) out[c] = data[(y * W + x) * C + (C == 3 ? c : 0)];
+        if (taps) { taps->idx[0] = y * W + x; taps->w[0] = 1.f; taps->idx[1] = taps->idx[2] = taps->idx[3] = -1; taps->w[1] = taps->w[2] = taps->w[3] = 0.f; }
+        return V3(out[0], out[1], out[2]);
+    }
+    float px = fmaf(ux, (float) W, -.5f), py = fmaf(uy, (float) H, -.5f);
+    float fx = floorf(px), fy = floorf(py);
+    int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    int32_t x0 = wrap_i(ix, W, t.wrap), x1 = wrap_i(ix + 1, W, t.wrap), y0 = wrap_i(iy, H, t.wrap), y1 = wrap_i(iy + 1, H, t.wrap);
+    int32_t i00 = y0 * W + x0, i10 = y0 * W + x1, i01 = y1 * W + x0, i11 = y1 * W + x1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int cc = C == 3 ? c : 0;
+        float v00 = data[i00 * C + cc], v10 = data[i10 * C + cc], v01 = data[i01 * C + cc], v11 = data[i11 * C + cc];
+        out[c] = fmaf(w0y, fmaf(w0x, v00, w1x * v10), w1y * fmaf(w0x, v01, w1x * v11));
+    }
+    if (taps) { taps->idx[0] = i00; taps->idx[1] = i10; taps->idx[2] = i01; taps->idx[3] = i11;
+                taps->w[0] = w0y * w0x; taps->w[1] = w0y * w1x; taps->w[2] = w1y * w0x; taps->w[3] = w1y * w1x; }
+    return V3(out[0], out[1], out[2]);
+}
+// SmoothDiffuse::eval_pdf, diffuse.cpp:160-180
+MI_DEV void diffuse_eval_pdf(v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
+    active = active && wi.z > 0.f && wo.z > 0.f;
+    val = active ? (refl * MI_INV_PI) * wo.z : V3(0.f, 0.f, 0.f);
+    pdf = active ? MI_INV_PI * wo.z : 0.f;
+}
+// SmoothDiffuse::sample, diffuse.cpp:101-125 (JIT semantics: weight masked, fields always written)
+MI_DEV void diffuse_sample(v3 refl, v3 wi, float s2x, float s2y, bool active, v3 &wo, float &pdf, v3 &weight) {
+    active = active && wi.z > 0.f;
+    wo = square_to_cosine_hemisphere(s2x, s2y);
+    pdf = MI_INV_PI * wo.z;
+    weight = (active && pdf > 0.f) ? refl : V3(0.f, 0.f, 0.f);
+}
+
+struct DS { v3 p, n; float pdf; v3 d; float dist; int32_t emitter; };     // DirectionSample, records.h:93-195
+
+// Scene::sample_emitter_direction (scene.cpp:299-353) -> AreaLight::sample_direction (area.cpp:117-168)
+// -> Shape::sample_direction (shape.cpp:358-375) -> Rectangle::sample_position (rectangle.cpp:166-180).
+// The shadow ray is returned to the caller so that fused and wavefront modes can trace it their own way.
+MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, float sy, bool active, DS &ds, v3 &spec, Ray &shadow) {
+    ds.p = ds.n = ds.d = V3(0.f, 0.f, 0.f); ds.pdf = 0.f; ds.dist = 0.f; ds.emitter = -1; spec = V3(0.f, 0.f, 0.f);
+    if (sc.n_emitters == 0) return false;
+    uint32_t index = 0; float emitter_weight = 1.f;
+    if (sc.n_emitters > 1) {                                               // scene.cpp:227-250
+        float cf = (float) sc.n_emitters, scaled = sx * cf;
+        index = min((uint32_t) scaled, sc.n_emitters - 1u);
+        emitter_weight = cf; sx = scaled - (float) index;
+    }
+    const DEmitter &em = sc.emitters[index];
+    const DShape &sh = sc.shapes[em.shape];
+    ds.emitter = (int32_t) index;
+    if (sh.type != MI355_SHAPE_RECTANGLE) return false;
+    ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
+    ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
+    ds.d = ds.p - si.p;
+    float dist2 = sqnorm3(ds.d); ds.dist = sqrtf(dist2);
+    ds.d = ds.d * rcp_(ds.dist);
+    float dp = fabsf(dot3(ds.d, ds.n));
+    float x = dist2 / dp;
+    ds.pdf *= isfinite(x) ? x : 0.f;
+    active = active && dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;            // area.cpp:136
+    spec = active ? ld3(em.radiance) * rcp_(ds.pdf) : V3(0.f, 0.f, 0.f);
+    if (sc.n_emitters > 1) { ds.pdf *= sc.inv_emitter_count; spec = spec * emitter_weight; }
+    active = active && ds.pdf != 0.f;
+    if (active) shadow = spawn_ray_to(si.p, si.n, ds.p);
+    return active;                                                         // true: a shadow ray must be tested
+}
+// Scene::pdf_emitter_direction (scene.cpp:355-366) -> area.cpp:170-197 -> shape.cpp:377-388
+MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 d, v3 n, float dist) {
+    const DShape &sh = sc.shapes[sc.emitters[emitter].shape];
+    float dp = dot3(d, n);
+    if (!(dp < 0.f)) return 0.f;
+    float adp = fabsf(dp);
+    float pdf = sh.inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    return pdf * sc.inv_emitter_count;
+}
+
+// -------------------------------------------------------------------------------------------
+// primary rays: integrator.cpp:293-310,419-455; perspective.cpp:239-280
+// -------------------------------------------------------------------------------------------
+MI_DEV Ray sample_primary_ray(const DScene &sc, float pos_x, float pos_y) {
+    float sx = 1.f / (float) sc.crop_w, sy = 1.f / (float) sc.crop_h;
+    float ox = -(float) sc.crop_x * sx, oy = -(float) sc.crop_y * sy;
+    float ax = fmaf(pos_x, sx, ox), ay = fmaf(pos_y, sy, oy);
+    const float *m = sc.sample_to_camera;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], ax, v); v = fmaf(m[i*4+1], ay, v); v = fmaf(m[i*4+2], 0.f, v); r[i] = v; }
+    float iw = rcp_(r[3]);
+    v3 d = normalize3(V3(r[0] * iw, r[1] * iw, r[2] * iw));
+    const float *tw = sc.cam_to_world;
+    Ray ray; ray.d = xf_vector(tw, d);
+    float inv_z = rcp_(d.z), near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;
+    ray.o = V3(tw[3], tw[7], tw[11]) + ray.d * near_t;
+    ray.maxt = far_t - near_t;
+    return ray;
+}
+
+struct Counters3 { uint32_t isect, shade, shadow; };
+
+// -------------------------------------------------------------------------------------------
+// PathIntegrator::sample, src/integrators/path.cpp:95-287
+// -------------------------------------------------------------------------------------------
+MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
+                        bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt) {
+    v3 throughput = V3(1.f, 1.f, 1.f), result = V3(0.f, 0.f, 0.f); float eta = 1.f; uint32_t depth = 0;
+    bool valid_ray = false;                                                // no environment emitter, path.cpp:115
+    v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    active = active && max_depth != 0;
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        Hit hit = scene_intersect(sc, ray, active, stk);
+        if (active) cnt.isect++;
+        bool si_valid = active && hit.t != MI_INF;
+        bool active_next = si_valid && (depth + 1 < max_depth);            // path.cpp:177
+        active = false;
+        if (si_valid) {
+            cnt.shade++;
+            SI si = compute_si(sc, ray, hit);
+            const DShape &sh = sc.shapes[hit.shape];
+            int32_t emitter = sh.emitter;
+            if (emitter >= 0) {                                            // path.cpp:158-174
+                v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);   // records.h:173-180
+                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+                float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+                v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
+                result = fma3(throughput, le * mis_bsdf, result);
+            }
+            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
+            // ---- emitter sampling (path.cpp:186-208)
+            float ex = next_1d(rng), ey = next_1d(rng);
+            DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
+            bool need_shadow = sample_emitter_direction(sc, si, ex, ey, active_next, ds, em_weight, shadow);
+            // ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33)
+            float s1 = next_1d(rng); (void) s1; float s2x = next_1d(rng), s2y = next_1d(rng);
+            v3 wo = si_to_local(si, ds.d);
+            v3 bsdf_val; float bsdf_pdf; diffuse_eval_pdf(refl, si.wi, wo, true, bsdf_val, bsdf_pdf);
+            v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2x, s2y, true, bs_wo, bs_pdf, bsdf_weight);
+            v3 contrib = (bsdf_val * em_weight) * mis_weight(ds.pdf, bsdf_pdf);
+            bool occluded = scene_ray_test(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
+            if (need_shadow) cnt.shadow++;
+            if (need_shadow && !occluded) result = fma3(throughput, contrib, result);   // path.cpp:220-230
+            // ---- BSDF sampling + loop update (path.cpp:234-280)
+            ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
+            throughput = throughput * bsdf_weight;
+            valid_ray = true;
+            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
+            depth += 1;
+            float tmax = max3(throughput);
+            float rr_prob = fminf(tmax * (eta * eta), .95f);
+            bool rr_active = depth >= rr_depth, rr_continue = next_1d(rng) < rr_prob;
+            if (rr_active) throughput = throughput * rcp_(rr_prob);
+            active = active_next && (!rr_active || rr_continue) && tmax != 0.f;
+        }
+    }
+    result_out = valid_ray ? result : V3(0.f, 0.f, 0.f); valid_out = valid_ray;
+}
+
+// -------------------------------------------------------------------------------------------
+// PRBIntegrator.sample, src/python/python/ad/integrators/prb.py:59-257
+//   BACKWARD = false: primal estimator, returns L
+//   BACKWARD = true : replays the same RNG stream with L = state_in and accumulates
+//                     dL * d(Le + Lr_dir + Lr_ind)/d(theta) (closed form of prb.py:202-247)
+// Gradient sinks: `s_grad` = per-workgroup LDS accumulators for the "small" parameters
+// (constant reflectances, emitter radiances), `g_grad` = the global gradient buffer (textures).
+// -------------------------------------------------------------------------------------------
+struct GradSink { float *s_grad; float *g_grad; };
+
+template <bool BACKWARD>
+MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
+                       bool active, uint32_t *stk, v3 dL, v3 state_in, GradSink sink,
+                       v3 &L_out, bool &valid_out, Counters3 &cnt) {
+    uint32_t depth = 0; v3 L = BACKWARD ? state_in : V3(0.f, 0.f, 0.f); v3 beta = V3(1.f, 1.f, 1.f); float eta = 1.f;
+    v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        Hit hit = scene_intersect(sc, ray, active, stk);
+        if (active) cnt.isect++;
+        bool si_valid = active && hit.t != MI_INF;
+        bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
+        active = false;
+        if (si_valid) {
+            cnt.shade++;
+            SI si = compute_si(sc, ray, hit);
+            const DShape &sh = sc.shapes[hit.shape];
+            int32_t emitter = sh.emitter;
+            v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
+            if (emitter >= 0) {                                            // prb.py:126-134
+                v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
+                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+                le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
+                le_front = si.wi.z > 0.f;
+                v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
+                Le = (beta * le_mis) * e;
+            }
+            active_next = active_next && (depth + 1 < max_depth);          // prb.py:139
+            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+            TexTaps taps; v3 refl;
+            if (bsdf.texture >= 0) refl = texture_eval(sc, sc.textures[bsdf.texture], si.uv, BACKWARD ? &taps : nullptr);
+            else refl = ld3(bsdf.reflectance);
+            // ---- emitter sampling (prb.py:142-162)
+            float ex = next_1d(rng), ey = next_1d(rng);
+            DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
+            bool need_shadow = sample_emitter_direction(sc, si, ex, ey, active_next, ds, em_weight, shadow);
+            bool occluded = scene_ray_test(sc, shadow, need_shadow, stk);
+            if (need_shadow) cnt.shadow++;
+            bool active_em = need_shadow && !occluded;
+            if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
+            v3 wo = si_to_local(si, ds.d);
+            v3 bsdf_value_em; float bsdf_pdf_em; diffuse_eval_pdf(refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+            v3 Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
+            // ---- detached BSDF sampling (prb.py:166-169)
+            float s1 = next_1d(rng); (void) s1; float s2x = next_1d(rng), s2y = next_1d(rng);
+            v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2x, s2y, active_next, bs_wo, bs_pdf, bsdf_weight);
+            // ---- update (prb.py:173-182)
+            v3 beta_pre = beta;
+            L = BACKWARD ? (L - Le) - Lr_dir : (L + Le) + Lr_dir;
+            ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
+            beta = beta * bsdf_weight;
+            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
+            // ---- stopping criterion (prb.py:186-198)
+            float bmax = max3(beta);
+            active_next = active_next && bmax != 0.f;
+            float rr_prob = fminf(bmax * (eta * eta), .95f);
+            bool rr_active = depth >= rr_depth;
+            if (rr_active) beta = beta * rcp_(rr_prob);
+            bool rr_continue = next_1d(rng) < rr_prob;
+            active_next = active_next && (!rr_active || rr_continue);
+            if (BACKWARD) {                                                // prb.py:202-247
+                float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f;
+                v3 det = bsdf_weight * bs_pdf;
+                v3 inv = V3(det.x != 0.f ? rcp_(det.x) : 0.f, det.y != 0.f ? rcp_(det.y) : 0.f, det.z != 0.f ? rcp_(det.z) : 0.f);
+                float dval = ev_active ? MI_INV_PI * co : 0.f;
+                v3 dLo = (L * inv) * dval;                                 // d Lr_ind / d albedo
+                bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f;
+                float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
+                dLo = dLo + ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
+                v3 ga = dL * dLo;
+                if (bsdf.texture >= 0) {
+                    const DTexture &tx = sc.textures[bsdf.texture];
+                    if (tx.grad_slot >= 0 && sink.g_grad) {
+                        float *gb = sink.g_grad + tx.grad_offset;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (taps.idx[k] >= 0 && taps.w[k] != 0.f) {
+                            if (tx.c == 3) { atomicAdd(gb + taps.idx[k] * 3 + 0, taps.w[k] * ga.x); atomicAdd(gb + taps.idx[k] * 3 + 1, taps.w[k] * ga.y);
+                                             atomicAdd(gb + taps.idx[k] * 3 + 2, taps.w[k] * ga.z); }
+                            else atomicAdd(gb + taps.idx[k], taps.w[k] * (ga.x + ga.y + ga.z));
+                        }
+                    }
+                } else if (bsdf.grad_slot >= 0) {
+                    float *gb = sink.s_grad + bsdf.grad_slot;
+                    atomicAdd(gb + 0, ga.x); atomicAdd(gb + 1, ga.y); atomicAdd(gb + 2, ga.z);
+                }
+                if (emitter >= 0 && le_front && sc.emitters[emitter].grad_slot >= 0) {          // d Le / d radiance
+                    float *gb = sink.s_grad + sc.emitters[emitter].grad_slot;
+                    atomicAdd(gb + 0, dL.x * beta_pre.x * le_mis); atomicAdd(gb + 1, dL.y * beta_pre.y * le_mis);
+                    atomicAdd(gb + 2, dL.z * beta_pre.z * le_mis);
+                }
+                if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
+                    float *gb = sink.s_grad + sc.emitters[ds.emitter].grad_slot;
+                    v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
+                    atomicAdd(gb + 0, dL.x * w.x); atomicAdd(gb + 1, dL.y * w.y); atomicAdd(gb + 2, dL.z * w.z);
+                }
+            }
+            depth += 1;                                                    // prb.py:249
+            active = active_next;
+        }
+    }
+    L_out = L; valid_out = depth != 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// film: ImageBlock::put coalesced path (imageblock.cpp:418-531)
+// -------------------------------------------------------------------------------------------
+#define MI_MAX_TAPS 5
+struct Splat { int32_t x0, y0; int count; float wx[MI_MAX_TAPS], wy[MI_MAX_TAPS]; };
+MI_DEV Splat splat_weights(const DScene &sc, float pos_x, float pos_y) {
+    Splat s;
+    if (sc.rfilter == MI355_RFILTER_BOX) {                                 // imageblock.cpp:210-233
+        s.x0 = (int32_t) floorf(pos_x) - (int32_t) sc.crop_x; s.y0 = (int32_t) floorf(pos_y) - (int32_t) sc.crop_y;
+        s.count = 1; s.wx[0] = s.wy[0] = 1.f;
+#pragma unroll
+        for (int i = 1; i < MI_MAX_TAPS; ++i) s.wx[i] = s.wy[i] = 0.f;
+        return s;
+    }
+    int n = (int) ceilf(sc.filter_radius - .5f); s.count = 2 * n + 1;
+    int32_t pix = (int32_t) floorf(pos_x) - n, piy = (int32_t) floorf(pos_y) - n;
+    s.x0 = pix - (int32_t) sc.crop_x; s.y0 = piy - (int32_t) sc.crop_y;
+    float rx = (float) pix + .5f - pos_x, ry = (float) piy + .5f - pos_y;
+#pragma unroll
+    for (int i = 0; i < MI_MAX_TAPS; ++i) {
+        s.wx[i] = i < s.count ? filter_eval(sc, rx) : 0.f; s.wy[i] = i < s.count ? filter_eval(sc, ry) : 0.f;
+        rx += 1.f; ry += 1.f;
+    }
+    return s;
+}

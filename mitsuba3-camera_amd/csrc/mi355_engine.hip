@@ -1,0 +1,715 @@
+// mi355_engine.hip -- kernels and host side of the C ABI declared in include/mi355.h.
+//
+// Kernels (all gfx950, 256-thread workgroups = 4 waves of 64):
+//   k_render<INTEGRATOR, OUT>   one lane per camera path: TEA/PCG32 seed -> pixel jitter -> primary ray
+//                               -> PathIntegrator::sample / PRBIntegrator.sample (primal) in registers
+//                               -> per-pixel pre-reduced film splat through LDS (one atomic per tap+channel
+//                               per wave instead of 100 per lane)
+//   k_splat_weights             W[p] = sum of filter weights (PRB step 1a)
+//   k_prb_backward              dL gather -> primal replay -> adjoint replay; parameter gradients reduced in LDS
+//   k_develop                   HDRFilm::develop
+//   k_debug_intersect           Scene::ray_intersect_preliminary / ray_test on caller rays
+// There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
+#include "mi355_device.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+#include <numeric>
+
+#define BLOCK 256
+#define WAVES (BLOCK / 64)
+#define ROW_STRIDE 68                       // 64 lanes + 4 pad floats: 16-B aligned rows, shifts banks by 4 per row
+#define SPLAT_ROWS 29                       // 25 tap weights + 4 channel values
+#define WAVE_FLOATS (SPLAT_ROWS * ROW_STRIDE)
+#define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
+#define MAX_SMALL_GRAD 1024
+
+static_assert(WAVE_FLOATS >= STACK_WORDS, "BVH stack aliases the splat staging area");
+
+struct RenderArgs {
+    uint32_t seed, spp_total, max_depth, rr_depth, flags;
+    uint32_t pixel_begin, pixel_count, s_begin, s_count;
+    uint32_t n_local;          // pixel_count * s_count
+    uint32_t seg;              // lanes per pixel inside one wave for the LDS splat (0 = direct atomics)
+    uint32_t lane_begin;       // OUT_LANES only
+};
+
+enum { OUT_FILM = 0, OUT_LANES = 1 };
+
+// lane bookkeeping shared by all sampling kernels: integrator.cpp:293-310
+struct LaneInfo { bool act; uint32_t lane; int32_t px, py; uint32_t pixel; };
+MI_DEV LaneInfo lane_info(const DScene &sc, const RenderArgs &a, uint32_t i) {
+    LaneInfo li; li.act = i < a.n_local;
+    uint32_t ii = li.act ? i : 0;
+    li.pixel = a.pixel_begin + ii / a.s_count;
+    uint32_t s = a.s_begin + ii % a.s_count;
+    li.lane = li.pixel * a.spp_total + s;
+    uint32_t y = li.pixel / sc.crop_w;
+    li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
+    return li;
+}
+
+// Pre-reduced film splat.  All lanes of a wave that belong to the same pixel share one 5x5 footprint, so
+// the wave stages tap weights [25][64] and channel values [CH][64] in LDS and every (pixel, tap, channel)
+// output is summed by one lane and added to HBM with ONE atomic.  Lanes whose footprint differs from the
+// pixel's nominal one (pos rounds up to the next integer) fall back to their own atomics.
+template <int CH>
+MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, float *film,
+                       const LaneInfo &li, uint32_t i_wave_first, const Splat &sp, const float *values) {
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    const uint32_t lane_id = threadIdx.x & 63;
+    int n = (sp.count - 1) / 2;
+    int32_t x0n = li.px - n - (int32_t) sc.crop_x, y0n = li.py - n - (int32_t) sc.crop_y;
+    bool nominal = li.act && sp.x0 == x0n && sp.y0 == y0n;
+    bool lds_path = a.seg != 0;
+    if (lds_path) {
+#pragma unroll
+        for (int ty = 0; ty < 5; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 5; ++tx)
+                smem_wave[(ty * 5 + tx) * ROW_STRIDE + lane_id] = nominal ? sp.wy[ty] * sp.wx[tx] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) smem_wave[(25 + c) * ROW_STRIDE + lane_id] = nominal ? values[c] : 0.f;
+    }
+    __syncthreads();
+    if (lds_path) {
+        const uint32_t seg = a.seg, groups = 64u / seg, total = groups * 25u * CH;
+        for (uint32_t o = lane_id; o < total; o += 64) {
+            uint32_t g = o / (25u * CH), r = o - g * (25u * CH), t = r / CH, c = r - t * CH;
+            const float *wr = smem_wave + t * ROW_STRIDE + g * seg;
+            const float *vr = smem_wave + (25 + c) * ROW_STRIDE + g * seg;
+            float sum = 0.f;
+            for (uint32_t l = 0; l < seg; l += 4) {
+                float4 wv = *reinterpret_cast<const float4 *>(wr + l);
+                float4 vv = *reinterpret_cast<const float4 *>(vr + l);
+                sum = fmaf(wv.x, vv.x, sum); sum = fmaf(wv.y, vv.y, sum); sum = fmaf(wv.z, vv.z, sum); sum = fmaf(wv.w, vv.w, sum);
+            }
+            uint32_t ig = i_wave_first + g * seg;
+            if (ig < a.n_local && sum != 0.f) {
+                uint32_t pixel = a.pixel_begin + ig / a.s_count;
+                int32_t py = (int32_t) (pixel / sc.crop_w), px = (int32_t) (pixel - (uint32_t) py * sc.crop_w);
+                int32_t x = px - n + (int32_t) (t % 5u), y = py - n + (int32_t) (t / 5u);
+                if (x >= 0 && y >= 0 && x < W && y < H) atomicAdd(film + ((size_t) y * W + x) * CH + c, sum);
+            }
+        }
+    }
+    if (li.act && !(lds_path && nominal)) {                                // imageblock.cpp:478-493
+        for (int ty = 0; ty < sp.count; ++ty) for (int tx = 0; tx < sp.count; ++tx) {
+            int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+            if (x < 0 || y < 0 || x >= W || y >= H) continue;
+            float w = sp.wy[ty] * sp.wx[tx];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) atomicAdd(film + ((size_t) y * W + x) * CH + c, values[c] * w);
+        }
+    }
+}
+
+MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long long *g_counters) {
+    // s_cnt zeroed + synced by the caller
+    atomicAdd(&s_cnt[0], cnt.isect); atomicAdd(&s_cnt[1], cnt.shade); atomicAdd(&s_cnt[2], cnt.shadow);
+    __syncthreads();
+    if (threadIdx.x < 3 && g_counters) atomicAdd(&g_counters[1 + threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
+}
+
+template <int INTEGRATOR, int OUT>
+__global__ __launch_bounds__(BLOCK) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
+                                                  unsigned long long *g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    float *smem_wave = smem + wave * WAVE_FLOATS;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem_wave) + lane_id;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    LaneInfo li;
+    if (OUT == OUT_LANES) {   // lanes of the whole job, no sharding
+        li.act = i < a.n_local; li.lane = a.lane_begin + (li.act ? i : 0);
+        li.pixel = li.lane / a.spp_total;
+        uint32_t y = li.pixel / sc.crop_w; li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
+    } else li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);     // integrator.cpp:435
+    Ray ray = sample_primary_ray(sc, pos_x, pos_y);
+    Counters3 cnt = { 0, 0, 0 };
+    v3 rgb; bool valid;
+    if (INTEGRATOR == MI355_INTEGRATOR_PATH)
+        path_sample(sc, rng, ray, a.max_depth, a.rr_depth, li.act, stk, rgb, valid, cnt);
+    else {
+        GradSink none = { nullptr, nullptr };
+        prb_sample<false>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, li.act, stk,
+                          V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, rgb, valid, cnt);
+    }
+    __syncthreads();                                                        // traversal stack region is reused below
+    if (OUT == OUT_LANES) {
+        if (li.act) { float4 o = make_float4(rgb.x, rgb.y, rgb.z, valid ? 1.f : 0.f); reinterpret_cast<float4 *>(lanes_out)[i] = o; }
+    } else {
+        Splat sp = splat_weights(sc, pos_x, pos_y);
+        float values[4] = { rgb.x, rgb.y, rgb.z, 1.f };                     // integrator.cpp:477-486 (rgb film, no alpha)
+        film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+    }
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
+// RBIntegrator.render_backward step 1a: common.py:741-758 with L = 1, weight = 1
+__global__ __launch_bounds__(BLOCK) void k_splat_weights(DScene sc, RenderArgs a, float *weight) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    LaneInfo li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    float one[1] = { 1.f };
+    film_splat<1>(sc, a, smem + wave * WAVE_FLOATS, weight, li, blockIdx.x * BLOCK + wave * 64, sp, one);
+}
+
+// RBIntegrator.render_backward steps 1b-3: common.py:741-796
+__global__ __launch_bounds__(BLOCK) void k_prb_backward(DScene sc, RenderArgs a, const float *grad_in, const float *weight,
+                                                        float *g_grad, const uint32_t *small_map, uint32_t n_small,
+                                                        unsigned long long *g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ float s_grad[MAX_SMALL_GRAD];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) s_grad[k] = 0.f;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + wave * STACK_WORDS) + lane_id;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    LaneInfo li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);
+    Ray ray = sample_primary_ray(sc, pos_x, pos_y);
+    // dL = adjoint of splat + develop: sum over taps of grad_in[p] * w(p) / W[p]   (hdrfilm.cpp:400)
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    v3 dL = V3(0.f, 0.f, 0.f);
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    if (li.act) for (int ty = 0; ty < sp.count; ++ty) for (int tx = 0; tx < sp.count; ++tx) {
+        int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        size_t p = (size_t) y * W + x; float wv = weight[p]; float dv = wv == 0.f ? 1.f : wv;
+        float w = sp.wy[ty] * sp.wx[tx] / dv;
+        dL.x += grad_in[3 * p] * w; dL.y += grad_in[3 * p + 1] * w; dL.z += grad_in[3 * p + 2] * w;
+    }
+    Counters3 cnt = { 0, 0, 0 };
+    bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
+    GradSink none = { nullptr, nullptr }, sink = { s_grad, g_grad };
+    Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
+    v3 L, L2; bool valid;
+    prb_sample<false>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, li.act, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
+    prb_sample<true>(sc, rng, ray, a.max_depth, a.rr_depth, hide, li.act, stk, dL, L, sink, L2, valid, cnt);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
+// HDRFilm::develop, hdrfilm.cpp:304-409
+__global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 v = reinterpret_cast<const float4 *>(film)[i];
+    float dv = v.w == 0.f ? 1.f : v.w;
+    image[3 * i] = v.x / dv; image[3 * i + 1] = v.y / dv; image[3 * i + 2] = v.z / dv;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_debug_intersect(DScene sc, const float *rays, uint32_t n, float *hits) {
+    __shared__ uint32_t smem[WAVES * STACK_WORDS];
+    uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x; bool act = i < n; uint32_t ii = act ? i : 0;
+    Ray r; r.o = ld3(rays + 8 * (size_t) ii); r.d = ld3(rays + 8 * (size_t) ii + 3); r.maxt = rays[8 * (size_t) ii + 6];
+    Hit h = scene_intersect(sc, r, act, stk);
+    bool occ = scene_ray_test(sc, r, act, stk);
+    if (act) {
+        float *o = hits + 8 * (size_t) i;
+        o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = __uint_as_float(h.prim); o[4] = __uint_as_float(h.shape);
+        o[5] = __uint_as_float(occ ? 1u : 0u); o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI355_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *mi355_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
+// ---- host float helpers (same operation order as the device code) ------------------------------
+struct h3 { float x, y, z; };
+static inline h3 H3(float x, float y, float z) { h3 r = { x, y, z }; return r; }
+static inline float hdot(h3 a, h3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline h3 hcross(h3 a, h3 b) { return H3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
+static inline h3 hsub(h3 a, h3 b) { return H3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline h3 hscale(h3 a, float s) { return H3(a.x * s, a.y * s, a.z * s); }
+static inline h3 hxf_vector(const float *m, h3 v) {
+    h3 r = H3(m[0] * v.x, m[4] * v.x, m[8] * v.x);
+    r = H3(fmaf(m[1], v.y, r.x), fmaf(m[5], v.y, r.y), fmaf(m[9], v.y, r.z));
+    r = H3(fmaf(m[2], v.z, r.x), fmaf(m[6], v.z, r.y), fmaf(m[10], v.z, r.z));
+    return r;
+}
+static inline h3 hxf_normal(const float *to_object, h3 n) {
+    const float *m = to_object;
+    h3 r = H3(m[0] * n.x, m[1] * n.x, m[2] * n.x);
+    r = H3(fmaf(m[4], n.y, r.x), fmaf(m[5], n.y, r.y), fmaf(m[6], n.y, r.z));
+    r = H3(fmaf(m[8], n.z, r.x), fmaf(m[9], n.z, r.y), fmaf(m[10], n.z, r.z));
+    return r;
+}
+static void hmat4_mul(const float *a, const float *b, float *o) {
+    float r[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float s = a[i * 4 + 0] * b[0 * 4 + j];
+        for (int k = 1; k < 4; ++k) s = fmaf(a[i * 4 + k], b[k * 4 + j], s);
+        r[i * 4 + j] = s;
+    }
+    memcpy(o, r, sizeof(r));
+}
+static void hmat4_identity(float *m) { memset(m, 0, 64); m[0] = m[5] = m[10] = m[15] = 1.f; }
+static void hmat4_scale(float x, float y, float z, float *m) { hmat4_identity(m); m[0] = x; m[5] = y; m[10] = z; }
+static void hmat4_translate(float x, float y, float z, float *m) { hmat4_identity(m); m[3] = x; m[7] = y; m[11] = z; }
+
+// perspective_projection (sensor.h:228-265) + Transform::perspective (transform.h:216-233); also returns the
+// analytic inverse that Transform carries along (transform.h:62-71)
+static void host_perspective_projection(const int32_t *film, const int32_t *crop, const int32_t *off, float fov_x,
+                                        float near_, float far_, float *m, float *inv) {
+    float fx = (float) film[0], fy = (float) film[1];
+    float rsx = (float) crop[0] / fx, rsy = (float) crop[1] / fy, rox = (float) off[0] / fx, roy = (float) off[1] / fy;
+    float aspect = fx / fy;
+    float recip = 1.f / (far_ - near_);
+    float tn = tanf((fov_x * .5f) * (MI_PI / 180.f)), cot = 1.f / tn;
+    float P[16], Pi[16];
+    memset(P, 0, 64); P[0] = cot; P[5] = cot; P[10] = far_ * recip; P[11] = -near_ * far_ * recip; P[14] = 1.f;
+    memset(Pi, 0, 64); Pi[0] = tn; Pi[5] = tn; Pi[15] = 1.f / near_; Pi[11] = 1.f; Pi[14] = (near_ - far_) / (far_ * near_);
+    float S1[16], T1[16], S2[16], T2[16], S1i[16], T1i[16], S2i[16], T2i[16], t[16];
+    hmat4_scale(1.f / rsx, 1.f / rsy, 1.f, S1);      hmat4_scale(1.f / (1.f / rsx), 1.f / (1.f / rsy), 1.f, S1i);
+    hmat4_translate(-rox, -roy, 0.f, T1);            hmat4_translate(rox, roy, 0.f, T1i);
+    hmat4_scale(-0.5f, -0.5f * aspect, 1.f, S2);     hmat4_scale(1.f / -0.5f, 1.f / (-0.5f * aspect), 1.f, S2i);
+    hmat4_translate(-1.f, -1.f / aspect, 0.f, T2);   hmat4_translate(1.f, 1.f / aspect, 0.f, T2i);
+    hmat4_mul(S1, T1, t); hmat4_mul(t, S2, t); hmat4_mul(t, T2, t); hmat4_mul(t, P, m);
+    hmat4_mul(Pi, T2i, t); hmat4_mul(t, S2i, t); hmat4_mul(t, T1i, t); hmat4_mul(t, S1i, inv);
+}
+extern "C" void mi355_perspective_projection(const int32_t film_size[2], const int32_t crop_size[2], const int32_t crop_offset[2],
+                                             float fov_x, float near_clip, float far_clip, float out_matrix[16]) {
+    float inv[16]; host_perspective_projection(film_size, crop_size, crop_offset, fov_x, near_clip, far_clip, out_matrix, inv);
+}
+static float host_estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]), a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+    float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2);
+    return fmaf(x8, a4, fmaf(x4, b1, b0));
+}
+// GaussianFilter ctor, gaussian.cpp:46-86
+extern "C" void mi355_gaussian_coeffs(float stddev, float out_coeff[10]) {
+    static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                                      -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+    double scale = 1; float radius = 4.f * stddev;
+    for (int i = 0; i < 10; ++i) { out_coeff[i] = (float) (coeff[i] * scale); scale /= ((double) stddev * (double) stddev); }
+    out_coeff[0] -= host_estrin10(radius * radius, out_coeff);
+}
+
+// ---- scene object --------------------------------------------------------------------------------
+#define MAX_EVENTS 64
+struct mi355_scene {
+    int device = 0;
+    DScene ds;                                  // kernel argument (device pointers inside)
+    std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
+    std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
+    std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
+    std::vector<float> texdata;
+    std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
+    std::vector<uint32_t> small_map;
+    // device buffers
+    DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+          *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
+    DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
+    unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow
+    uint64_t n_gen = 0, n_splat = 0;
+    hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
+    float ms_accum = 0.f; uint32_t launches_accum = 0;
+};
+
+template <typename T> static int upload(T **dst, const std::vector<T> &src) {
+    size_t n = std::max<size_t>(src.size(), 1);
+    HIP_TRY(hipMalloc((void **) dst, n * sizeof(T)));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+// binary BVH, median split along the longest centroid axis, leaves of <= 4 triangles
+struct BuildTri { float lo[3], hi[3], c[3]; uint32_t face; };
+static void bvh_build(std::vector<DBvhNode> &nodes, std::vector<BuildTri> &bt, uint32_t node, uint32_t begin, uint32_t end) {
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = begin; i < end; ++i) for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(lo[k], bt[i].lo[k]); hi[k] = std::max(hi[k], bt[i].hi[k]);
+        clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]);
+    }
+    for (int k = 0; k < 3; ++k) { nodes[node].lo[k] = lo[k]; nodes[node].hi[k] = hi[k]; }
+    uint32_t n = end - begin;
+    if (n <= 4) { nodes[node].left = begin; nodes[node].count = n; return; }
+    int axis = 0; float ext = chi[0] - clo[0];
+    for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
+    uint32_t mid = begin + n / 2;
+    std::nth_element(bt.begin() + begin, bt.begin() + mid, bt.begin() + end,
+                     [axis](const BuildTri &a, const BuildTri &b) { return a.c[axis] < b.c[axis]; });
+    uint32_t left = (uint32_t) nodes.size();
+    nodes.push_back(DBvhNode()); nodes.push_back(DBvhNode());
+    nodes[node].left = left; nodes[node].count = 0;
+    bvh_build(nodes, bt, left, begin, mid);
+    bvh_build(nodes, bt, left + 1, mid, end);
+}
+
+static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
+    const mi355_sensor_desc &se = d->sensor;
+    if (se.type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build");
+    if (!se.crop_width || !se.crop_height || !se.film_width || !se.film_height) return fail(MI355_ERR_INVALID, "empty film");
+    DScene &ds = s->ds; memset(&ds, 0, sizeof(ds));
+    // textures
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mi355_texture_desc &t = d->textures[i];
+        if ((t.channels != 1 && t.channels != 3) || t.width < 2 || t.height < 2 || !t.data)
+            return fail(MI355_ERR_INVALID, "bitmap texture must be >= 2x2 with 1 or 3 channels (bitmap.cpp:313-330)");
+        DTexture o; memset(&o, 0, sizeof(o)); o.w = t.width; o.h = t.height; o.c = t.channels; o.filter = t.filter; o.wrap = t.wrap;
+        o.grad_slot = -1; o.data_offset = s->texdata.size(); memcpy(o.to_uv, t.to_uv, sizeof(o.to_uv));
+        s->texdata.insert(s->texdata.end(), t.data, t.data + (size_t) t.width * t.height * t.channels);
+        s->textures.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_bsdfs; ++i) {
+        const mi355_bsdf_desc &b = d->bsdfs[i];
+        if (b.type != MI355_BSDF_DIFFUSE) return fail(MI355_ERR_UNSUPPORTED, "bsdf type not supported by this build (diffuse only)");
+        if (b.reflectance_texture >= (int32_t) d->n_textures) return fail(MI355_ERR_INVALID, "bsdf references a missing texture");
+        DBsdf o; memset(&o, 0, sizeof(o)); o.type = b.type; memcpy(o.reflectance, b.reflectance, 12); o.texture = b.reflectance_texture; o.grad_slot = -1;
+        s->bsdfs.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_emitters; ++i) {
+        const mi355_emitter_desc &e = d->emitters[i];
+        if (e.type != MI355_EMITTER_AREA) return fail(MI355_ERR_UNSUPPORTED, "emitter type not supported (area only)");
+        if (e.shape >= d->n_shapes) return fail(MI355_ERR_INVALID, "emitter references a missing shape");
+        if (d->shapes[e.shape].type != MI355_SHAPE_RECTANGLE) return fail(MI355_ERR_UNSUPPORTED, "area emitters must sit on rectangles in this build");
+        DEmitter o; memset(&o, 0, sizeof(o)); o.type = e.type; memcpy(o.radiance, e.radiance, 12); o.shape = e.shape; o.grad_slot = -1;
+        s->emitters.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const mi355_shape_desc &sd = d->shapes[i];
+        if (sd.bsdf >= d->n_bsdfs) return fail(MI355_ERR_INVALID, "shape references a missing bsdf");
+        if (sd.emitter >= (int32_t) d->n_emitters) return fail(MI355_ERR_INVALID, "shape references a missing emitter");
+        DShape o; memset(&o, 0, sizeof(o)); o.type = sd.type; o.bsdf = sd.bsdf; o.emitter = sd.emitter; o.bvh_root = -1;
+        o.flags = sd.flip_normals ? DSHAPE_FLIP : 0u;
+        memcpy(o.to_world, sd.to_world, 48); memcpy(o.to_object, sd.to_object, 48);
+        if (sd.type == MI355_SHAPE_RECTANGLE) {                             // Rectangle::update, rectangle.cpp:115-126
+            h3 fs = hxf_vector(o.to_world, H3(2.f, 0.f, 0.f)), ft = hxf_vector(o.to_world, H3(0.f, 2.f, 0.f));
+            h3 n = hxf_normal(o.to_object, H3(0.f, 0.f, 1.f)); n = hscale(n, 1.0f / sqrtf(hdot(n, n)));
+            o.frame_s[0] = fs.x; o.frame_s[1] = fs.y; o.frame_s[2] = fs.z; o.frame_t[0] = ft.x; o.frame_t[1] = ft.y; o.frame_t[2] = ft.z;
+            o.frame_n[0] = n.x; o.frame_n[1] = n.y; o.frame_n[2] = n.z;
+            h3 cr = hcross(fs, ft); o.inv_area = 1.0f / sqrtf(hdot(cr, cr));
+        } else if (sd.type == MI355_SHAPE_MESH) {
+            if (!sd.vertex_positions || !sd.faces || !sd.face_count || !sd.vertex_count) return fail(MI355_ERR_INVALID, "mesh without vertices/faces");
+            o.tri_offset = (uint32_t) s->tris.size(); o.tri_count = sd.face_count; o.vtx_offset = (uint32_t) (s->positions.size() / 3);
+            if (sd.vertex_normals) o.flags |= DSHAPE_HAS_NRM;
+            if (sd.vertex_texcoords) o.flags |= DSHAPE_HAS_UV;
+            s->positions.insert(s->positions.end(), sd.vertex_positions, sd.vertex_positions + 3 * (size_t) sd.vertex_count);
+            if (sd.vertex_normals) s->normals.insert(s->normals.end(), sd.vertex_normals, sd.vertex_normals + 3 * (size_t) sd.vertex_count);
+            else s->normals.insert(s->normals.end(), 3 * (size_t) sd.vertex_count, 0.f);
+            if (sd.vertex_texcoords) s->texcoords.insert(s->texcoords.end(), sd.vertex_texcoords, sd.vertex_texcoords + 2 * (size_t) sd.vertex_count);
+            else s->texcoords.insert(s->texcoords.end(), 2 * (size_t) sd.vertex_count, 0.f);
+            std::vector<BuildTri> bt(sd.face_count);
+            for (int k = 0; k < 3; ++k) { o.bbox_min[k] = INFINITY; o.bbox_max[k] = -INFINITY; }
+            double area = 0;
+            for (uint32_t f = 0; f < sd.face_count; ++f) {
+                const uint32_t *fi = sd.faces + 3 * (size_t) f;
+                for (int k = 0; k < 3; ++k) if (fi[k] >= sd.vertex_count) return fail(MI355_ERR_INVALID, "face index out of range");
+                const float *a = sd.vertex_positions + 3 * (size_t) fi[0], *b = sd.vertex_positions + 3 * (size_t) fi[1], *c = sd.vertex_positions + 3 * (size_t) fi[2];
+                for (int k = 0; k < 3; ++k) {
+                    bt[f].lo[k] = std::min(a[k], std::min(b[k], c[k])); bt[f].hi[k] = std::max(a[k], std::max(b[k], c[k]));
+                    bt[f].c[k] = (bt[f].lo[k] + bt[f].hi[k]) * .5f;
+                    o.bbox_min[k] = std::min(o.bbox_min[k], bt[f].lo[k]); o.bbox_max[k] = std::max(o.bbox_max[k], bt[f].hi[k]);
+                }
+                bt[f].face = f;
+                h3 cr = hcross(hsub(H3(b[0], b[1], b[2]), H3(a[0], a[1], a[2])), hsub(H3(c[0], c[1], c[2]), H3(a[0], a[1], a[2])));
+                area += 0.5 * (double) sqrtf(hdot(cr, cr));
+                s->faces.push_back(fi[0]); s->faces.push_back(fi[1]); s->faces.push_back(fi[2]);
+            }
+            o.inv_area = (float) (1.0 / area);
+            if (sd.face_count > 16) {
+                uint32_t root = (uint32_t) s->bvh.size(); s->bvh.push_back(DBvhNode());
+                std::vector<DBvhNode> &nodes = s->bvh;
+                bvh_build(nodes, bt, root, 0, sd.face_count);
+                o.bvh_root = (int32_t) root;
+            }
+            for (uint32_t k = 0; k < sd.face_count; ++k) {                  // traversal order; DTri carries p0,e1,e2 (mesh.h:436)
+                uint32_t f = bt[k].face; const uint32_t *fi = sd.faces + 3 * (size_t) f;
+                const float *a = sd.vertex_positions + 3 * (size_t) fi[0], *b = sd.vertex_positions + 3 * (size_t) fi[1], *c = sd.vertex_positions + 3 * (size_t) fi[2];
+                DTri t; for (int q = 0; q < 3; ++q) { t.p0[q] = a[q]; t.e1[q] = b[q] - a[q]; t.e2[q] = c[q] - a[q]; }
+                s->tris.push_back(t); s->tri_face.push_back(f);
+            }
+        } else return fail(MI355_ERR_UNSUPPORTED, "shape type not supported by this build (rectangle, mesh)");
+        s->shapes.push_back(o);
+    }
+    // gradient layout: constant reflectances, textures, emitter radiances (mi355_scene_param_layout)
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < s->bsdfs.size(); ++i) if (s->bsdfs[i].texture < 0) {
+        mi355_param_info pi = { MI355_PARAM_BSDF_REFLECTANCE, i, off, 3 }; s->layout.push_back(pi);
+        s->bsdfs[i].grad_slot = (int32_t) s->small_map.size();
+        for (int k = 0; k < 3; ++k) s->small_map.push_back((uint32_t) (off + k));
+        off += 3;
+    }
+    for (uint32_t i = 0; i < s->textures.size(); ++i) {
+        uint64_t sz = (uint64_t) s->textures[i].w * s->textures[i].h * s->textures[i].c;
+        mi355_param_info pi = { MI355_PARAM_TEXTURE_DATA, i, off, sz }; s->layout.push_back(pi);
+        s->textures[i].grad_slot = (int32_t) i; s->textures[i].grad_offset = off; off += sz;
+    }
+    for (uint32_t i = 0; i < s->emitters.size(); ++i) {
+        mi355_param_info pi = { MI355_PARAM_EMITTER_RADIANCE, i, off, 3 }; s->layout.push_back(pi);
+        s->emitters[i].grad_slot = (int32_t) s->small_map.size();
+        for (int k = 0; k < 3; ++k) s->small_map.push_back((uint32_t) (off + k));
+        off += 3;
+    }
+    s->grad_total = off;
+    if (off > 0xffffffffull) return fail(MI355_ERR_UNSUPPORTED, "more than 2^32 differentiable floats");
+    if (s->small_map.size() > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant differentiable parameters for the LDS reducer");
+    // sensor / film
+    int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
+            coff[2] = { (int32_t) se.crop_offset_x, (int32_t) se.crop_offset_y };
+    float c2s[16];
+    host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
+    memcpy(ds.cam_to_world, se.to_world, 48);
+    ds.near_clip = se.near_clip; ds.far_clip = se.far_clip;
+    ds.crop_w = se.crop_width; ds.crop_h = se.crop_height; ds.crop_x = se.crop_offset_x; ds.crop_y = se.crop_offset_y;
+    ds.rfilter = se.rfilter;
+    if (se.rfilter == MI355_RFILTER_GAUSSIAN) { mi355_gaussian_coeffs(se.rfilter_param, ds.filter_coeff); ds.filter_radius = 4.f * se.rfilter_param; }
+    else if (se.rfilter == MI355_RFILTER_TENT) ds.filter_radius = se.rfilter_param;
+    else if (se.rfilter == MI355_RFILTER_BOX) ds.filter_radius = .5f;
+    else return fail(MI355_ERR_UNSUPPORTED, "reconstruction filter not supported (box, gaussian, tent)");
+    if (se.rfilter != MI355_RFILTER_BOX && 2 * (int) ceilf(ds.filter_radius - .5f) + 1 > MI_MAX_TAPS)
+        return fail(MI355_ERR_UNSUPPORTED, "filter radius > 2.5 pixels is outside this build's splat footprint");
+    ds.n_shapes = (uint32_t) s->shapes.size(); ds.n_bsdfs = (uint32_t) s->bsdfs.size(); ds.n_emitters = (uint32_t) s->emitters.size();
+    ds.n_textures = (uint32_t) s->textures.size();
+    ds.inv_emitter_count = ds.n_emitters ? 1.f / (float) ds.n_emitters : 0.f;
+    // upload
+    int rc;
+    if ((rc = upload(&s->d_shapes, s->shapes))) return rc;
+    if ((rc = upload(&s->d_tris, s->tris))) return rc;
+    if ((rc = upload(&s->d_faces, s->faces))) return rc;
+    if ((rc = upload(&s->d_tri_face, s->tri_face))) return rc;
+    if ((rc = upload(&s->d_positions, s->positions))) return rc;
+    if ((rc = upload(&s->d_normals, s->normals))) return rc;
+    if ((rc = upload(&s->d_texcoords, s->texcoords))) return rc;
+    if ((rc = upload(&s->d_bvh, s->bvh))) return rc;
+    if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
+    if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
+    if ((rc = upload(&s->d_textures, s->textures))) return rc;
+    if ((rc = upload(&s->d_texdata, s->texdata))) return rc;
+    if ((rc = upload(&s->d_small_map, s->small_map))) return rc;
+    HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+    ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
+    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
+    ds.texdata = s->d_texdata;
+    return MI355_OK;
+}
+
+extern "C" int mi355_scene_create(const mi355_scene_desc *desc, int device, mi355_scene **out) {
+    if (!desc || !out) return fail(MI355_ERR_INVALID, "null argument");
+    if (desc->abi_version != MI355_ABI_VERSION) return fail(MI355_ERR_INVALID, "ABI version mismatch");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(MI355_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(MI355_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mi355_scene *s = new mi355_scene(); s->device = device;
+    int rc = build_device_scene(s, desc);
+    if (rc != MI355_OK) { std::string keep = g_err; mi355_scene_destroy(s); g_err = keep; return rc; }
+    *out = s; return MI355_OK;
+}
+extern "C" int mi355_scene_destroy(mi355_scene *s) {
+    if (!s) return MI355_OK;
+    (void) hipSetDevice(s->device);
+    void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face };
+    for (void *b : bufs) if (b) (void) hipFree(b);
+    if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
+    delete s; return MI355_OK;
+}
+
+static int param_target(mi355_scene *s, uint32_t kind, uint32_t index, uint64_t count, float **host, float **dev) {
+    if (kind == MI355_PARAM_BSDF_REFLECTANCE) {
+        if (index >= s->bsdfs.size() || count != 3) return fail(MI355_ERR_INVALID, "bad bsdf reflectance update");
+        *host = s->bsdfs[index].reflectance; *dev = (float *) ((char *) (s->d_bsdfs + index) + offsetof(DBsdf, reflectance)); return MI355_OK;
+    }
+    if (kind == MI355_PARAM_EMITTER_RADIANCE) {
+        if (index >= s->emitters.size() || count != 3) return fail(MI355_ERR_INVALID, "bad emitter radiance update");
+        *host = s->emitters[index].radiance; *dev = (float *) ((char *) (s->d_emitters + index) + offsetof(DEmitter, radiance)); return MI355_OK;
+    }
+    if (kind == MI355_PARAM_TEXTURE_DATA) {
+        if (index >= s->textures.size()) return fail(MI355_ERR_INVALID, "bad texture index");
+        const DTexture &t = s->textures[index];
+        if (count != (uint64_t) t.w * t.h * t.c) return fail(MI355_ERR_INVALID, "texture update must keep the tensor shape");
+        *host = s->texdata.data() + t.data_offset; *dev = s->d_texdata + t.data_offset; return MI355_OK;
+    }
+    return fail(MI355_ERR_INVALID, "unknown parameter kind");
+}
+extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t index, const float *values, uint64_t count) {
+    if (!s || !values) return fail(MI355_ERR_INVALID, "null argument");
+    float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    memcpy(h, values, count * 4);
+    HIP_TRY(hipMemcpy(d, values, count * 4, hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+extern "C" int mi355_scene_set_param_device(mi355_scene *s, uint32_t kind, uint32_t index, const float *d_values, uint64_t count, void *stream) {
+    if (!s || !d_values) return fail(MI355_ERR_INVALID, "null argument");
+    float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(d, d_values, count * 4, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    HIP_TRY(hipMemcpyAsync(h, d_values, count * 4, hipMemcpyDeviceToHost, (hipStream_t) stream));   // keep the host mirror coherent
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return MI355_OK;
+}
+extern "C" int mi355_scene_param_layout(const mi355_scene *s, mi355_param_info *out, uint32_t capacity, uint64_t *total_floats) {
+    if (!s) return fail(MI355_ERR_INVALID, "null scene");
+    for (uint32_t i = 0; i < s->layout.size() && i < capacity; ++i) if (out) out[i] = s->layout[i];
+    if (total_floats) *total_floats = s->grad_total;
+    return (int) s->layout.size();
+}
+
+static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderArgs *a) {
+    if (!s || !p) return fail(MI355_ERR_INVALID, "null argument");
+    uint32_t npix = s->ds.crop_w * s->ds.crop_h;
+    if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
+    if ((uint64_t) npix * p->spp > 0xffffffffull)
+        return fail(MI355_ERR_INVALID, "W*H*spp exceeds 2^32 lanes; split into passes (integrator.cpp:247-265)");
+    a->seed = p->seed; a->spp_total = p->spp; a->max_depth = (uint32_t) p->max_depth; a->rr_depth = (uint32_t) p->rr_depth; a->flags = p->flags;
+    a->pixel_begin = p->pixel_begin; a->pixel_count = p->pixel_count ? p->pixel_count : npix - p->pixel_begin;
+    a->s_begin = p->spp_begin; a->s_count = p->spp_count ? p->spp_count : p->spp - p->spp_begin;
+    if (p->pixel_begin > npix || a->pixel_count > npix - p->pixel_begin) return fail(MI355_ERR_INVALID, "pixel shard out of range");
+    if (p->spp_begin > p->spp || a->s_count > p->spp - p->spp_begin) return fail(MI355_ERR_INVALID, "spp shard out of range");
+    uint64_t n = (uint64_t) a->pixel_count * a->s_count;
+    if (n > 0xffffffffull - BLOCK) return fail(MI355_ERR_INVALID, "shard too large");
+    a->n_local = (uint32_t) n;
+    // LDS splat needs every wave to be cut into whole pixels: s_count = 2^k >= 4, or a multiple of 64
+    uint32_t sc = a->s_count; a->seg = 0;
+    if (sc % 64 == 0) a->seg = 64; else if (sc >= 4 && (sc & (sc - 1)) == 0) a->seg = sc;
+    a->lane_begin = 0;
+    return MI355_OK;
+}
+static int ensure_events(mi355_scene *s) {
+    if (s->ev_created) return MI355_OK;
+    for (int i = 0; i < MAX_EVENTS; ++i) { HIP_TRY(hipEventCreate(&s->ev[i][0])); HIP_TRY(hipEventCreate(&s->ev[i][1])); }
+    s->ev_created = true; return MI355_OK;
+}
+static int drain_events(mi355_scene *s) {
+    for (int i = 0; i < s->n_ev; ++i) {
+        HIP_TRY(hipEventSynchronize(s->ev[i][1])); float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->ev[i][0], s->ev[i][1]));
+        s->ms_accum += ms; s->launches_accum++;
+    }
+    s->n_ev = 0; return MI355_OK;
+}
+struct Timed {
+    mi355_scene *s; hipStream_t st; bool on; int slot;
+    int begin() {
+        if (!on) return MI355_OK;
+        int rc = ensure_events(s); if (rc) return rc;
+        if (s->n_ev == MAX_EVENTS) { rc = drain_events(s); if (rc) return rc; }
+        slot = s->n_ev; HIP_TRY(hipEventRecord(s->ev[slot][0], st)); return MI355_OK;
+    }
+    int end() { if (!on) return MI355_OK; HIP_TRY(hipEventRecord(s->ev[slot][1], st)); s->n_ev++; return MI355_OK; }
+};
+
+extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
+    if (p->mode != MI355_MODE_FUSED) return fail(MI355_ERR_UNSUPPORTED, "wavefront mode is not part of this build yet");
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0) return MI355_OK;
+    hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
+    if ((rc = tm.begin())) return rc;
+    if (p->integrator == MI355_INTEGRATOR_PRB)
+        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
+    else
+        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tm.end())) return rc;
+    s->n_gen += a.n_local; s->n_splat += a.n_local;
+    return MI355_OK;
+}
+extern "C" int mi355_film_develop(mi355_scene *s, const float *d_film_rgbw, float *d_image_rgb, void *stream) {
+    if (!s || !d_film_rgbw || !d_image_rgb) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t n = s->ds.crop_w * s->ds.crop_h;
+    hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, d_film_rgbw, d_image_rgb, n);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_render(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, float *d_image_rgb, void *stream) {
+    if (!s || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(d_film_rgbw, 0, (size_t) s->ds.crop_w * s->ds.crop_h * 16, (hipStream_t) stream));
+    int rc = mi355_render_accumulate(s, p, d_film_rgbw, stream); if (rc) return rc;
+    if (d_image_rgb) return mi355_film_develop(s, d_film_rgbw, d_image_rgb, stream);
+    return MI355_OK;
+}
+extern "C" int mi355_prb_splat_weights(mi355_scene *s, const mi355_render_params *p, float *d_weight, void *stream) {
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (!d_weight) return fail(MI355_ERR_INVALID, "null weight buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0) return MI355_OK;
+    hipLaunchKernelGGL(k_splat_weights, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, a, d_weight);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,
+                                     float *d_grad_params, void *stream) {
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (!d_grad_in || !d_weight || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0) return MI355_OK;
+    hipStream_t st = (hipStream_t) stream;
+    Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
+    if ((rc = tm.begin())) return rc;
+    hipLaunchKernelGGL(k_prb_backward, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, d_grad_in, d_weight,
+                       d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tm.end())) return rc;
+    s->n_gen += a.n_local;
+    return MI355_OK;
+}
+extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset) {
+    if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = drain_events(s); if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[8]; HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->n_gen = s->n_gen; out->n_isect = h[1]; out->n_shade = h[2]; out->n_shadow = h[3]; out->n_splat = s->n_splat;
+    out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum;
+    if (reset) { HIP_TRY(hipMemset(s->d_counters, 0, sizeof(h))); s->n_gen = s->n_splat = 0; s->ms_accum = 0.f; s->launches_accum = 0; }
+    return MI355_OK;
+}
+extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_params *p, uint32_t lane_begin, uint32_t count, float *d_out, void *stream) {
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (!d_out) return fail(MI355_ERR_INVALID, "null output");
+    uint64_t total = (uint64_t) s->ds.crop_w * s->ds.crop_h * p->spp;
+    if ((uint64_t) lane_begin + count > total) return fail(MI355_ERR_INVALID, "lane range outside the job");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!count) return MI355_OK;
+    a.n_local = count; a.lane_begin = lane_begin; a.seg = 0;
+    dim3 grid((count + BLOCK - 1) / BLOCK), block(BLOCK); hipStream_t st = (hipStream_t) stream;
+    if (p->integrator == MI355_INTEGRATOR_PRB)
+        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_LANES>), grid, block, 0, st, s->ds, a, (float *) nullptr, d_out, (unsigned long long *) nullptr);
+    else
+        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_LANES>), grid, block, 0, st, s->ds, a, (float *) nullptr, d_out, (unsigned long long *) nullptr);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_debug_ray_intersect(mi355_scene *s, const float *d_rays, uint32_t n, float *d_hits, void *stream) {
+    if (!s || !d_rays || !d_hits) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!n) return MI355_OK;
+    hipLaunchKernelGGL(k_debug_intersect, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, d_rays, n, d_hits);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}

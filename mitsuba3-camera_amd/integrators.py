@@ -1,0 +1,351 @@
+"""Host-side mirror of the reference's Integrator interface for the `path` and `prb` plugins.
+
+  Integrator.render / render_backward      include/mitsuba/render/integrator.h:74-215
+  SamplingIntegrator::render (JIT branch)  src/render/integrator.cpp:246-360
+  RBIntegrator.render_backward             src/python/python/ad/integrators/common.py:631-796
+  mi.render + _RenderOp                    src/python/python/util.py:356-523
+  mi.traverse / SceneParameters            src/python/python/util.py:13-350
+
+Device memory, streams and the multi-GPU collectives come from torch (plumbing); every sample is
+traced by libmi355.so through the C ABI.  One process drives one GPU; a multi-GPU job passes
+`shard=(rank, world_size)` and the film / gradient buffers are summed with torch.distributed
+(RCCL over xGMI) -- the only exchange the path has.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _abi as abi
+from .scene import Scene, PluginError
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def sample_tea_32(v0, v1, rounds=4):
+    """include/mitsuba/core/random.h:76-91 (host copy used for seed_grad, util.py:517)."""
+    v0 &= 0xffffffff; v1 &= 0xffffffff; s = 0
+    for _ in range(rounds):
+        s = (s + 0x9e3779b9) & 0xffffffff
+        v0 = (v0 + ((((v1 << 4) & 0xffffffff) + 0xa341316c) ^ ((v1 + s) & 0xffffffff) ^ ((v1 >> 5) + 0xc8013ea4))) & 0xffffffff
+        v1 = (v1 + ((((v0 << 4) & 0xffffffff) + 0xad90777d) ^ ((v0 + s) & 0xffffffff) ^ ((v0 >> 5) + 0x7e95761e))) & 0xffffffff
+    return v0, v1
+
+
+def torch_float32():
+    return _torch().float32
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def shard_pixels(n_pixels, rank, world):
+    """Contiguous pixel band of rank `rank` (row-major lanes => contiguous global lane ids)."""
+    per = (n_pixels + world - 1) // world
+    b = min(rank * per, n_pixels); e = min(b + per, n_pixels)
+    return b, e - b
+
+
+class Integrator:
+    """Common part of MonteCarloIntegrator (integrator.cpp:505-522) and ADIntegrator (common.py:20-60)."""
+    integrator_id = abi.INTEGRATOR_PATH
+    name = "path"
+
+    def __init__(self, props=None):
+        props = dict(props or {})
+        md = int(props.get("max_depth", self.default_max_depth))
+        if md < 0 and md != -1:
+            raise PluginError('"max_depth" must be set to -1 (infinite) or a value >= 0')
+        self.max_depth = md
+        self.rr_depth = int(props.get("rr_depth", 5))
+        if self.rr_depth <= 0:
+            raise PluginError('"rr_depth" must be set to a value greater than zero!')
+        self.hide_emitters = bool(props.get("hide_emitters", False))
+        self.mode = abi.MODE_FUSED
+        self.timing = False
+
+    default_max_depth = -1
+
+    def aov_names(self):
+        return []
+
+    # ---- parameter block for the C ABI -----------------------------------------------------------
+    def _params(self, scene, seed, spp, shard=None, spp_shard=None):
+        f = scene.sensor.film
+        p = abi.RenderParams()
+        p.seed = (int(seed) + scene.sensor.base_seed) & 0xffffffff      # sampler.cpp:120: m_base_seed + seed
+        p.spp = int(spp)
+        p.max_depth = self.max_depth; p.rr_depth = self.rr_depth
+        p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0)
+        p.mode = self.mode; p.integrator = self.integrator_id
+        npix = f.crop_width * f.crop_height
+        if shard is not None:
+            p.pixel_begin, p.pixel_count = shard
+            if p.pixel_count == 0:
+                p.pixel_begin, p.pixel_count = npix, 0
+        if spp_shard is not None:
+            p.spp_begin, p.spp_count = spp_shard
+        return p
+
+    def _resolve_spp(self, scene, spp):
+        return int(spp) if spp else scene.sensor.sample_count
+
+    # ---- Integrator::render -----------------------------------------------------------------------
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
+        """Returns the developed image (H x W x 3, torch, on the scene's device); with develop=False the raw
+        RGBW accumulator.  `shard=(rank, world)`: this process renders its pixel band and the accumulators are
+        summed over `group` (torch.distributed) before develop."""
+        torch = _torch()
+        h = scene.handle()
+        dev = torch.device("cuda", scene._device)
+        f = scene.sensor.film
+        spp = self._resolve_spp(scene, spp)
+        film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
+        band = None
+        if shard is not None:
+            band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1])
+        p = self._params(scene, seed, spp, shard=band)
+        st = _stream_ptr(dev)
+        if band is None or band[1] > 0:
+            abi.check(abi.lib().mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), st))
+        if shard is not None and shard[1] > 1:
+            import torch.distributed as dist
+            dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
+        if not develop:
+            return film
+        img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
+        abi.check(abi.lib().mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), st))
+        if evaluate:
+            torch.cuda.current_stream(dev).synchronize()
+        return img
+
+    # ---- Integrator::render_backward ---------------------------------------------------------------
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
+        """Accumulates d(loss)/d(theta) for every differentiable scene parameter into `params.grad_buffer`
+        (and returns it).  Default implementation of the reference (integrator.cpp:65-84) records the whole
+        primal with AD; the path integrator here shares PRB's adjoint kernels instead."""
+        torch = _torch()
+        h = scene.handle()
+        dev = torch.device("cuda", scene._device)
+        f = scene.sensor.film
+        spp = self._resolve_spp(scene, spp)
+        grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
+        if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
+            raise ValueError("grad_in must have shape (H, W, 3)")
+        band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1]) if shard is not None else None
+        p = self._params(scene, seed, spp, shard=band)
+        p.integrator = abi.INTEGRATOR_PRB
+        st = _stream_ptr(dev)
+        weight = torch.zeros((f.crop_height, f.crop_width), dtype=torch.float32, device=dev)
+        active = band is None or band[1] > 0
+        if active:
+            abi.check(abi.lib().mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(weight.data_ptr()), st))
+        if shard is not None and shard[1] > 1:
+            import torch.distributed as dist
+            dist.all_reduce(weight, op=dist.ReduceOp.SUM, group=group)
+        grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(scene_param_total(scene), 1), device=dev)
+        local = torch.zeros_like(grads) if (shard is not None and shard[1] > 1) else grads
+        if active:
+            abi.check(abi.lib().mi355_render_backward(h, C.byref(p), C.c_void_p(grad_in.data_ptr()),
+                                                      C.c_void_p(weight.data_ptr()), C.c_void_p(local.data_ptr()), st))
+        if shard is not None and shard[1] > 1:
+            import torch.distributed as dist
+            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)      # the ONE collective of the adjoint path
+            grads += local
+        return grads
+
+    def counters(self, scene, reset=False):
+        c = abi.Counters()
+        abi.check(abi.lib().mi355_get_counters(scene.handle(), C.byref(c), 1 if reset else 0))
+        return {k: getattr(c, k) for k, _ in abi.Counters._fields_}
+
+    def lane_radiance(self, scene, seed, spp, lane_begin, count):
+        """Per-lane (r,g,b,valid) of global lanes [lane_begin, lane_begin+count) -- check_vectorization hook."""
+        torch = _torch()
+        h = scene.handle(); dev = torch.device("cuda", scene._device)
+        out = torch.empty((count, 4), dtype=torch.float32, device=dev)
+        p = self._params(scene, seed, self._resolve_spp(scene, spp))
+        abi.check(abi.lib().mi355_debug_lane_radiance(h, C.byref(p), int(lane_begin), int(count), C.c_void_p(out.data_ptr()), _stream_ptr(dev)))
+        torch.cuda.current_stream(dev).synchronize()
+        return out
+
+
+class PathIntegrator(Integrator):
+    """src/integrators/path.cpp"""
+    integrator_id = abi.INTEGRATOR_PATH
+    name = "path"
+    default_max_depth = -1
+
+
+class PRBIntegrator(Integrator):
+    """src/python/python/ad/integrators/prb.py (max_depth default 6: common.py:31)"""
+    integrator_id = abi.INTEGRATOR_PRB
+    name = "prb"
+    default_max_depth = 6
+
+
+def make_integrator(props):
+    t = props.get("type")
+    if t == "path":
+        return PathIntegrator(props)
+    if t == "prb":
+        return PRBIntegrator(props)
+    raise PluginError('integrator plugin "%s" is outside the path (path, prb)' % t)
+
+
+# ------------------------------------------------------------------------------------------------
+# traverse / SceneParameters: util.py:13-350
+# ------------------------------------------------------------------------------------------------
+def scene_param_layout(scene):
+    h = scene.handle()
+    cap = 4096
+    arr = (abi.ParamInfo * cap)(); total = C.c_uint64()
+    n = abi.check(abi.lib().mi355_scene_param_layout(h, arr, cap, C.byref(total)))
+    return [(arr[i].kind, arr[i].index, arr[i].offset, arr[i].size) for i in range(n)], total.value
+
+
+def scene_param_total(scene):
+    return scene_param_layout(scene)[1]
+
+
+class SceneParameters:
+    """Dictionary of differentiable scene parameters; `update()` pushes edits to the device replica
+    (SceneParameters.update -> parameters_changed, util.py:185-232).  Values are torch tensors on the
+    scene's device; gradients written by render_backward are read with `grad(key)`."""
+
+    def __init__(self, scene):
+        torch = _torch()
+        self.scene = scene
+        self._entries = {}     # key -> (kind, index, shape)
+        self._values = {}
+        self._dirty = set()
+        self._grads = None
+        scene.handle()
+        dev = torch.device("cuda", scene._device)
+        layout, total = scene_param_layout(scene)
+        self._layout = {(k, i): (off, size) for k, i, off, size in layout}
+        self._total = total
+        for i, b in enumerate(scene.bsdfs):
+            if b.texture is None:
+                self._add("%s.reflectance.value" % b.id, abi.PARAM_BSDF_REFLECTANCE, i, torch.tensor(b.reflectance, device=dev))
+        for i, t in enumerate(scene.textures):
+            self._add("%s.reflectance.data" % t.id, abi.PARAM_TEXTURE_DATA, i, torch.tensor(t.data, device=dev))
+        for i, e in enumerate(scene.emitters):
+            self._add("%s.emitter.radiance.value" % e.shape.id, abi.PARAM_EMITTER_RADIANCE, i, torch.tensor(e.radiance, device=dev))
+
+    def _add(self, key, kind, index, value):
+        self._entries[key] = (kind, index, tuple(value.shape))
+        self._values[key] = value
+
+    def keys(self): return self._entries.keys()
+    def __contains__(self, k): return k in self._entries
+    def __len__(self): return len(self._entries)
+    def __iter__(self): return iter(self._entries)
+    def items(self): return self._values.items()
+
+    def __getitem__(self, key):
+        return self._values[key]
+
+    def __setitem__(self, key, value):
+        torch = _torch()
+        if key not in self._entries:
+            raise KeyError(key)
+        kind, index, shape = self._entries[key]
+        v = torch.as_tensor(value, dtype=torch.float32, device=self._values[key].device)
+        if tuple(v.shape) != shape:
+            raise ValueError("parameter %s must keep its shape %s" % (key, shape))
+        self._values[key] = v
+        self._dirty.add(key)
+
+    def update(self, values=None):
+        torch = _torch()
+        if values:
+            for k, v in values.items():
+                self[k] = v
+        for key in sorted(self._dirty):
+            self._push(key, self._values[key])
+        out = sorted(self._dirty)
+        self._dirty.clear()
+        return out
+
+    def _push(self, key, tensor):
+        """Upload one parameter to the device replica and keep the host description coherent."""
+        kind, index, _ = self._entries[key]
+        v = tensor.detach().to(torch_float32()).contiguous()
+        abi.check(abi.lib().mi355_scene_set_param_device(self.scene.handle(), kind, index, C.c_void_p(v.data_ptr()), v.numel(),
+                                                          _stream_ptr(v.device)))
+        host = v.cpu().numpy()
+        if kind == abi.PARAM_BSDF_REFLECTANCE:
+            self.scene.bsdfs[index].reflectance = host.copy()
+        elif kind == abi.PARAM_EMITTER_RADIANCE:
+            self.scene.emitters[index].radiance = host.copy()
+        else:
+            self.scene.textures[index].data = np.ascontiguousarray(host.reshape(self.scene.textures[index].data.shape))
+
+    # ---- gradients ---------------------------------------------------------------------------------
+    def grad_buffer(self, device):
+        torch = _torch()
+        if self._grads is None or self._grads.device != device:
+            self._grads = torch.zeros(max(self._total, 1), dtype=torch.float32, device=device)
+        return self._grads
+
+    def zero_grad(self):
+        if self._grads is not None:
+            self._grads.zero_()
+
+    def grad(self, key):
+        kind, index, shape = self._entries[key]
+        off, size = self._layout[(kind, index)]
+        torch = _torch()
+        if self._grads is None:
+            return torch.zeros(shape, device=self._values[key].device)
+        return self._grads[off:off + size].reshape(shape)
+
+
+def traverse(scene):
+    return SceneParameters(scene)
+
+
+# ------------------------------------------------------------------------------------------------
+# mi.render: util.py:410-523, as a torch.autograd.Function instead of dr.CustomOp
+# ------------------------------------------------------------------------------------------------
+def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0, shard=None, group=None):
+    torch = _torch()
+    if params is not None and not isinstance(params, SceneParameters):
+        raise Exception('params should be an instance of mi.SceneParameter!')
+    assert isinstance(scene, Scene)
+    if integrator is None:
+        integrator = scene.integrator()
+    if integrator is None:
+        raise Exception('No integrator specified! Add an integrator in the scene description or provide an integrator directly as argument.')
+    if spp_grad == 0:
+        spp_grad = spp
+    if seed_grad == 0:
+        seed_grad = sample_tea_32(seed, 1)[0]          # util.py:517
+    elif seed_grad == seed:
+        raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
+
+    if params is not None:
+        params.update()
+    diff_keys = [k for k in (params.keys() if params is not None else []) if params[k].requires_grad]
+    if not diff_keys:
+        return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
+
+    class _RenderOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *tensors):
+            for k, t in zip(diff_keys, tensors):
+                params._push(k, t)
+            return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            params.zero_grad()
+            integrator.render_backward(scene, params, grad_out.contiguous(), sensor, seed=seed_grad, spp=spp_grad,
+                                       shard=shard, group=group)
+            return tuple(params.grad(k).clone() for k in diff_keys)
+
+    return _RenderOp.apply(*[params[k] for k in diff_keys])

@@ -1,0 +1,493 @@
+"""Host-side scene description: the subset of Mitsuba's dict/plugin front-end that the hot path
+needs, flattened into the POD records of include/mi355.h.
+
+Mirrors (names, argument meaning, error behaviour):
+  mi.load_dict                         src/python/python/... (dict loader), src/core/xml.cpp:1147-1163 (rgb expansion)
+  mi.cornell_box()                     src/python/python/util.py:565-699
+  parse_fov                            src/render/sensor.cpp:149-199
+  Cube                                 src/shapes/cube.cpp:105-163 (24 vertices / 12 triangles, world space)
+  Rectangle / PerspectiveCamera / HDRFilm / GaussianFilter / IndependentSampler property names
+Anything outside the path's scope raises, like PluginManager does for a missing plugin
+(src/core/plugin.cpp:144-158).
+"""
+import math
+import os
+import ctypes as C
+import numpy as np
+
+from . import _abi as abi
+from .transforms import Transform4f, ScalarTransform4f
+
+
+class PluginError(RuntimeError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+# parse_fov: src/render/sensor.cpp:149-199
+# ------------------------------------------------------------------------------------------------
+def parse_fov(props, aspect):
+    if "fov" in props and "focal_length" in props:
+        raise PluginError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
+    if "fov" in props:
+        fov = float(props["fov"])
+        fov_axis = str(props.get("fov_axis", "x")).lower()
+        if fov_axis == "smaller":
+            fov_axis = "y" if aspect > 1 else "x"
+        elif fov_axis == "larger":
+            fov_axis = "x" if aspect > 1 else "y"
+    else:
+        f = str(props.get("focal_length", "50mm"))
+        if f.endswith("mm"):
+            f = f[:-2]
+        try:
+            value = float(f)
+        except ValueError:
+            raise PluginError("Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!")
+        fov = 2.0 * math.degrees(math.atan(math.sqrt(36.0 * 36 + 24 * 24) / (2.0 * value)))
+        fov_axis = "diagonal"
+    if fov_axis == "x":
+        result = fov
+    elif fov_axis == "y":
+        result = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+    elif fov_axis == "diagonal":
+        diagonal = 2.0 * math.tan(0.5 * math.radians(fov))
+        width = diagonal / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        result = math.degrees(2.0 * math.atan(width * 0.5))
+    else:
+        raise PluginError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+    if result <= 0.0 or result >= 180.0:
+        raise PluginError("The horizontal field of view must be in the range [0, 180]!")
+    return result
+
+
+# ------------------------------------------------------------------------------------------------
+# host objects
+# ------------------------------------------------------------------------------------------------
+class Texture:
+    """`bitmap` texture from a tensor (raw=True semantics, bitmap.cpp:183-190)."""
+
+    def __init__(self, data, filter_type="bilinear", wrap_mode="repeat", to_uv=None, id=None):
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float32))
+        if data.ndim == 2:
+            data = data[:, :, None]
+        if data.ndim != 3 or data.shape[2] not in (1, 3):
+            raise PluginError("Unsupported tensor channel count: %s (expected 1 or 3)" % (data.shape,))
+        if data.shape[0] < 2 or data.shape[1] < 2:
+            raise PluginError("bitmap texture must be at least 2x2 pixels in size!")
+        try:
+            self.filter = {"nearest": abi.FILTER_NEAREST, "bilinear": abi.FILTER_BILINEAR}[filter_type]
+        except KeyError:
+            raise PluginError('Invalid filter type "%s", must be one of: "nearest", or "bilinear"!' % filter_type)
+        try:
+            self.wrap = {"repeat": abi.WRAP_REPEAT, "mirror": abi.WRAP_MIRROR, "clamp": abi.WRAP_CLAMP}[wrap_mode]
+        except KeyError:
+            raise PluginError('Invalid wrap mode "%s", must be one of: "repeat", "mirror", or "clamp"!' % wrap_mode)
+        self.data = data
+        self.to_uv = np.array([1, 0, 0, 0, 1, 0], dtype=np.float32) if to_uv is None else np.asarray(to_uv, dtype=np.float32).reshape(6)
+        self.id = id
+
+
+class BSDF:
+    def __init__(self, id, reflectance=(0.5, 0.5, 0.5), texture=None):
+        self.id = id
+        self.type = abi.BSDF_DIFFUSE
+        self.reflectance = np.asarray(reflectance, dtype=np.float32).reshape(3).copy()
+        self.texture = texture      # Texture or None
+
+
+class Emitter:
+    def __init__(self, radiance):
+        self.type = abi.EMITTER_AREA
+        self.radiance = np.asarray(radiance, dtype=np.float32).reshape(3).copy()
+        self.shape = None
+
+
+class Shape:
+    def __init__(self, id, kind, to_world, bsdf, emitter=None, flip_normals=False):
+        self.id = id
+        self.type = kind
+        self.to_world = to_world
+        self.bsdf = bsdf
+        self.emitter = emitter
+        self.flip_normals = flip_normals
+        self.vertex_positions = self.vertex_normals = self.vertex_texcoords = self.faces = None
+
+    def primitive_count(self):
+        return 1 if self.type == abi.SHAPE_RECTANGLE else int(self.faces.shape[0])
+
+    def surface_area(self):
+        if self.type == abi.SHAPE_RECTANGLE:      # rectangle.cpp:158-160
+            s = self.to_world.transform_vector([2, 0, 0]); t = self.to_world.transform_vector([0, 2, 0])
+            return float(np.linalg.norm(np.cross(s, t)))
+        p = self.vertex_positions; f = self.faces
+        return float(0.5 * np.linalg.norm(np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]]), axis=1).sum())
+
+    def bbox(self):
+        if self.type == abi.SHAPE_RECTANGLE:      # rectangle.cpp:128-138
+            c = np.array([self.to_world.transform_affine(q) for q in ([-1, -1, 0], [-1, 1, 0], [1, -1, 0], [1, 1, 0])])
+        else:
+            c = self.vertex_positions
+        return c.min(axis=0), c.max(axis=0)
+
+
+_CUBE_V = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1],
+                    [1, -1, -1], [1, 1, -1], [1, 1, 1], [1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1],
+                    [-1, -1, 1], [-1, 1, 1], [-1, 1, -1], [-1, -1, -1], [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]], dtype=np.float32)
+_CUBE_N = np.repeat(np.array([[0, -1, 0], [0, 1, 0], [1, 0, 0], [0, 0, 1], [-1, 0, 0], [0, 0, -1]], dtype=np.float32), 4, axis=0)
+_CUBE_UV = np.tile(np.array([[0, 1], [1, 1], [1, 0], [0, 0]], dtype=np.float32), (6, 1))
+_CUBE_F = np.array([[0, 1, 2], [3, 0, 2], [4, 5, 6], [7, 4, 6], [8, 9, 10], [11, 8, 10], [12, 13, 14], [15, 12, 14],
+                    [16, 17, 18], [19, 16, 18], [20, 21, 22], [23, 20, 22]], dtype=np.uint32)
+
+
+def _make_cube(shape):
+    """Cube ctor: cube.cpp:105-163 -- vertices and normals pre-transformed to world space."""
+    tw = shape.to_world
+    m = tw.matrix; it = tw.inverse_transpose
+    pos = (_CUBE_V @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
+    nrm = (_CUBE_N @ it[:3, :3].T).astype(np.float32)
+    nrm = (nrm / np.sqrt((nrm * nrm).sum(axis=1, keepdims=True))).astype(np.float32)
+    shape.vertex_positions = np.ascontiguousarray(pos)
+    shape.vertex_normals = np.ascontiguousarray(nrm)
+    shape.vertex_texcoords = np.ascontiguousarray(_CUBE_UV.copy())
+    shape.faces = np.ascontiguousarray(_CUBE_F.copy())
+
+
+def _load_obj(filename):
+    """Minimal Wavefront OBJ reader (v / vt / vn / f with triangles or convex polygons): the vertex/face
+    buffer format of src/shapes/obj.cpp (unique (v,vt,vn) triplets become vertices; v is flipped like obj.cpp)."""
+    vs, vts, vns, keys, tris = [], [], [], {}, []
+    with open(filename) as fh:
+        for line in fh:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                vs.append([float(x) for x in t[1:4]])
+            elif t[0] == "vt":
+                vts.append([float(t[1]), 1.0 - float(t[2])])
+            elif t[0] == "vn":
+                vns.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = []
+                for w in t[1:]:
+                    parts = (w.split("/") + ["", ""])[:3]
+                    key = tuple(int(p) if p else 0 for p in parts)
+                    key = tuple((k + (len(a) + 1) if k < 0 else k) for k, a in zip(key, (vs, vts, vns)))
+                    if key not in keys:
+                        keys[key] = len(keys)
+                    idx.append(keys[key])
+                for k in range(1, len(idx) - 1):
+                    tris.append([idx[0], idx[k], idx[k + 1]])
+    order = sorted(keys.items(), key=lambda kv: kv[1])
+    pos = np.array([vs[k[0] - 1] for k, _ in order], dtype=np.float32)
+    has_uv = all(k[1] > 0 for k, _ in order) and len(vts) > 0
+    has_n = all(k[2] > 0 for k, _ in order) and len(vns) > 0
+    uv = np.array([vts[k[1] - 1] for k, _ in order], dtype=np.float32) if has_uv else None
+    nrm = np.array([vns[k[2] - 1] for k, _ in order], dtype=np.float32) if has_n else None
+    return pos, nrm, uv, np.array(tris, dtype=np.uint32)
+
+
+class Film:
+    def __init__(self, props):
+        t = props.get("type", "hdrfilm")
+        if t != "hdrfilm":
+            raise PluginError('film plugin "%s" is outside the path (hdrfilm only)' % t)
+        self.width = int(props.get("width", 768)); self.height = int(props.get("height", 576))
+        self.crop_width = int(props.get("crop_width", self.width)); self.crop_height = int(props.get("crop_height", self.height))
+        self.crop_offset_x = int(props.get("crop_offset_x", 0)); self.crop_offset_y = int(props.get("crop_offset_y", 0))
+        pf = str(props.get("pixel_format", "rgb")).lower()
+        if pf != "rgb":
+            raise PluginError('pixel_format "%s" is outside the path (rgb only: RGBW accumulation, hdrfilm.cpp:245-259)' % pf)
+        rf = props.get("rfilter", {"type": "gaussian"})
+        rt = rf.get("type", "gaussian")
+        if rt == "gaussian":
+            self.rfilter = abi.RFILTER_GAUSSIAN; self.rfilter_param = float(rf.get("stddev", 0.5)); self.radius = 4 * self.rfilter_param
+        elif rt == "box":
+            self.rfilter = abi.RFILTER_BOX; self.rfilter_param = 0.5; self.radius = 0.5
+        elif rt == "tent":
+            self.rfilter = abi.RFILTER_TENT; self.rfilter_param = float(rf.get("radius", 1.0)); self.radius = self.rfilter_param
+        else:
+            raise PluginError('rfilter plugin "%s" is outside the path (box, gaussian, tent)' % rt)
+
+    def size(self): return (self.width, self.height)
+    def crop_size(self): return (self.crop_width, self.crop_height)
+    def crop_offset(self): return (self.crop_offset_x, self.crop_offset_y)
+
+
+class Sensor:
+    def __init__(self, props):
+        t = props.get("type", "perspective")
+        if t != "perspective":
+            raise PluginError('sensor plugin "%s" is outside the path in this build (perspective)' % t)
+        self.film = Film(props.get("film", {}))
+        self.to_world = props.get("to_world", Transform4f())
+        if not isinstance(self.to_world, Transform4f):
+            self.to_world = Transform4f(self.to_world)
+        if self.to_world.has_scale():
+            raise PluginError("Scale factors in the camera-to-world transformation are not allowed!")
+        self.near_clip = float(props.get("near_clip", 1e-2)); self.far_clip = float(props.get("far_clip", 1e4))
+        self.x_fov = float(np.float32(parse_fov(props, self.film.width / float(self.film.height))))
+        smp = props.get("sampler", {"type": "independent"})
+        if smp.get("type", "independent") != "independent":
+            raise PluginError('sampler plugin "%s" is outside the path (independent)' % smp.get("type"))
+        self.sample_count = int(smp.get("sample_count", 4)); self.base_seed = int(smp.get("seed", 0))
+
+
+class Scene:
+    def __init__(self):
+        self.shapes, self.bsdfs, self.emitters, self.textures = [], [], [], []
+        self.sensor = None
+        self.integrator_props = None
+        self._handle = None
+        self._device = None
+        self._keep = []
+
+    # ---- Mitsuba-like accessors ------------------------------------------------------------------
+    def sensors(self): return [self.sensor]
+    def integrator(self):
+        from .integrators import make_integrator
+        return make_integrator(self.integrator_props) if self.integrator_props else None
+
+    # ---- flatten ---------------------------------------------------------------------------------
+    def desc(self):
+        """Build the ctypes mi355_scene_desc (keeps the numpy buffers alive in self._keep)."""
+        keep = []
+        tex = (abi.TextureDesc * max(len(self.textures), 1))()
+        for i, t in enumerate(self.textures):
+            tex[i].width, tex[i].height, tex[i].channels = t.data.shape[1], t.data.shape[0], t.data.shape[2]
+            tex[i].filter, tex[i].wrap = t.filter, t.wrap
+            tex[i].to_uv[:] = t.to_uv.tolist()
+            tex[i].data = t.data.ctypes.data_as(abi.f32p); keep.append(t.data)
+        bs = (abi.BsdfDesc * max(len(self.bsdfs), 1))()
+        for i, b in enumerate(self.bsdfs):
+            bs[i].type = b.type; bs[i].reflectance[:] = b.reflectance.tolist()
+            bs[i].reflectance_texture = self.textures.index(b.texture) if b.texture is not None else -1
+        em = (abi.EmitterDesc * max(len(self.emitters), 1))()
+        for i, e in enumerate(self.emitters):
+            em[i].type = e.type; em[i].radiance[:] = e.radiance.tolist(); em[i].shape = self.shapes.index(e.shape)
+        sh = (abi.ShapeDesc * max(len(self.shapes), 1))()
+        for i, s in enumerate(self.shapes):
+            sh[i].type = s.type; sh[i].bsdf = self.bsdfs.index(s.bsdf)
+            sh[i].emitter = self.emitters.index(s.emitter) if s.emitter is not None else -1
+            sh[i].flip_normals = 1 if s.flip_normals else 0
+            sh[i].to_world[:] = s.to_world.affine12().tolist(); sh[i].to_object[:] = s.to_world.inverse_affine12().tolist()
+            if s.type == abi.SHAPE_MESH:
+                sh[i].vertex_count = s.vertex_positions.shape[0]; sh[i].face_count = s.faces.shape[0]
+                sh[i].vertex_positions = s.vertex_positions.ctypes.data_as(abi.f32p)
+                sh[i].faces = s.faces.ctypes.data_as(abi.u32p)
+                if s.vertex_normals is not None:
+                    sh[i].vertex_normals = s.vertex_normals.ctypes.data_as(abi.f32p)
+                if s.vertex_texcoords is not None:
+                    sh[i].vertex_texcoords = s.vertex_texcoords.ctypes.data_as(abi.f32p)
+                keep += [s.vertex_positions, s.faces, s.vertex_normals, s.vertex_texcoords]
+        d = abi.SceneDesc()
+        d.abi_version = abi.ABI_VERSION
+        d.n_shapes, d.n_bsdfs, d.n_emitters, d.n_textures = len(self.shapes), len(self.bsdfs), len(self.emitters), len(self.textures)
+        d.shapes, d.bsdfs, d.emitters, d.textures = sh, bs, em, tex
+        se, f = self.sensor, self.sensor.film
+        d.sensor.type = abi.SENSOR_PERSPECTIVE
+        d.sensor.to_world[:] = se.to_world.affine12().tolist()
+        d.sensor.x_fov, d.sensor.near_clip, d.sensor.far_clip = se.x_fov, se.near_clip, se.far_clip
+        d.sensor.film_width, d.sensor.film_height = f.width, f.height
+        d.sensor.crop_offset_x, d.sensor.crop_offset_y = f.crop_offset_x, f.crop_offset_y
+        d.sensor.crop_width, d.sensor.crop_height = f.crop_width, f.crop_height
+        d.sensor.rfilter, d.sensor.rfilter_param = f.rfilter, f.rfilter_param
+        keep += [tex, bs, em, sh]
+        self._keep = keep
+        return d
+
+    # ---- engine handle ------------------------------------------------------------------------------
+    def handle(self, device=None):
+        """Create (once) the device replica through the C ABI.  Fails loudly without a GPU."""
+        import torch
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if self._handle is not None and self._device == device:
+            return self._handle
+        if self._handle is not None:
+            self.release()
+        h = C.c_void_p()
+        d = self.desc()
+        abi.check(abi.lib().mi355_scene_create(C.byref(d), int(device), C.byref(h)))
+        self._handle, self._device = h, device
+        return h
+
+    def release(self):
+        if self._handle is not None:
+            abi.lib().mi355_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# load_dict
+# ------------------------------------------------------------------------------------------------
+def _rgb(v, what, bounded):
+    """{'type':'rgb','value':..} or a plain float/list.  Reflectances must lie in [0,1] (srgb.cpp:52-66);
+    emitter radiances are unbounded (xml.cpp:1147-1163, d65.cpp:146-155)."""
+    if isinstance(v, dict):
+        t = v.get("type")
+        if t == "rgb":
+            v = v["value"]
+        elif t in ("uniform", "d65"):
+            raise PluginError('spectrum plugin "%s" is outside the RGB path' % t)
+        else:
+            raise PluginError('texture plugin "%s" cannot be used as a constant colour' % t)
+    a = np.asarray(v, dtype=np.float32)
+    if a.ndim == 0:
+        a = np.full(3, a, dtype=np.float32)
+    a = a.reshape(3)
+    if bounded and (np.any(a < 0) or np.any(a > 1)):
+        raise PluginError("%s: invalid RGB reflectance value %s, must be in the range [0, 1]!" % (what, a.tolist()))
+    return a
+
+
+def _make_bsdf(scene, props, id):
+    t = props.get("type")
+    if t != "diffuse":
+        raise PluginError('bsdf plugin "%s" is outside the path in this build (diffuse)' % t)
+    refl = props.get("reflectance", 0.5)
+    if isinstance(refl, dict) and refl.get("type") == "bitmap":
+        if "data" not in refl:
+            raise PluginError("bitmap textures must be given as a tensor ('data') in this build (no image file I/O)")
+        if not refl.get("raw", True):
+            raise PluginError('Bitmap "raw" parameter must be `true` when initializing using tensor data!')
+        to_uv = refl.get("to_uv")
+        if isinstance(to_uv, Transform4f):
+            m = to_uv.matrix; to_uv = [m[0, 0], m[0, 1], m[0, 3], m[1, 0], m[1, 1], m[1, 3]]
+        tex = Texture(refl["data"], refl.get("filter_type", "bilinear"), refl.get("wrap_mode", "repeat"), to_uv, id=id)
+        scene.textures.append(tex)
+        b = BSDF(id, (0.5, 0.5, 0.5), tex)
+    else:
+        b = BSDF(id, _rgb(refl, "diffuse.reflectance", True))
+    scene.bsdfs.append(b)
+    return b
+
+
+def load_dict(d):
+    """mi.load_dict for the plugins on the path.  Returns a Scene (type 'scene') or a single-shape Scene-less
+    object for shape dicts used by unit tests."""
+    t = d.get("type")
+    if t != "scene":
+        # convenience used by the reference's shape tests: mi.load_dict({'type': 'rectangle', ...})
+        sc = load_dict({"type": "scene", "shape": d})
+        return sc.shapes[0]
+    scene = Scene()
+    named = {}
+    pending_shapes = []
+    for key, v in d.items():
+        if key == "type" or not isinstance(v, dict):
+            continue
+        vt = v.get("type")
+        if vt in ("path", "prb"):
+            scene.integrator_props = dict(v)
+        elif vt in ("perspective",):
+            scene.sensor = Sensor(v)
+        elif vt in ("diffuse",):
+            named[key] = _make_bsdf(scene, v, key)
+        elif vt in ("rectangle", "cube", "obj", "mesh"):
+            pending_shapes.append((key, v))
+        elif vt in ("thinlens", "orthographic", "realisticlens", "radialwarp", "volpath", "direct", "ptracer", "aov",
+                    "sphere", "disk", "cylinder", "ply", "serialized", "constant", "point", "envmap", "directional",
+                    "roughconductor", "dielectric", "conductor", "plastic", "twosided"):
+            raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)
+        else:
+            raise PluginError('Plugin "%s" not found!' % vt)
+    default_bsdf = None
+    for key, v in pending_shapes:
+        vt = v["type"]
+        tw = v.get("to_world", Transform4f())
+        if not isinstance(tw, Transform4f):
+            tw = Transform4f(tw)
+        bp = v.get("bsdf")
+        if bp is None:
+            if default_bsdf is None:
+                default_bsdf = _make_bsdf(scene, {"type": "diffuse"}, "__default_bsdf")
+            bsdf = default_bsdf
+        elif bp.get("type") == "ref":
+            if bp["id"] not in named:
+                raise PluginError('Referenced object "%s" not found!' % bp["id"])
+            bsdf = named[bp["id"]]
+        else:
+            bsdf = _make_bsdf(scene, bp, key + ".bsdf")
+        kind = abi.SHAPE_RECTANGLE if vt == "rectangle" else abi.SHAPE_MESH
+        shape = Shape(key, kind, tw, bsdf, flip_normals=bool(v.get("flip_normals", False)))
+        if vt == "cube":
+            _make_cube(shape)
+        elif vt == "obj":
+            pos, nrm, uv, faces = _load_obj(v["filename"])
+            m, it = tw.matrix, tw.inverse_transpose
+            shape.vertex_positions = np.ascontiguousarray((pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+            if nrm is not None and not v.get("face_normals", False):
+                n = (nrm @ it[:3, :3].T).astype(np.float32)
+                shape.vertex_normals = np.ascontiguousarray((n / np.sqrt((n * n).sum(axis=1, keepdims=True))).astype(np.float32))
+            shape.vertex_texcoords = None if uv is None else np.ascontiguousarray(uv)
+            shape.faces = np.ascontiguousarray(faces)
+        elif vt == "mesh":     # extension: buffers as mi.Mesh exposes them through traverse() (mesh.h:523-527)
+            m, it = tw.matrix, tw.inverse_transpose
+            pos = np.asarray(v["vertex_positions"], dtype=np.float32).reshape(-1, 3)
+            shape.vertex_positions = np.ascontiguousarray((pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+            if v.get("vertex_normals") is not None:
+                n = (np.asarray(v["vertex_normals"], dtype=np.float32).reshape(-1, 3) @ it[:3, :3].T).astype(np.float32)
+                shape.vertex_normals = np.ascontiguousarray((n / np.sqrt((n * n).sum(axis=1, keepdims=True))).astype(np.float32))
+            if v.get("vertex_texcoords") is not None:
+                shape.vertex_texcoords = np.ascontiguousarray(np.asarray(v["vertex_texcoords"], dtype=np.float32).reshape(-1, 2))
+            shape.faces = np.ascontiguousarray(np.asarray(v["faces"], dtype=np.uint32).reshape(-1, 3))
+        ep = v.get("emitter")
+        if ep is not None:
+            if ep.get("type") != "area":
+                raise PluginError('emitter plugin "%s" is outside the path (area)' % ep.get("type"))
+            if kind != abi.SHAPE_RECTANGLE:
+                raise PluginError("area emitters on meshes are outside this build's path (rectangle emitters only)")
+            e = Emitter(_rgb(ep.get("radiance", 1.0), "area.radiance", False))
+            e.shape = shape; shape.emitter = e
+            scene.emitters.append(e)
+        scene.shapes.append(shape)
+    if scene.sensor is None:
+        scene.sensor = Sensor({"type": "perspective", "film": {"type": "hdrfilm"}})
+    return scene
+
+
+def cornell_box():
+    """mi.cornell_box(): src/python/python/util.py:565-699, verbatim values."""
+    T = ScalarTransform4f
+    return {
+        'type': 'scene',
+        'integrator': {'type': 'path', 'max_depth': 8},
+        'sensor': {
+            'type': 'perspective', 'fov_axis': 'smaller', 'near_clip': 0.001, 'far_clip': 100.0,
+            'focus_distance': 1000, 'fov': 39.3077,
+            'to_world': T.look_at(origin=[0, 0, 3.90], target=[0, 0, 0], up=[0, 1, 0]),
+            'sampler': {'type': 'independent', 'sample_count': 64},
+            'film': {'type': 'hdrfilm', 'width': 256, 'height': 256, 'rfilter': {'type': 'gaussian'},
+                     'pixel_format': 'rgb', 'component_format': 'float32'},
+        },
+        'white': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.885809, 0.698859, 0.666422]}},
+        'green': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.105421, 0.37798, 0.076425]}},
+        'red': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.570068, 0.0430135, 0.0443706]}},
+        'light': {
+            'type': 'rectangle',
+            'to_world': T.translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19]),
+            'bsdf': {'type': 'ref', 'id': 'white'},
+            'emitter': {'type': 'area', 'radiance': {'type': 'rgb', 'value': [18.387, 13.9873, 6.75357]}},
+        },
+        'floor': {'type': 'rectangle', 'to_world': T.translate([0.0, -1.0, 0.0]).rotate([1, 0, 0], -90),
+                  'bsdf': {'type': 'ref', 'id': 'white'}},
+        'ceiling': {'type': 'rectangle', 'to_world': T.translate([0.0, 1.0, 0.0]).rotate([1, 0, 0], 90),
+                    'bsdf': {'type': 'ref', 'id': 'white'}},
+        'back': {'type': 'rectangle', 'to_world': T.translate([0.0, 0.0, -1.0]), 'bsdf': {'type': 'ref', 'id': 'white'}},
+        'green-wall': {'type': 'rectangle', 'to_world': T.translate([1.0, 0.0, 0.0]).rotate([0, 1, 0], -90),
+                       'bsdf': {'type': 'ref', 'id': 'green'}},
+        'red-wall': {'type': 'rectangle', 'to_world': T.translate([-1.0, 0.0, 0.0]).rotate([0, 1, 0], 90),
+                     'bsdf': {'type': 'ref', 'id': 'red'}},
+        'small-box': {'type': 'cube', 'to_world': T.translate([0.335, -0.7, 0.38]).rotate([0, 1, 0], -17).scale(0.3),
+                      'bsdf': {'type': 'ref', 'id': 'white'}},
+        'large-box': {'type': 'cube', 'to_world': T.translate([-0.33, -0.4, -0.28]).rotate([0, 1, 0], 18.25).scale([0.3, 0.61, 0.3]),
+                      'bsdf': {'type': 'ref', 'id': 'white'}},
+    }

@@ -1,0 +1,1052 @@
+/*
+ * mi_oracle.c -- CPU restatement (plain C99 + OpenMP) of the reference hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (mitsuba3-camera_amd/, csrc/,
+ * libmi355.so) may include, link or call this file; only tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg use it, and there only as the checker / the reported
+ * CPU baseline.
+ *
+ * PARITY STATUS: the reference (Mitsuba 3.5.0 fork + Dr.Jit 0.4.4) can neither be built nor
+ * imported in this environment (ext/drjit, ext/embree, ... are empty submodules),
+ * and it ships no reference images.  This restatement is therefore pinned ONLY by the
+ * known-answer vectors the reference's own tests hold for the leaf functions of the path
+ * (tests/golden/reference_kats.json, checked in tests/test_oracle_kats.py):
+ *   TEA (src/core/tests/test_random.py:8-27), perspective_projection and parse_fov
+ *   (src/render/tests/test_sensor.py:5-57), diffuse eval/pdf (src/bsdfs/tests/test_diffuse.py:14-37),
+ *   rectangle hit grid (src/shapes/tests/test_rectangle.py:33-57), cube hit/normal/uv
+ *   (src/shapes/tests/test_cube.py:26-70), gaussian filter / imageblock / hdrfilm identities.
+ * PCG32 arithmetic lives in Dr.Jit (absent): pinned to the published pcg32 demo vector instead.
+ * Whole-image radiance and PRB gradients against llvm_ad_rgb are "parity unpinned"; they are
+ * checked by self-consistency (finite differences, energy identities) only.
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ * Arithmetic notes: Dr.Jit's dot/cross/matrix-vector products are fmadd chains, ray(t) is an
+ * fmadd, `Array / scalar` is a multiplication by rcp(); this file spells those out with fmaf()
+ * and must be compiled with -ffp-contract=off so that nothing else is fused.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/mi355.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ----------------------------------------------------------------------------------------
+ * constants (include/mitsuba/core/math.h:17-23; dr::Epsilon<float> = 2^-24 [Dr.Jit, recalled])
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_EPS        5.9604644775390625e-8f
+#define RAY_EPS        (ORC_EPS * 1500.f)
+#define SHADOW_EPS     (RAY_EPS * 10.f)
+#define ORC_PI         3.14159265358979323846f
+#define ORC_INV_PI     0.31830988618379067154f
+#define ORC_LARGEST    FLT_MAX
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y; } v2;
+
+static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* dr::fmadd(a, s, c) on arrays */
+static inline v3 fma3s(v3 a, float s, v3 c) { return V3(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
+static inline v3 fma3(v3 a, v3 b, v3 c) { return V3(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
+/* Dr.Jit dot_(): x0*y0, then fmadd per further component [recalled] */
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+/* Dr.Jit cross(): fmsub(a.yzx, b.zxy, a.zxy * b.yzx) [recalled] */
+static inline v3 cross3(v3 a, v3 b) {
+    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline float rcpf_(float x) { return 1.0f / x; }
+static inline float rsqrtf_(float x) { return 1.0f / sqrtf(x); }
+static inline float sqnorm3(v3 a) { return dot3(a, a); }
+static inline float norm3(v3 a) { return sqrtf(dot3(a, a)); }
+/* dr::normalize(v) = v * rsqrt(squared_norm(v)) [recalled] */
+static inline v3 normalize3(v3 a) { return scale3(a, rsqrtf_(sqnorm3(a))); }
+static inline float max3(v3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+static inline float mulsign(float a, float b) {
+    uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+    ua ^= (ub & 0x80000000u); float r; memcpy(&r, &ua, 4); return r;
+}
+static inline float signf_(float x) { return copysignf(1.0f, x); }
+
+/* include/mitsuba/core/vector.h:116-136 */
+static void coordinate_system(v3 n, v3 *s, v3 *t) {
+    float sign = signf_(n.z), a = -rcpf_(sign + n.z), b = n.x * n.y * a;
+    *s = V3(mulsign((n.x * n.x) * a, n.z) + 1.0f, mulsign(b, n.z), mulsign(-n.x, n.z));
+    *t = V3(b, fmaf(n.y, n.y * a, sign), -n.y);
+}
+
+/* 3x4 affine transforms; include/mitsuba/core/transform.h:98-141 */
+static inline v3 xf_point(const float *m, v3 p) {
+    v3 r = V3(m[3], m[7], m[11]);
+    r = fma3s(V3(m[0], m[4], m[8]), p.x, r);
+    r = fma3s(V3(m[1], m[5], m[9]), p.y, r);
+    r = fma3s(V3(m[2], m[6], m[10]), p.z, r);
+    return r;
+}
+static inline v3 xf_vector(const float *m, v3 v) {
+    v3 r = scale3(V3(m[0], m[4], m[8]), v.x);
+    r = fma3s(V3(m[1], m[5], m[9]), v.y, r);
+    r = fma3s(V3(m[2], m[6], m[10]), v.z, r);
+    return r;
+}
+/* normals use the inverse transpose = transpose(to_object) (transform.h:146-155) */
+static inline v3 xf_normal(const float *to_object, v3 n) {
+    const float *m = to_object; /* (M^-1)^T columns are rows of M^-1 */
+    v3 r = scale3(V3(m[0], m[1], m[2]), n.x);
+    r = fma3s(V3(m[4], m[5], m[6]), n.y, r);
+    r = fma3s(V3(m[8], m[9], m[10]), n.z, r);
+    return r;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * RNG: TEA + PCG32
+ * ---------------------------------------------------------------------------------------- */
+/* include/mitsuba/core/random.h:76-91 */
+ORC_API void orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t out[2]) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    out[0] = v0; out[1] = v1;
+}
+/* random.h:136-140 */
+ORC_API float orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t o[2]; orc_tea32(v0, v1, rounds, o);
+    uint32_t u = (o[1] >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f;
+}
+/* random.h:158-162 */
+ORC_API double orc_tea_float64(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t o[2]; orc_tea32(v0, v1, rounds, o);
+    uint64_t v = (uint64_t) o[0] + ((uint64_t) o[1] << 32);
+    uint64_t u = (v >> 12) | 0x3ff0000000000000ull; double d; memcpy(&d, &u, 8); return d - 1.0;
+}
+
+typedef struct { uint64_t state, inc; } pcg32;
+#define PCG32_MULT 0x5851f42d4c957f2dULL
+/* PCG32 (O'Neill; Dr.Jit random.h [recalled]) */
+static inline uint32_t pcg32_next(pcg32 *r) {
+    uint64_t old = r->state;
+    r->state = old * PCG32_MULT + r->inc;
+    uint32_t xorshift = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t) (old >> 59u);
+    return (xorshift >> rot) | (xorshift << ((~rot + 1u) & 31u));
+}
+static inline void pcg32_seed(pcg32 *r, uint64_t initstate, uint64_t initseq) {
+    r->state = 0; r->inc = (initseq << 1u) | 1u;
+    pcg32_next(r); r->state += initstate; pcg32_next(r);
+}
+static inline float pcg32_float(pcg32 *r) {
+    uint32_t u = (pcg32_next(r) >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f;
+}
+ORC_API void orc_pcg32_raw(uint64_t initstate, uint64_t initseq, int n, uint32_t *out) {
+    pcg32 r; pcg32_seed(&r, initstate, initseq);
+    for (int i = 0; i < n; ++i) out[i] = pcg32_next(&r);
+}
+/* PCG32Sampler::seed, JIT branch: src/render/sampler.cpp:116-135 (base_seed = 0) */
+static inline void sampler_seed(pcg32 *r, uint32_t seed, uint32_t lane) {
+    uint32_t v[2]; orc_tea32(seed, lane, 4, v);
+    pcg32_seed(r, (uint64_t) v[0], (uint64_t) v[1]);
+}
+/* IndependentSampler::next_1d: src/samplers/independent.cpp:88-97 */
+ORC_API void orc_sampler_floats(uint32_t seed, uint32_t lane, int n, float *out) {
+    pcg32 r; sampler_seed(&r, seed, lane);
+    for (int i = 0; i < n; ++i) out[i] = pcg32_float(&r);
+}
+
+/* ----------------------------------------------------------------------------------------
+ * warps, filter
+ * ---------------------------------------------------------------------------------------- */
+/* include/mitsuba/core/warp.h:54-90 */
+static v2 square_to_uniform_disk_concentric(v2 s) {
+    float x = fmaf(2.f, s.x, -1.f), y = fmaf(2.f, s.y, -1.f);
+    int is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * ORC_PI * rp / r;
+    if (q13) phi = 0.5f * ORC_PI - phi;
+    if (is_zero) phi = 0.f;
+    float sn = sinf(phi), cs = cosf(phi);
+    v2 o = { r * cs, r * sn }; return o;
+}
+/* warp.h:412-420 */
+static v3 square_to_cosine_hemisphere(v2 s) {
+    v2 p = square_to_uniform_disk_concentric(s);
+    float sq = fmaf(p.y, p.y, p.x * p.x);
+    float z = sqrtf(fmaxf(1.f - sq, 0.f));
+    return V3(p.x, p.y, z);
+}
+ORC_API void orc_square_to_cosine_hemisphere(const float *s, int n, float *out) {
+    for (int i = 0; i < n; ++i) { v2 q = { s[2*i], s[2*i+1] }; v3 r = square_to_cosine_hemisphere(q);
+        out[3*i] = r.x; out[3*i+1] = r.y; out[3*i+2] = r.z; }
+}
+
+/* Dr.Jit estrin_impl [recalled]: pairwise fmadd, recurse on x^2 */
+static float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]),
+          a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+    float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2), b2 = a4;
+    float c0 = fmaf(x4, b1, b0), c1 = b2;
+    return fmaf(x8, c1, c0);
+}
+/* GaussianFilter ctor: src/rfilters/gaussian.cpp:46-86 */
+ORC_API void orc_gaussian_coeffs(float stddev, float *out) {
+    static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2,
+                                      2.136713061e-3, -1.679873860e-4, 9.202145248e-6, -3.329417433e-7,
+                                      7.128382794e-9, -6.821193280e-11 };
+    double scale = 1; float radius = 4.f * stddev;
+    for (int i = 0; i < 10; ++i) { out[i] = (float) (coeff[i] * scale); scale /= ((double) stddev * (double) stddev); }
+    out[0] -= estrin10(radius * radius, out);
+}
+/* GaussianFilter::eval (non-CUDA): gaussian.cpp:88-98 */
+static inline float gaussian_eval(const float *c, float x) { return fmaxf(estrin10(x * x, c), 0.f); }
+ORC_API void orc_gaussian_eval(float stddev, const float *x, int n, float *out) {
+    float c[10]; orc_gaussian_coeffs(stddev, c);
+    for (int i = 0; i < n; ++i) out[i] = gaussian_eval(c, x[i]);
+}
+/* TentFilter::eval: src/rfilters/tent.cpp (max(0, 1 - |x / radius|)) */
+static inline float tent_eval(float radius, float x) { return fmaxf(0.f, 1.f - fabsf(x * (1.f / radius))); }
+
+/* ----------------------------------------------------------------------------------------
+ * sensor
+ * ---------------------------------------------------------------------------------------- */
+static void mat4_mul(const float *a, const float *b, float *o) {
+    float r[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float s = a[i*4+0] * b[0*4+j];
+        for (int k = 1; k < 4; ++k) s = fmaf(a[i*4+k], b[k*4+j], s);
+        r[i*4+j] = s;
+    }
+    memcpy(o, r, sizeof(r));
+}
+static void mat4_identity(float *m) { memset(m, 0, 64); m[0] = m[5] = m[10] = m[15] = 1.f; }
+static void mat4_scale(float x, float y, float z, float *m) { mat4_identity(m); m[0] = x; m[5] = y; m[10] = z; }
+static void mat4_translate(float x, float y, float z, float *m) { mat4_identity(m); m[3] = x; m[7] = y; m[11] = z; }
+/* Transform::perspective: include/mitsuba/core/transform.h:216-233 */
+static void mat4_perspective(float fov, float near_, float far_, float *m, float *inv) {
+    float recip = 1.f / (far_ - near_);
+    float tn = tanf((fov * .5f) * (ORC_PI / 180.f)), cot = 1.f / tn;
+    memset(m, 0, 64); m[0] = cot; m[5] = cot; m[10] = far_ * recip; m[11] = -near_ * far_ * recip; m[14] = 1.f;
+    memset(inv, 0, 64); inv[0] = tn; inv[5] = tn; inv[15] = 1.f / near_; inv[11] = 1.f;
+    inv[14] = (near_ - far_) / (far_ * near_);
+}
+/* perspective_projection: include/mitsuba/render/sensor.h:228-265; returns matrix and its
+   analytic inverse (Transform keeps both, transform.h:62-71) */
+static void perspective_projection(const int32_t *film, const int32_t *crop, const int32_t *off,
+                                   float fov_x, float near_, float far_, float *m, float *inv) {
+    float fx = (float) film[0], fy = (float) film[1];
+    float rsx = (float) crop[0] / fx, rsy = (float) crop[1] / fy;
+    float rox = (float) off[0] / fx, roy = (float) off[1] / fy;
+    float aspect = fx / fy;
+    float S1[16], T1[16], S2[16], T2[16], P[16], Pi[16], t[16];
+    float S1i[16], T1i[16], S2i[16], T2i[16];
+    mat4_scale(1.f / rsx, 1.f / rsy, 1.f, S1);          mat4_scale(1.f / (1.f / rsx), 1.f / (1.f / rsy), 1.f, S1i);
+    mat4_translate(-rox, -roy, 0.f, T1);                mat4_translate(rox, roy, 0.f, T1i);
+    mat4_scale(-0.5f, -0.5f * aspect, 1.f, S2);         mat4_scale(1.f / -0.5f, 1.f / (-0.5f * aspect), 1.f, S2i);
+    mat4_translate(-1.f, -1.f / aspect, 0.f, T2);       mat4_translate(1.f, 1.f / aspect, 0.f, T2i);
+    mat4_perspective(fov_x, near_, far_, P, Pi);
+    mat4_mul(S1, T1, t); mat4_mul(t, S2, t); mat4_mul(t, T2, t); mat4_mul(t, P, m);
+    mat4_mul(Pi, T2i, t); mat4_mul(t, S2i, t); mat4_mul(t, T1i, t); mat4_mul(t, S1i, inv);
+}
+ORC_API void orc_perspective_projection(const int32_t film[2], const int32_t crop[2], const int32_t off[2],
+                                        float fov_x, float near_, float far_, float *out16, float *out_inv16) {
+    float inv[16]; perspective_projection(film, crop, off, fov_x, near_, far_, out16, inv);
+    if (out_inv16) memcpy(out_inv16, inv, 64);
+}
+
+/* ----------------------------------------------------------------------------------------
+ * scene
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t type, bsdf; int32_t emitter; uint32_t flip_normals;
+    float to_world[12], to_object[12];
+    v3 frame_s, frame_t, frame_n; float inv_area;        /* rectangle.cpp:115-126 */
+    uint32_t vertex_count, face_count;
+    float *pos, *nrm, *uv; uint32_t *faces;
+} OShape;
+typedef struct { uint32_t w, h, c, filter, wrap; float to_uv[6]; float *data; } OTexture;
+typedef struct {
+    uint32_t n_shapes, n_bsdfs, n_emitters, n_textures;
+    OShape *shapes; mi355_bsdf_desc *bsdfs; mi355_emitter_desc *emitters; OTexture *textures;
+    mi355_sensor_desc sensor;
+    float sample_to_camera[16], camera_to_sample[16];
+    float filter_coeff[10]; float filter_radius;
+    uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
+} OScene;
+
+static void *dupmem(const void *p, size_t n) { if (!p || !n) return NULL; void *q = malloc(n); memcpy(q, p, n); return q; }
+
+ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
+    if (!d || d->abi_version != MI355_ABI_VERSION) return NULL;
+    OScene *s = (OScene *) calloc(1, sizeof(OScene));
+    s->n_shapes = d->n_shapes; s->n_bsdfs = d->n_bsdfs; s->n_emitters = d->n_emitters; s->n_textures = d->n_textures;
+    s->shapes = (OShape *) calloc(d->n_shapes ? d->n_shapes : 1, sizeof(OShape));
+    s->bsdfs = (mi355_bsdf_desc *) dupmem(d->bsdfs, sizeof(mi355_bsdf_desc) * d->n_bsdfs);
+    s->emitters = (mi355_emitter_desc *) dupmem(d->emitters, sizeof(mi355_emitter_desc) * d->n_emitters);
+    s->textures = (OTexture *) calloc(d->n_textures ? d->n_textures : 1, sizeof(OTexture));
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mi355_texture_desc *t = &d->textures[i]; OTexture *o = &s->textures[i];
+        o->w = t->width; o->h = t->height; o->c = t->channels; o->filter = t->filter; o->wrap = t->wrap;
+        memcpy(o->to_uv, t->to_uv, sizeof(o->to_uv));
+        o->data = (float *) dupmem(t->data, sizeof(float) * (size_t) t->width * t->height * t->channels);
+    }
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const mi355_shape_desc *sd = &d->shapes[i]; OShape *o = &s->shapes[i];
+        o->type = sd->type; o->bsdf = sd->bsdf; o->emitter = sd->emitter; o->flip_normals = sd->flip_normals;
+        memcpy(o->to_world, sd->to_world, 48); memcpy(o->to_object, sd->to_object, 48);
+        if (sd->type == MI355_SHAPE_RECTANGLE) {
+            /* Rectangle::update, rectangle.cpp:115-126 */
+            o->frame_s = xf_vector(o->to_world, V3(2.f, 0.f, 0.f));
+            o->frame_t = xf_vector(o->to_world, V3(0.f, 2.f, 0.f));
+            o->frame_n = normalize3(xf_normal(o->to_object, V3(0.f, 0.f, 1.f)));
+            o->inv_area = rcpf_(norm3(cross3(o->frame_s, o->frame_t)));
+        } else if (sd->type == MI355_SHAPE_MESH) {
+            o->vertex_count = sd->vertex_count; o->face_count = sd->face_count;
+            o->pos = (float *) dupmem(sd->vertex_positions, 12u * sd->vertex_count);
+            o->nrm = (float *) dupmem(sd->vertex_normals, 12u * sd->vertex_count);
+            o->uv = (float *) dupmem(sd->vertex_texcoords, 8u * sd->vertex_count);
+            o->faces = (uint32_t *) dupmem(sd->faces, 12u * sd->face_count);
+            /* Mesh::surface_area: sum of triangle areas (mesh.cpp) */
+            double area = 0;
+            for (uint32_t f = 0; f < o->face_count; ++f) {
+                const uint32_t *fi = o->faces + 3 * f;
+                v3 p0 = V3(o->pos[3*fi[0]], o->pos[3*fi[0]+1], o->pos[3*fi[0]+2]);
+                v3 p1 = V3(o->pos[3*fi[1]], o->pos[3*fi[1]+1], o->pos[3*fi[1]+2]);
+                v3 p2 = V3(o->pos[3*fi[2]], o->pos[3*fi[2]+1], o->pos[3*fi[2]+2]);
+                area += 0.5 * (double) norm3(cross3(sub3(p1, p0), sub3(p2, p0)));
+            }
+            o->inv_area = (float) (1.0 / area);
+        } else { free(s); return NULL; }
+    }
+    s->sensor = d->sensor;
+    int32_t film[2] = { (int32_t) d->sensor.film_width, (int32_t) d->sensor.film_height };
+    int32_t crop[2] = { (int32_t) d->sensor.crop_width, (int32_t) d->sensor.crop_height };
+    int32_t off[2] = { (int32_t) d->sensor.crop_offset_x, (int32_t) d->sensor.crop_offset_y };
+    perspective_projection(film, crop, off, d->sensor.x_fov, d->sensor.near_clip, d->sensor.far_clip,
+                           s->camera_to_sample, s->sample_to_camera);
+    if (d->sensor.rfilter == MI355_RFILTER_GAUSSIAN) {
+        orc_gaussian_coeffs(d->sensor.rfilter_param, s->filter_coeff); s->filter_radius = 4.f * d->sensor.rfilter_param;
+    } else if (d->sensor.rfilter == MI355_RFILTER_TENT) s->filter_radius = d->sensor.rfilter_param;
+    else s->filter_radius = 0.5f;
+    return s;
+}
+ORC_API void orc_scene_destroy(OScene *s) {
+    if (!s) return;
+    for (uint32_t i = 0; i < s->n_shapes; ++i) { free(s->shapes[i].pos); free(s->shapes[i].nrm); free(s->shapes[i].uv); free(s->shapes[i].faces); }
+    for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
+    free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s);
+}
+/* SceneParameters.update for one parameter: src/python/python/util.py:185-232 */
+ORC_API int orc_scene_set_param(OScene *s, uint32_t kind, uint32_t index, const float *v, uint64_t n) {
+    if (kind == MI355_PARAM_BSDF_REFLECTANCE && index < s->n_bsdfs && n == 3) { memcpy(s->bsdfs[index].reflectance, v, 12); return 0; }
+    if (kind == MI355_PARAM_EMITTER_RADIANCE && index < s->n_emitters && n == 3) { memcpy(s->emitters[index].radiance, v, 12); return 0; }
+    if (kind == MI355_PARAM_TEXTURE_DATA && index < s->n_textures) {
+        OTexture *t = &s->textures[index]; if (n != (uint64_t) t->w * t->h * t->c) return -1;
+        memcpy(t->data, v, 4 * n); return 0;
+    }
+    return -1;
+}
+ORC_API void orc_get_counters(OScene *s, uint64_t out[3], int reset) {
+    out[0] = s->c_isect; out[1] = s->c_shade; out[2] = s->c_shadow;
+    if (reset) s->c_isect = s->c_shade = s->c_shadow = 0;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * rays and intersections
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { v3 o, d; float maxt; } Ray;
+typedef struct { float t; v2 prim_uv; uint32_t prim_index, shape_index; } PI;   /* interaction.h:570-675 */
+typedef struct {
+    float t; v3 p, n; v2 uv; v3 sh_s, sh_t, sh_n; v3 dp_du, dp_dv; v3 wi;
+    uint32_t prim_index; int32_t shape;                    /* shape = -1 when invalid */
+} SI;                                                       /* interaction.h:171-492 */
+
+static inline v3 ray_at(const Ray *r, float t) { return fma3s(r->d, t, r->o); }   /* ray.h:61 */
+
+/* Rectangle::ray_intersect_preliminary_impl: src/shapes/rectangle.cpp:446-468 */
+static inline int rect_intersect(const OShape *sh, const Ray *ray, float *t_out, v2 *uv_out) {
+    v3 o = xf_point(sh->to_object, ray->o), d = xf_vector(sh->to_object, ray->d);
+    float t = -o.z / d.z;
+    v3 local = fma3s(d, t, o);
+    int hit = t >= 0.f && t <= ray->maxt && fabsf(local.x) <= 1.f && fabsf(local.y) <= 1.f;
+    *t_out = t; uv_out->x = local.x; uv_out->y = local.y;
+    return hit;
+}
+static inline v3 mesh_vertex(const OShape *sh, uint32_t i) { return V3(sh->pos[3*i], sh->pos[3*i+1], sh->pos[3*i+2]); }
+/* Mesh::moeller_trumbore: include/mitsuba/render/mesh.h:430-453 */
+static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
+    v3 e1 = sub3(p1, p0), e2 = sub3(p2, p0);
+    v3 pvec = cross3(ray->d, e2);
+    float inv_det = rcpf_(dot3(e1, pvec));
+    v3 tvec = sub3(ray->o, p0);
+    float u = dot3(tvec, pvec) * inv_det;
+    int active = u >= 0.f && u <= 1.f;
+    v3 qvec = cross3(tvec, e1);
+    float v = dot3(ray->d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    float t = dot3(e2, qvec) * inv_det;
+    active = active && t >= 0.f && t <= ray->maxt;
+    *t_out = t; uv_out->x = u; uv_out->y = v;
+    return active;
+}
+
+/* Scene::ray_intersect_preliminary (closest hit): scene.cpp:192-199; traversal semantics of
+   kdtree.h:2197-2293 (maxt shrinks to the closest hit so far) restated as a linear scan. */
+static PI scene_intersect(OScene *sc, const Ray *ray_in) {
+    Ray ray = *ray_in; PI pi; pi.t = INFINITY; pi.prim_uv.x = pi.prim_uv.y = 0; pi.prim_index = 0; pi.shape_index = 0xffffffffu;
+    for (uint32_t i = 0; i < sc->n_shapes; ++i) {
+        const OShape *sh = &sc->shapes[i];
+        if (sh->type == MI355_SHAPE_RECTANGLE) {
+            float t; v2 uv;
+            if (rect_intersect(sh, &ray, &t, &uv) && t < pi.t) { pi.t = t; pi.prim_uv = uv; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
+        } else {
+            for (uint32_t f = 0; f < sh->face_count; ++f) {
+                const uint32_t *fi = sh->faces + 3 * f; float t; v2 uv;
+                if (moeller_trumbore(&ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv) && t < pi.t) {
+                    pi.t = t; pi.prim_uv = uv; pi.prim_index = f; pi.shape_index = i; ray.maxt = t;
+                }
+            }
+        }
+    }
+    return pi;
+}
+/* Scene::ray_test (any hit): scene.cpp:201-210 */
+static int scene_ray_test(OScene *sc, const Ray *ray) {
+    for (uint32_t i = 0; i < sc->n_shapes; ++i) {
+        const OShape *sh = &sc->shapes[i]; float t; v2 uv;
+        if (sh->type == MI355_SHAPE_RECTANGLE) { if (rect_intersect(sh, ray, &t, &uv)) return 1; }
+        else for (uint32_t f = 0; f < sh->face_count; ++f) {
+            const uint32_t *fi = sh->faces + 3 * f;
+            if (moeller_trumbore(ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv)) return 1;
+        }
+    }
+    return 0;
+}
+
+/* PreliminaryIntersection::compute_surface_interaction (interaction.h:642-668) ->
+   Rectangle::compute_surface_interaction (rectangle.cpp:497-567, IsDiff branch of the
+   llvm_ad_rgb target: si.p = ray(t), no re-projection) / Mesh::compute_surface_interaction
+   (mesh.cpp:1375-1548) -> finalize_surface_interaction (interaction.h:464-484) */
+static SI compute_si(const OScene *sc, const Ray *ray, const PI *pi) {
+    SI si; memset(&si, 0, sizeof(si)); si.t = INFINITY; si.shape = -1;
+    if (!(pi->t != INFINITY)) { si.wi = neg3(ray->d); return si; }
+    const OShape *sh = &sc->shapes[pi->shape_index];
+    si.t = pi->t; si.shape = (int32_t) pi->shape_index; si.prim_index = pi->prim_index;
+    if (sh->type == MI355_SHAPE_RECTANGLE) {
+        si.p = ray_at(ray, pi->t);
+        si.n = sh->frame_n; si.sh_n = sh->frame_n; si.dp_du = sh->frame_s; si.dp_dv = sh->frame_t;
+        si.uv.x = fmaf(pi->prim_uv.x, .5f, .5f); si.uv.y = fmaf(pi->prim_uv.y, .5f, .5f);
+    } else {
+        const uint32_t *fi = sh->faces + 3 * pi->prim_index;
+        v3 p0 = mesh_vertex(sh, fi[0]), p1 = mesh_vertex(sh, fi[1]), p2 = mesh_vertex(sh, fi[2]);
+        float b1 = pi->prim_uv.x, b2 = pi->prim_uv.y, b0 = 1.f - b1 - b2;
+        si.p = fma3s(p0, b0, fma3s(p1, b1, scale3(p2, b2)));
+        si.n = normalize3(cross3(sub3(p1, p0), sub3(p2, p0)));          /* mesh.h:120-128 */
+        si.uv.x = b1; si.uv.y = b2;
+        coordinate_system(si.n, &si.dp_du, &si.dp_dv);
+        v3 dp0 = sub3(p1, p0), dp1 = sub3(p2, p0);
+        if (sh->uv) {
+            v2 uv0 = { sh->uv[2*fi[0]], sh->uv[2*fi[0]+1] }, uv1 = { sh->uv[2*fi[1]], sh->uv[2*fi[1]+1] },
+               uv2 = { sh->uv[2*fi[2]], sh->uv[2*fi[2]+1] };
+            si.uv.x = fmaf(uv2.x, b2, fmaf(uv1.x, b1, uv0.x * b0));
+            si.uv.y = fmaf(uv2.y, b2, fmaf(uv1.y, b1, uv0.y * b0));
+            v2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+            float det = fmaf(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcpf_(det);
+            if (det != 0.f) {
+                si.dp_du = scale3(V3(fmaf(duv1.y, dp0.x, -(duv0.y * dp1.x)), fmaf(duv1.y, dp0.y, -(duv0.y * dp1.y)), fmaf(duv1.y, dp0.z, -(duv0.y * dp1.z))), inv_det);
+                si.dp_dv = scale3(V3(fmaf(-duv1.x, dp0.x, duv0.x * dp1.x), fmaf(-duv1.x, dp0.y, duv0.x * dp1.y), fmaf(-duv1.x, dp0.z, duv0.x * dp1.z)), inv_det);
+            }
+        }
+        if (sh->nrm) {
+            v3 n0 = V3(sh->nrm[3*fi[0]], sh->nrm[3*fi[0]+1], sh->nrm[3*fi[0]+2]),
+               n1 = V3(sh->nrm[3*fi[1]], sh->nrm[3*fi[1]+1], sh->nrm[3*fi[1]+2]),
+               n2 = V3(sh->nrm[3*fi[2]], sh->nrm[3*fi[2]+1], sh->nrm[3*fi[2]+2]);
+            v3 n = fma3s(n2, b2, fma3s(n1, b1, scale3(n0, b0)));
+            float il = rsqrtf_(sqnorm3(n));
+            si.sh_n = scale3(n, il);
+        } else si.sh_n = si.n;
+        if (sh->flip_normals) { si.n = neg3(si.n); si.sh_n = neg3(si.sh_n); }
+    }
+    /* initialize_sh_frame: interaction.h:245-255 */
+    si.sh_s = normalize3(fma3s(si.sh_n, -dot3(si.sh_n, si.dp_du), si.dp_du));
+    if (si.dp_du.x == 0.f && si.dp_du.y == 0.f && si.dp_du.z == 0.f) { v3 tt; coordinate_system(si.sh_n, &si.sh_s, &tt); }
+    si.sh_t = cross3(si.sh_n, si.sh_s);
+    v3 md = neg3(ray->d);
+    si.wi = V3(dot3(md, si.sh_s), dot3(md, si.sh_t), dot3(md, si.sh_n));           /* frame.h:33-35 */
+    return si;
+}
+static inline v3 si_to_world(const SI *si, v3 v) { return fma3s(si->sh_n, v.z, fma3s(si->sh_t, v.y, scale3(si->sh_s, v.x))); } /* frame.h:38-40 */
+static inline v3 si_to_local(const SI *si, v3 v) { return V3(dot3(v, si->sh_s), dot3(v, si->sh_t), dot3(v, si->sh_n)); }
+/* Interaction::offset_p: interaction.h:158-162 */
+static inline v3 offset_p(v3 p, v3 n, v3 d) {
+    float mag = (1.f + fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z))) * RAY_EPS;
+    mag = mulsign(mag, dot3(n, d));
+    return fma3s(n, mag, p);
+}
+/* Interaction::spawn_ray: interaction.h:133-135 */
+static inline Ray spawn_ray(v3 p, v3 n, v3 d) { Ray r; r.o = offset_p(p, n, d); r.d = d; r.maxt = ORC_LARGEST; return r; }
+/* Interaction::spawn_ray_to: interaction.h:138-145 */
+static inline Ray spawn_ray_to(v3 p, v3 n, v3 target) {
+    Ray r; r.o = offset_p(p, n, sub3(target, p));
+    v3 d = sub3(target, r.o); float dist = norm3(d);
+    r.d = scale3(d, rcpf_(dist)); r.maxt = dist * (1.f - SHADOW_EPS); return r;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * textures / BSDF / emitter
+ * ---------------------------------------------------------------------------------------- */
+static inline int32_t wrap_i(int32_t p, int32_t n, uint32_t mode) {
+    if (mode == MI355_WRAP_CLAMP) return p < 0 ? 0 : (p > n - 1 ? n - 1 : p);
+    if (mode == MI355_WRAP_REPEAT) { int32_t m = p % n; return m < 0 ? m + n : m; }
+    int32_t m = p % (2 * n); if (m < 0) m += 2 * n; return m < n ? m : 2 * n - 1 - m;
+}
+/* BitmapTexture::interpolate_3 (bitmap.cpp:696-710) -> dr::Texture<Float,2>::eval_nonaccel
+   [Dr.Jit, recalled]: pos = uv*res - 0.5, 4-tap lerp; tensor is (H, W, C), uv.x <-> W.
+   Optionally returns the 4 tap indices/weights for the adjoint scatter. */
+static v3 texture_eval(const OTexture *t, v2 uv_in, int32_t idx[4], float wgt[4]) {
+    v2 uv = { fmaf(t->to_uv[0], uv_in.x, fmaf(t->to_uv[1], uv_in.y, t->to_uv[2])),
+              fmaf(t->to_uv[3], uv_in.x, fmaf(t->to_uv[4], uv_in.y, t->to_uv[5])) };
+    int32_t W = (int32_t) t->w, H = (int32_t) t->h, C = (int32_t) t->c;
+    float out[3] = { 0, 0, 0 };
+    if (t->filter == MI355_FILTER_NEAREST) {
+        int32_t x = wrap_i((int32_t) floorf(uv.x * (float) W), W, t->wrap), y = wrap_i((int32_t) floorf(uv.y * (float) H), H, t->wrap);
+        for (int c = 0; c < 3; ++c) out[c] = t->data[(y * W + x) * C + (C == 3 ? c : 0)];
+        if (idx) { idx[0] = y * W + x; wgt[0] = 1.f; idx[1] = idx[2] = idx[3] = -1; wgt[1] = wgt[2] = wgt[3] = 0.f; }
+        return V3(out[0], out[1], out[2]);
+    }
+    float px = fmaf(uv.x, (float) W, -.5f), py = fmaf(uv.y, (float) H, -.5f);
+    float fx = floorf(px), fy = floorf(py);
+    int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    int32_t x0 = wrap_i(ix, W, t->wrap), x1 = wrap_i(ix + 1, W, t->wrap), y0 = wrap_i(iy, H, t->wrap), y1 = wrap_i(iy + 1, H, t->wrap);
+    int32_t i00 = y0 * W + x0, i10 = y0 * W + x1, i01 = y1 * W + x0, i11 = y1 * W + x1;
+    for (int c = 0; c < 3; ++c) {
+        int cc = C == 3 ? c : 0;
+        float v00 = t->data[i00 * C + cc], v10 = t->data[i10 * C + cc], v01 = t->data[i01 * C + cc], v11 = t->data[i11 * C + cc];
+        out[c] = fmaf(w0y, fmaf(w0x, v00, w1x * v10), w1y * fmaf(w0x, v01, w1x * v11));
+    }
+    if (idx) { idx[0] = i00; idx[1] = i10; idx[2] = i01; idx[3] = i11;
+               wgt[0] = w0y * w0x; wgt[1] = w0y * w1x; wgt[2] = w1y * w0x; wgt[3] = w1y * w1x; }
+    return V3(out[0], out[1], out[2]);
+}
+static inline v3 bsdf_reflectance(const OScene *sc, const mi355_bsdf_desc *b, const SI *si) {
+    if (b->reflectance_texture >= 0) return texture_eval(&sc->textures[b->reflectance_texture], si->uv, NULL, NULL);
+    return V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+}
+/* SmoothDiffuse::eval_pdf: src/bsdfs/diffuse.cpp:160-180 */
+static void diffuse_eval_pdf(v3 refl, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
+    float ci = wi.z, co = wo.z;
+    active = active && ci > 0.f && co > 0.f;
+    if (active) { *val = scale3(scale3(refl, ORC_INV_PI), co); *pdf = ORC_INV_PI * co; }
+    else { *val = V3(0, 0, 0); *pdf = 0.f; }
+}
+/* SmoothDiffuse::sample: diffuse.cpp:101-125 (JIT semantics: no early-out, weight masked) */
+static void diffuse_sample(v3 refl, v3 wi, v2 s2, int active, v3 *wo, float *pdf, v3 *weight) {
+    active = active && wi.z > 0.f;
+    *wo = square_to_cosine_hemisphere(s2);
+    *pdf = ORC_INV_PI * wo->z;
+    *weight = (active && *pdf > 0.f) ? refl : V3(0, 0, 0);
+}
+ORC_API void orc_diffuse_eval_pdf(const float *refl, const float *wi, const float *wo, float *val3, float *pdf) {
+    v3 v; diffuse_eval_pdf(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), V3(wo[0], wo[1], wo[2]), 1, &v, pdf);
+    val3[0] = v.x; val3[1] = v.y; val3[2] = v.z;
+}
+ORC_API void orc_diffuse_sample(const float *refl, const float *wi, const float *s2, float *wo3, float *pdf, float *w3) {
+    v3 wo, w; v2 s = { s2[0], s2[1] };
+    diffuse_sample(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), s, 1, &wo, pdf, &w);
+    wo3[0] = wo.x; wo3[1] = wo.y; wo3[2] = wo.z; w3[0] = w.x; w3[1] = w.y; w3[2] = w.z;
+}
+
+/* PathIntegrator::mis_weight: src/integrators/path.cpp:300-305 */
+static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
+
+typedef struct { v3 p, n; v2 uv; float pdf; v3 d; float dist; int32_t emitter; } DS;   /* records.h:93-195 */
+
+/* Scene::sample_emitter_direction (scene.cpp:299-353) -> AreaLight::sample_direction
+   (area.cpp:117-168, uniform-radiance branch) -> Shape::sample_direction (shape.cpp:358-375)
+   -> Rectangle::sample_position (rectangle.cpp:166-180); visibility via ray_test. */
+static void sample_emitter_direction(OScene *sc, const SI *si, v2 sample, int active, DS *ds, v3 *spec, uint64_t *n_shadow) {
+    memset(ds, 0, sizeof(*ds)); *spec = V3(0, 0, 0); ds->emitter = -1;
+    if (sc->n_emitters == 0) return;
+    uint32_t index = 0; float emitter_weight = 1.f, pmf = 1.f;
+    if (sc->n_emitters > 1) {                                           /* sample_emitter, scene.cpp:227-250 */
+        float cf = (float) sc->n_emitters, scaled = sample.x * cf;
+        index = (uint32_t) scaled; if (index > sc->n_emitters - 1) index = sc->n_emitters - 1;
+        emitter_weight = cf; sample.x = scaled - (float) index; pmf = 1.f / cf;
+    }
+    const mi355_emitter_desc *em = &sc->emitters[index];
+    const OShape *sh = &sc->shapes[em->shape];
+    ds->emitter = (int32_t) index;
+    if (sh->type == MI355_SHAPE_RECTANGLE) {
+        ds->p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
+        ds->n = sh->frame_n; ds->pdf = sh->inv_area; ds->uv = sample;
+    } else { ds->pdf = 0.f; return; }                                   /* mesh emitters: outside the path's configs */
+    ds->d = sub3(ds->p, si->p);
+    float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2);
+    ds->d = scale3(ds->d, rcpf_(ds->dist));
+    float dp = fabsf(dot3(ds->d, ds->n));
+    float x = dist2 / dp;
+    ds->pdf *= isfinite(x) ? x : 0.f;
+    active = active && dot3(ds->d, ds->n) < 0.f && ds->pdf != 0.f;      /* area.cpp:136 */
+    v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
+    *spec = active ? scale3(rad, rcpf_(ds->pdf)) : V3(0, 0, 0);          /* area.cpp:165-167 */
+    if (sc->n_emitters > 1) { ds->pdf *= pmf; *spec = scale3(*spec, emitter_weight); }
+    active = active && ds->pdf != 0.f;
+    if (active) {                                                       /* scene.cpp:341-346 */
+        Ray sr = spawn_ray_to(si->p, si->n, ds->p);
+        (*n_shadow)++;
+        if (scene_ray_test(sc, &sr)) { *spec = V3(0, 0, 0); ds->pdf = 0.f; }
+    }
+}
+/* Scene::pdf_emitter_direction (scene.cpp:355-366) -> AreaLight::pdf_direction (area.cpp:170-197)
+   -> Shape::pdf_direction (shape.cpp:377-388) */
+static float pdf_emitter_direction(const OScene *sc, int32_t emitter, v3 d, v3 n, float dist) {
+    const OShape *sh = &sc->shapes[sc->emitters[emitter].shape];
+    float dp = dot3(d, n);
+    if (!(dp < 0.f)) return 0.f;
+    float adp = fabsf(dp);
+    float pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    return pdf * (1.f / (float) sc->n_emitters);
+}
+
+/* ----------------------------------------------------------------------------------------
+ * primary rays: SamplingIntegrator::render_sample head (integrator.cpp:419-455) and
+ * PerspectiveCamera::sample_ray_differential (perspective.cpp:239-280)
+ * ---------------------------------------------------------------------------------------- */
+static void lane_to_pixel(const OScene *sc, uint32_t lane, uint32_t spp, int32_t *px, int32_t *py) {
+    uint32_t idx = lane / spp, W = sc->sensor.crop_width;                /* integrator.cpp:293-310 */
+    *py = (int32_t) (idx / W); *px = (int32_t) (idx - W * (idx / W));
+    *px += (int32_t) sc->sensor.crop_offset_x; *py += (int32_t) sc->sensor.crop_offset_y;
+}
+static Ray sample_primary_ray(const OScene *sc, v2 sample_pos) {
+    float sx = 1.f / (float) sc->sensor.crop_width, sy = 1.f / (float) sc->sensor.crop_height;
+    float ox = -(float) sc->sensor.crop_offset_x * sx, oy = -(float) sc->sensor.crop_offset_y * sy;
+    float ax = fmaf(sample_pos.x, sx, ox), ay = fmaf(sample_pos.y, sy, oy);
+    const float *m = sc->sample_to_camera;
+    /* Transform * Point with perspective divide, transform.h:113-121 */
+    float r[4];
+    for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], ax, v); v = fmaf(m[i*4+1], ay, v); v = fmaf(m[i*4+2], 0.f, v); r[i] = v; }
+    float iw = rcpf_(r[3]);
+    v3 near_p = V3(r[0] * iw, r[1] * iw, r[2] * iw);
+    v3 d = normalize3(near_p);
+    const float *tw = sc->sensor.to_world;
+    Ray ray; ray.o = V3(tw[3], tw[7], tw[11]); ray.d = xf_vector(tw, d);
+    float inv_z = rcpf_(d.z), near_t = sc->sensor.near_clip * inv_z, far_t = sc->sensor.far_clip * inv_z;
+    ray.o = add3(ray.o, scale3(ray.d, near_t));
+    ray.maxt = far_t - near_t;
+    return ray;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * PathIntegrator::sample -- src/integrators/path.cpp:95-287 (JIT masking semantics)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint64_t isect, shade, shadow; } Cnt;
+
+static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_params *rp, v3 *result_out, int *valid_out, Cnt *cnt) {
+    uint32_t max_depth = (uint32_t) rp->max_depth, rr_depth = (uint32_t) rp->rr_depth;
+    v3 throughput = V3(1, 1, 1), result = V3(0, 0, 0); float eta = 1.f; uint32_t depth = 0;
+    int valid_ray = 0;                                                  /* no environment emitter (path.cpp:115) */
+    v3 prev_p = V3(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_bsdf_delta = 1;
+    int active = 1;
+    if (max_depth == 0) { *result_out = result; *valid_out = 0; return; }
+    for (uint32_t it = 0; active && it < max_depth; ++it) {
+        PI pi = scene_intersect(sc, &ray); cnt->isect++;
+        SI si = compute_si(sc, &ray, &pi);
+        int si_valid = si.t != INFINITY;
+        int32_t emitter = si_valid ? sc->shapes[si.shape].emitter : -1;
+        /* ---- direct emission (path.cpp:158-174) */
+        if (emitter >= 0) {
+            v3 rel = sub3(si.p, prev_p); float dist = norm3(rel);
+            v3 d = scale3(rel, rcpf_(dist));                            /* records.h:173-180 */
+            float em_pdf = 0.f;
+            if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            const float *r = sc->emitters[emitter].radiance;
+            v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);   /* area.cpp:83-90 */
+            result = fma3(throughput, scale3(le, mis_bsdf), result);
+        }
+        int active_next = (depth + 1 < max_depth) && si_valid;          /* path.cpp:177 */
+        if (!si_valid) { break; }                                       /* nothing below can affect the result */
+        cnt->shade++;
+        const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
+        v3 refl = bsdf_reflectance(sc, bsdf, &si);
+        /* ---- emitter sampling (path.cpp:186-208) */
+        int active_em = active_next;                                    /* diffuse has BSDFFlags::Smooth */
+        DS ds; v3 em_weight; v2 s_em; s_em.x = pcg32_float(rng); s_em.y = pcg32_float(rng);
+        sample_emitter_direction(sc, &si, s_em, active_em, &ds, &em_weight, &cnt->shadow);
+        active_em = active_em && ds.pdf != 0.f;
+        v3 wo = si_to_local(&si, ds.d);
+        /* ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33) */
+        float s1 = pcg32_float(rng); (void) s1; v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
+        v3 bsdf_val; float bsdf_pdf; diffuse_eval_pdf(refl, si.wi, wo, 1, &bsdf_val, &bsdf_pdf);
+        v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2, 1, &bs_wo, &bs_pdf, &bsdf_weight);
+        if (active_em) {                                                /* path.cpp:220-230 */
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf);
+            result = fma3(throughput, scale3(mul3(bsdf_val, em_weight), mis_em), result);
+        }
+        /* ---- BSDF sampling (path.cpp:234-262) */
+        ray = spawn_ray(si.p, si.n, si_to_world(&si, bs_wo));
+        throughput = mul3(throughput, bsdf_weight);
+        eta *= 1.f;
+        valid_ray = valid_ray || si_valid;
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = 0;
+        /* ---- stopping criterion (path.cpp:266-280) */
+        depth += 1;
+        float tmax = max3(throughput);
+        float rr_prob = fminf(tmax * (eta * eta), .95f);
+        int rr_active = depth >= rr_depth, rr_continue = pcg32_float(rng) < rr_prob;
+        if (rr_active) throughput = scale3(throughput, rcpf_(rr_prob));
+        active = active_next && (!rr_active || rr_continue) && tmax != 0.f;
+    }
+    *result_out = valid_ray ? result : V3(0, 0, 0); *valid_out = valid_ray;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * PRBIntegrator.sample -- src/python/python/ad/integrators/prb.py:59-257
+ * mode 0 = Primal (returns L), mode 1 = Backward (state_in = L, accumulates parameter
+ * gradients; closed form of dr.backward_from(dL * Lo), see DESIGN.md "PRB adjoint")
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float *grad; const mi355_param_info *layout; uint32_t n_params; const int32_t *bsdf_slot, *tex_slot, *em_slot; } GradCtx;
+
+static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_params *rp, int backward,
+                       v3 dL, v3 state_in, const GradCtx *g, v3 *L_out, int *valid_out, Cnt *cnt) {
+    uint32_t max_depth = (uint32_t) rp->max_depth, rr_depth = (uint32_t) rp->rr_depth;
+    uint32_t depth = 0; v3 L = backward ? state_in : V3(0, 0, 0); v3 beta = V3(1, 1, 1); float eta = 1.f;
+    v3 prev_p = V3(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_bsdf_delta = 1; int active = 1;
+    for (uint32_t it = 0; active && it < max_depth; ++it) {
+        int active_next = 1;
+        PI pi = scene_intersect(sc, &ray); cnt->isect++;
+        SI si = compute_si(sc, &ray, &pi);
+        int si_valid = si.t != INFINITY;
+        if ((rp->flags & MI355_FLAG_HIDE_EMITTERS) && depth == 0 && !si_valid) active_next = 0;   /* prb.py:122-123 */
+        int32_t emitter = si_valid ? sc->shapes[si.shape].emitter : -1;
+        /* ---- direct emission (prb.py:126-134) */
+        v3 Le = V3(0, 0, 0); float le_mis = 0.f; int le_front = 0;
+        if (emitter >= 0) {
+            v3 rel = sub3(si.p, prev_p); float dist = norm3(rel); v3 d = scale3(rel, rcpf_(dist));
+            float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
+            const float *r = sc->emitters[emitter].radiance;
+            le_front = si.wi.z > 0.f && active_next;
+            v3 e = le_front ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);
+            Le = mul3(scale3(beta, le_mis), e);
+        }
+        active_next = active_next && (depth + 1 < max_depth) && si_valid;   /* prb.py:139 */
+        if (!si_valid) { if (!backward) L = add3(L, Le); break; }
+        cnt->shade++;
+        const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
+        int32_t tidx[4]; float twgt[4]; v3 refl;
+        if (bsdf->reflectance_texture >= 0) refl = texture_eval(&sc->textures[bsdf->reflectance_texture], si.uv, tidx, twgt);
+        else refl = V3(bsdf->reflectance[0], bsdf->reflectance[1], bsdf->reflectance[2]);
+        /* ---- emitter sampling (prb.py:142-162) */
+        int active_em = active_next;
+        DS ds; v3 em_weight; v2 s_em; s_em.x = pcg32_float(rng); s_em.y = pcg32_float(rng);
+        sample_emitter_direction(sc, &si, s_em, active_em, &ds, &em_weight, &cnt->shadow);
+        active_em = active_em && ds.pdf != 0.f;
+        v3 wo = si_to_local(&si, ds.d);
+        v3 bsdf_value_em; float bsdf_pdf_em; diffuse_eval_pdf(refl, si.wi, wo, active_em, &bsdf_value_em, &bsdf_pdf_em);
+        float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+        v3 Lr_dir = mul3(mul3(scale3(beta, mis_em), bsdf_value_em), em_weight);
+        /* ---- detached BSDF sampling (prb.py:166-169) */
+        float s1 = pcg32_float(rng); (void) s1; v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
+        v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2, active_next, &bs_wo, &bs_pdf, &bsdf_weight);
+        /* ---- update (prb.py:173-182) */
+        v3 beta_pre = beta;
+        L = backward ? sub3(sub3(L, Le), Lr_dir) : add3(add3(L, Le), Lr_dir);
+        ray = spawn_ray(si.p, si.n, si_to_world(&si, bs_wo));
+        eta *= 1.f; beta = mul3(beta, bsdf_weight);
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = 0;
+        /* ---- stopping criterion (prb.py:186-198) */
+        float bmax = max3(beta);
+        active_next = active_next && bmax != 0.f;
+        float rr_prob = fminf(bmax * (eta * eta), .95f);
+        int rr_active = depth >= rr_depth;
+        if (rr_active) beta = scale3(beta, rcpf_(rr_prob));
+        int rr_continue = pcg32_float(rng) < rr_prob;
+        active_next = active_next && (!rr_active || rr_continue);
+        /* ---- differential phase (prb.py:202-247), closed form */
+        if (backward && g) {
+            /* bsdf.eval(si, wo_sampled, active_next) and its detached twin (prb.py:213-227) */
+            float co = bs_wo.z; int ev_active = active_next && si.wi.z > 0.f && co > 0.f;
+            v3 det = scale3(bsdf_weight, bs_pdf);
+            v3 inv = V3(det.x != 0.f ? rcpf_(det.x) : 0.f, det.y != 0.f ? rcpf_(det.y) : 0.f, det.z != 0.f ? rcpf_(det.z) : 0.f);
+            float dval_dalb = ev_active ? ORC_INV_PI * co : 0.f;                         /* d bsdf_val / d albedo */
+            v3 dLo_dalb = scale3(mul3(L, inv), dval_dalb);                               /* Lr_ind term */
+            /* Lr_dir term: beta_pre * mis_em * (InvPi cos_o_em) * em_weight */
+            int em_active = active_em && si.wi.z > 0.f && wo.z > 0.f;
+            float dval_em = em_active ? ORC_INV_PI * wo.z : 0.f;
+            dLo_dalb = add3(dLo_dalb, mul3(scale3(scale3(beta_pre, mis_em), dval_em), em_weight));
+            v3 ga = mul3(dL, dLo_dalb);
+            uint32_t bidx = sc->shapes[si.shape].bsdf;
+            if (bsdf->reflectance_texture >= 0) {
+                int32_t slot = g->tex_slot[bsdf->reflectance_texture];
+                if (slot >= 0) {
+                    const OTexture *t = &sc->textures[bsdf->reflectance_texture];
+                    float *gb = g->grad + g->layout[slot].offset;
+                    for (int k = 0; k < 4; ++k) if (tidx[k] >= 0) {
+                        if (t->c == 3) { gb[tidx[k]*3+0] += twgt[k] * ga.x; gb[tidx[k]*3+1] += twgt[k] * ga.y; gb[tidx[k]*3+2] += twgt[k] * ga.z; }
+                        else gb[tidx[k]] += twgt[k] * (ga.x + ga.y + ga.z);
+                    }
+                }
+            } else {
+                int32_t slot = g->bsdf_slot[bidx];
+                if (slot >= 0) { float *gb = g->grad + g->layout[slot].offset; gb[0] += ga.x; gb[1] += ga.y; gb[2] += ga.z; }
+            }
+            /* emitter radiance: d Le / d rad = beta_pre*mis*[front];  d Lr_dir / d rad = beta_pre*mis_em*bsdf_value_em / ds.pdf */
+            if (emitter >= 0 && g->em_slot[emitter] >= 0 && le_front) {
+                float *gb = g->grad + g->layout[g->em_slot[emitter]].offset;
+                gb[0] += dL.x * beta_pre.x * le_mis; gb[1] += dL.y * beta_pre.y * le_mis; gb[2] += dL.z * beta_pre.z * le_mis;
+            }
+            if (active_em && ds.emitter >= 0 && g->em_slot[ds.emitter] >= 0) {
+                float *gb = g->grad + g->layout[g->em_slot[ds.emitter]].offset;
+                /* em_weight = em_val / ds.pdf (prb.py:154-155); ds.pdf already carries the emitter pmf (scene.cpp:324) */
+                v3 w = scale3(mul3(scale3(beta_pre, mis_em), bsdf_value_em), rcpf_(ds.pdf));
+                gb[0] += dL.x * w.x; gb[1] += dL.y * w.y; gb[2] += dL.z * w.z;
+            }
+        }
+        depth += 1;                                                       /* prb.py:249 (si valid here) */
+        active = active_next;
+    }
+    *L_out = L; *valid_out = depth != 0;
+}
+
+/* ----------------------------------------------------------------------------------------
+ * film: ImageBlock::put coalesced path (imageblock.cpp:418-531), HDRFilm::develop (hdrfilm.cpp:304-409)
+ * ---------------------------------------------------------------------------------------- */
+static inline float filter_eval(const OScene *sc, float x) {
+    if (sc->sensor.rfilter == MI355_RFILTER_GAUSSIAN) return gaussian_eval(sc->filter_coeff, x);
+    return tent_eval(sc->filter_radius, x);
+}
+/* returns the number of taps per axis and fills weights; (x0, y0) = top-left tap (film-local) */
+static int splat_weights(const OScene *sc, v2 pos, int32_t *x0, int32_t *y0, float *wx, float *wy) {
+    if (sc->sensor.rfilter == MI355_RFILTER_BOX) {                       /* imageblock.cpp:210-233 */
+        *x0 = (int32_t) floorf(pos.x) - (int32_t) sc->sensor.crop_offset_x;
+        *y0 = (int32_t) floorf(pos.y) - (int32_t) sc->sensor.crop_offset_y;
+        wx[0] = wy[0] = 1.f; return 1;
+    }
+    int n = (int) ceilf(sc->filter_radius - .5f), count = 2 * n + 1;
+    int32_t pix = (int32_t) floorf(pos.x) - n, piy = (int32_t) floorf(pos.y) - n;
+    *x0 = pix - (int32_t) sc->sensor.crop_offset_x; *y0 = piy - (int32_t) sc->sensor.crop_offset_y;
+    float rx = (float) pix + .5f - pos.x, ry = (float) piy + .5f - pos.y;
+    for (int i = 0; i < count; ++i) { wx[i] = filter_eval(sc, rx); wy[i] = filter_eval(sc, ry); rx += 1.f; ry += 1.f; }
+    return count;
+}
+static void film_put(const OScene *sc, float *film, int channels, v2 pos, const float *values) {
+    int32_t x0, y0; float wx[16], wy[16];
+    int count = splat_weights(sc, pos, &x0, &y0, wx, wy);
+    int32_t W = (int32_t) sc->sensor.crop_width, H = (int32_t) sc->sensor.crop_height;
+    for (int ys = 0; ys < count; ++ys) for (int xs = 0; xs < count; ++xs) {
+        int32_t x = x0 + xs, y = y0 + ys;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        float w = wy[ys] * wx[xs];
+        for (int k = 0; k < channels; ++k) film[((size_t) y * W + x) * channels + k] += values[k] * w;
+    }
+}
+ORC_API void orc_film_develop(const OScene *sc, const float *film_rgbw, float *image_rgb) {
+    size_t n = (size_t) sc->sensor.crop_width * sc->sensor.crop_height;
+    for (size_t i = 0; i < n; ++i) {
+        float w = film_rgbw[4*i+3]; float dv = (w == 0.f) ? 1.f : w;
+        for (int c = 0; c < 3; ++c) image_rgb[3*i+c] = film_rgbw[4*i+c] / dv;
+    }
+}
+/* test hook for ImageBlock::put KATs */
+ORC_API void orc_film_put(const OScene *sc, float *film_rgbw, const float *pos2, const float *values4, int n) {
+    for (int i = 0; i < n; ++i) { v2 p = { pos2[2*i], pos2[2*i+1] }; film_put(sc, film_rgbw, 4, p, values4 + 4*i); }
+}
+
+/* ----------------------------------------------------------------------------------------
+ * drivers
+ * ---------------------------------------------------------------------------------------- */
+static void shard_bounds(const OScene *sc, const mi355_render_params *rp, uint32_t *p0, uint32_t *pn, uint32_t *s0, uint32_t *sn) {
+    uint32_t npix = sc->sensor.crop_width * sc->sensor.crop_height;
+    *p0 = rp->pixel_begin; *pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin;
+    *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : rp->spp - rp->spp_begin;
+}
+static void trace_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane, v3 *rgb, int *valid, v2 *pos, Cnt *cnt) {
+    pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+    int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
+    v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);   /* integrator.cpp:435 */
+    Ray ray = sample_primary_ray(sc, sp);
+    if (rp->integrator == MI355_INTEGRATOR_PRB) prb_sample(sc, &rng, ray, rp, 0, V3(0,0,0), V3(0,0,0), NULL, rgb, valid, cnt);
+    else path_sample(sc, &rng, ray, rp, rgb, valid, cnt);
+    *pos = sp;
+}
+/* per-lane radiance for lanes [lane_begin, lane_begin+count): out = count x 4 (r,g,b,valid) */
+ORC_API void orc_lane_radiance(OScene *sc, const mi355_render_params *rp, uint32_t lane_begin, uint32_t count, float *out) {
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t) count; ++i) {
+        v3 rgb; int valid; v2 pos; Cnt c = { 0, 0, 0 };
+        trace_lane(sc, rp, lane_begin + (uint32_t) i, &rgb, &valid, &pos, &c);
+        out[4*i] = rgb.x; out[4*i+1] = rgb.y; out[4*i+2] = rgb.z; out[4*i+3] = (float) valid;
+    }
+}
+/* SamplingIntegrator::render JIT branch (integrator.cpp:246-360): accumulate the shard's lanes
+   into film_rgbw (H x W x 4, not cleared).  Returns the number of lanes traced. */
+ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
+    uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
+    size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    float *films = (float *) calloc(fsz * (size_t) n_threads, sizeof(float));
+    uint64_t ci = 0, cs = 0, csh = 0;
+    #pragma omp parallel num_threads(n_threads) reduction(+:ci, cs, csh)
+    {
+#ifdef _OPENMP
+        float *film = films + fsz * (size_t) omp_get_thread_num();
+#else
+        float *film = films;
+#endif
+        Cnt cnt = { 0, 0, 0 };
+        #pragma omp for schedule(dynamic, 64)
+        for (int64_t p = (int64_t) p0; p < (int64_t) (p0 + pn); ++p) {
+            for (uint32_t s = s0; s < s0 + sn; ++s) {
+                uint32_t lane = (uint32_t) p * rp->spp + s;
+                v3 rgb; int valid; v2 pos;
+                trace_lane(sc, rp, lane, &rgb, &valid, &pos, &cnt);
+                float vals[4] = { rgb.x, rgb.y, rgb.z, 1.f };           /* integrator.cpp:477-486 (no alpha) */
+                film_put(sc, film, 4, pos, vals);
+            }
+        }
+        ci += cnt.isect; cs += cnt.shade; csh += cnt.shadow;
+    }
+    for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
+    free(films);
+    sc->c_isect += ci; sc->c_shade += cs; sc->c_shadow += csh;
+    return (uint64_t) pn * sn;
+}
+
+/* parameter layout shared with the engine's definition (include/mi355.h: mi355_scene_param_layout):
+   bsdf reflectances (constant ones), then textures, then emitter radiances, in index order */
+ORC_API int orc_param_layout(const OScene *sc, mi355_param_info *out, uint32_t cap, uint64_t *total) {
+    uint32_t n = 0; uint64_t off = 0;
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) if (sc->bsdfs[i].type == MI355_BSDF_DIFFUSE && sc->bsdfs[i].reflectance_texture < 0) {
+        if (n < cap) { out[n].kind = MI355_PARAM_BSDF_REFLECTANCE; out[n].index = i; out[n].offset = off; out[n].size = 3; } n++; off += 3; }
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        uint64_t sz = (uint64_t) sc->textures[i].w * sc->textures[i].h * sc->textures[i].c;
+        if (n < cap) { out[n].kind = MI355_PARAM_TEXTURE_DATA; out[n].index = i; out[n].offset = off; out[n].size = sz; } n++; off += sz; }
+    for (uint32_t i = 0; i < sc->n_emitters; ++i) {
+        if (n < cap) { out[n].kind = MI355_PARAM_EMITTER_RADIANCE; out[n].index = i; out[n].offset = off; out[n].size = 3; } n++; off += 3; }
+    if (total) *total = off;
+    return (int) n;
+}
+
+/* RBIntegrator.render_backward step 1a (common.py:741-758): W[p] = sum of filter weights */
+ORC_API void orc_prb_splat_weights(OScene *sc, const mi355_render_params *rp, float *weight_hw) {
+    uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
+    for (uint32_t p = p0; p < p0 + pn; ++p) for (uint32_t s = s0; s < s0 + sn; ++s) {
+        uint32_t lane = p * rp->spp + s; pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+        int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
+        v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);
+        float one = 1.f; film_put(sc, weight_hw, 1, sp, &one);
+    }
+}
+/* adjoint of splat + develop for one lane: dL_c = sum_taps grad_in[p,c] * w(p) / W[p] */
+static v3 delta_L(const OScene *sc, v2 pos, const float *grad_in, const float *weight_hw) {
+    int32_t x0, y0; float wx[16], wy[16]; int count = splat_weights(sc, pos, &x0, &y0, wx, wy);
+    int32_t W = (int32_t) sc->sensor.crop_width, H = (int32_t) sc->sensor.crop_height;
+    v3 r = V3(0, 0, 0);
+    for (int ys = 0; ys < count; ++ys) for (int xs = 0; xs < count; ++xs) {
+        int32_t x = x0 + xs, y = y0 + ys; if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        size_t i = (size_t) y * W + x; float wv = weight_hw[i]; float dv = wv == 0.f ? 1.f : wv;
+        float w = wy[ys] * wx[xs] / dv;
+        r.x += grad_in[3*i] * w; r.y += grad_in[3*i+1] * w; r.z += grad_in[3*i+2] * w;
+    }
+    return r;
+}
+/* RBIntegrator.render_backward steps 1b-3 (common.py:741-796); gradients are ACCUMULATED into grad */
+ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, const float *grad_in,
+                                 const float *weight_hw, float *grad, int n_threads) {
+    uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
+    mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
+    int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1)), *em_slot = (int32_t *) malloc(4 * (sc->n_emitters + 1));
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) bsdf_slot[i] = -1;
+    for (uint32_t i = 0; i < sc->n_textures; ++i) tex_slot[i] = -1;
+    for (uint32_t i = 0; i < sc->n_emitters; ++i) em_slot[i] = -1;
+    for (int i = 0; i < np; ++i) {
+        if (layout[i].kind == MI355_PARAM_BSDF_REFLECTANCE) bsdf_slot[layout[i].index] = i;
+        else if (layout[i].kind == MI355_PARAM_TEXTURE_DATA) tex_slot[layout[i].index] = i;
+        else em_slot[layout[i].index] = i;
+    }
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    float *grads = (float *) calloc((size_t) total * (size_t) n_threads, sizeof(float));
+    #pragma omp parallel num_threads(n_threads)
+    {
+#ifdef _OPENMP
+        float *gl = grads + total * (size_t) omp_get_thread_num();
+#else
+        float *gl = grads;
+#endif
+        GradCtx g = { gl, layout, (uint32_t) np, bsdf_slot, tex_slot, em_slot };
+        Cnt cnt = { 0, 0, 0 };
+        #pragma omp for schedule(dynamic, 64)
+        for (int64_t p = (int64_t) p0; p < (int64_t) (p0 + pn); ++p) for (uint32_t s = s0; s < s0 + sn; ++s) {
+            uint32_t lane = (uint32_t) p * rp->spp + s;
+            pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+            int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
+            v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);
+            Ray ray = sample_primary_ray(sc, sp);
+            v3 dL = delta_L(sc, sp, grad_in, weight_hw);
+            pcg32 rng2 = rng;                                            /* sampler.clone(), common.py:767 */
+            v3 L; int valid;
+            prb_sample(sc, &rng2, ray, rp, 0, V3(0,0,0), V3(0,0,0), NULL, &L, &valid, &cnt);
+            v3 L2;
+            prb_sample(sc, &rng, ray, rp, 1, dL, L, &g, &L2, &valid, &cnt);
+        }
+    }
+    for (int t = 0; t < n_threads; ++t) for (uint64_t i = 0; i < total; ++i) grad[i] += grads[total * (size_t) t + i];
+    free(grads); free(bsdf_slot); free(tex_slot); free(em_slot);
+}
+
+/* ----------------------------------------------------------------------------------------
+ * ray-level test hooks (Scene::ray_intersect / ray_test on caller rays)
+ * rays: n x 8 (o, d, maxt, pad); hits: n x 8 (t, u, v, prim, shape, occluded, -, -);
+ * si_out (optional): n x 16 (p3, n3, uv2, sh_n3, wi3, t, pad)
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_ray_intersect(OScene *sc, const float *rays, uint32_t n, float *hits, float *si_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r; r.o = V3(rays[8*i], rays[8*i+1], rays[8*i+2]); r.d = V3(rays[8*i+3], rays[8*i+4], rays[8*i+5]); r.maxt = rays[8*i+6];
+        PI pi = scene_intersect(sc, &r);
+        float *h = hits + 8 * i; uint32_t occ = (uint32_t) scene_ray_test(sc, &r);
+        h[0] = pi.t; h[1] = pi.prim_uv.x; h[2] = pi.prim_uv.y; memcpy(&h[3], &pi.prim_index, 4); memcpy(&h[4], &pi.shape_index, 4); memcpy(&h[5], &occ, 4); h[6] = h[7] = 0;
+        if (si_out) {
+            SI si = compute_si(sc, &r, &pi); float *o = si_out + 16 * i;
+            o[0] = si.p.x; o[1] = si.p.y; o[2] = si.p.z; o[3] = si.n.x; o[4] = si.n.y; o[5] = si.n.z; o[6] = si.uv.x; o[7] = si.uv.y;
+            o[8] = si.sh_n.x; o[9] = si.sh_n.y; o[10] = si.sh_n.z; o[11] = si.wi.x; o[12] = si.wi.y; o[13] = si.wi.z; o[14] = si.t; o[15] = 0;
+        }
+    }
+}
+ORC_API void orc_primary_rays(OScene *sc, const float *sample_pos, uint32_t n, float *rays) {
+    for (uint32_t i = 0; i < n; ++i) {
+        v2 p = { sample_pos[2*i], sample_pos[2*i+1] }; Ray r = sample_primary_ray(sc, p); float *o = rays + 8 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.maxt; o[7] = 0;
+    }
+}
+ORC_API float orc_shape_surface_area(const OScene *sc, uint32_t shape) { return 1.f / sc->shapes[shape].inv_area; }
+ORC_API void orc_texture_eval(const OScene *sc, uint32_t tex, const float *uv, int n, float *out3) {
+    for (int i = 0; i < n; ++i) { v2 q = { uv[2*i], uv[2*i+1] }; v3 r = texture_eval(&sc->textures[tex], q, NULL, NULL); out3[3*i] = r.x; out3[3*i+1] = r.y; out3[3*i+2] = r.z; }
+}
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,180 @@
+"""ctypes wrapper of the CPU oracle (oracle/mi_oracle.c).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(HERE, "mi_oracle.c")
+    hdr = os.path.join(os.path.dirname(HERE), "include", "mi355.h")
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return LIB
+    r = subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "liboracle.so"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+_lib = None
+f32p = C.POINTER(C.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lib(abi):
+    """`abi` = the package's _abi module (ctypes mirror of include/mi355.h: the oracle consumes the same POD records)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    l = C.CDLL(LIB)
+    l.orc_scene_create.restype = C.c_void_p
+    l.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
+    l.orc_scene_destroy.argtypes = [C.c_void_p]
+    l.orc_scene_set_param.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+    l.orc_tea_float32.restype = C.c_float
+    l.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    l.orc_tea_float64.restype = C.c_double
+    l.orc_tea_float64.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    l.orc_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    l.orc_pcg32_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    l.orc_sampler_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    l.orc_perspective_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    l.orc_gaussian_coeffs.argtypes = [C.c_float, C.c_void_p]
+    l.orc_gaussian_eval.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    l.orc_square_to_cosine_hemisphere.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    l.orc_diffuse_eval_pdf.argtypes = [C.c_void_p] * 5
+    l.orc_diffuse_sample.argtypes = [C.c_void_p] * 6
+    l.orc_lane_radiance.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_uint32, C.c_uint32, C.c_void_p]
+    l.orc_render_accumulate.restype = C.c_uint64
+    l.orc_render_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int]
+    l.orc_film_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    l.orc_film_put.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_param_layout.restype = C.c_int
+    l.orc_param_layout.argtypes = [C.c_void_p, C.POINTER(abi.ParamInfo), C.c_uint32, C.POINTER(C.c_uint64)]
+    l.orc_prb_splat_weights.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p]
+    l.orc_render_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_ray_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    l.orc_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    l.orc_shape_surface_area.restype = C.c_float
+    l.orc_shape_surface_area.argtypes = [C.c_void_p, C.c_uint32]
+    l.orc_texture_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+    l.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_num_threads.restype = C.c_int
+    _lib = l
+    return l
+
+
+class OracleScene:
+    """CPU twin of a package Scene: built from the same mi355_scene_desc."""
+
+    def __init__(self, scene, abi):
+        self.abi = abi
+        self.l = lib(abi)
+        self.scene = scene
+        d = scene.desc()
+        self.h = self.l.orc_scene_create(C.byref(d))
+        if not self.h:
+            raise RuntimeError("oracle rejected the scene description")
+        f = scene.sensor.film
+        self.W, self.H = f.crop_width, f.crop_height
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.l.orc_scene_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+    def params(self, integrator, seed, spp, shard=None, spp_shard=None):
+        return integrator._params(self.scene, seed, spp, shard=shard, spp_shard=spp_shard)
+
+    def set_param(self, kind, index, values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        assert self.l.orc_scene_set_param(self.h, kind, index, _p(v), v.size) == 0
+
+    def lane_radiance(self, p, lane_begin, count):
+        out = np.empty((count, 4), dtype=np.float32)
+        self.l.orc_lane_radiance(self.h, C.byref(p), lane_begin, count, _p(out))
+        return out
+
+    def render(self, p, threads=0, develop=True):
+        film = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        n = self.l.orc_render_accumulate(self.h, C.byref(p), _p(film), threads)
+        if not develop:
+            return film, n
+        img = np.empty((self.H, self.W, 3), dtype=np.float32)
+        self.l.orc_film_develop(self.h, _p(film), _p(img))
+        return img, n
+
+    def develop(self, film):
+        film = np.ascontiguousarray(film, dtype=np.float32)
+        img = np.empty((self.H, self.W, 3), dtype=np.float32)
+        self.l.orc_film_develop(self.h, _p(film), _p(img))
+        return img
+
+    def film_put(self, pos, values):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 2); values = np.ascontiguousarray(values, dtype=np.float32).reshape(-1, 4)
+        film = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        self.l.orc_film_put(self.h, _p(film), _p(pos), _p(values), pos.shape[0])
+        return film
+
+    def param_layout(self):
+        arr = (self.abi.ParamInfo * 4096)(); total = C.c_uint64()
+        n = self.l.orc_param_layout(self.h, arr, 4096, C.byref(total))
+        return [(arr[i].kind, arr[i].index, arr[i].offset, arr[i].size) for i in range(n)], total.value
+
+    def splat_weights(self, p):
+        w = np.zeros((self.H, self.W), dtype=np.float32)
+        self.l.orc_prb_splat_weights(self.h, C.byref(p), _p(w))
+        return w
+
+    def render_backward(self, p, grad_in, weight=None, threads=0):
+        if weight is None:
+            weight = self.splat_weights(p)
+        _, total = self.param_layout()
+        g = np.zeros(max(total, 1), dtype=np.float32)
+        grad_in = np.ascontiguousarray(grad_in, dtype=np.float32); weight = np.ascontiguousarray(weight, dtype=np.float32)
+        self.l.orc_render_backward(self.h, C.byref(p), _p(grad_in), _p(weight), _p(g), threads)
+        return g
+
+    def ray_intersect(self, rays, with_si=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.empty((rays.shape[0], 8), dtype=np.float32)
+        si = np.empty((rays.shape[0], 16), dtype=np.float32) if with_si else None
+        self.l.orc_ray_intersect(self.h, _p(rays), rays.shape[0], _p(hits), _p(si) if with_si else None)
+        return (hits, si) if with_si else hits
+
+    def primary_rays(self, sample_pos):
+        sp = np.ascontiguousarray(sample_pos, dtype=np.float32).reshape(-1, 2)
+        rays = np.empty((sp.shape[0], 8), dtype=np.float32)
+        self.l.orc_primary_rays(self.h, _p(sp), sp.shape[0], _p(rays))
+        return rays
+
+    def surface_area(self, shape):
+        return float(self.l.orc_shape_surface_area(self.h, shape))
+
+    def texture_eval(self, tex, uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        out = np.empty((uv.shape[0], 3), dtype=np.float32)
+        self.l.orc_texture_eval(self.h, tex, _p(uv), uv.shape[0], _p(out))
+        return out
+
+    def counters(self, reset=False):
+        c = np.zeros(3, dtype=np.uint64)
+        self.l.orc_get_counters(self.h, _p(c), 1 if reset else 0)
+        return {"n_isect": int(c[0]), "n_shade": int(c[1]), "n_shadow": int(c[2])}
+
+
+def unpack_hits(hits):
+    """n x 8 float32 -> dict with integer fields reinterpreted."""
+    u = hits.view(np.uint32)
+    return {"t": hits[:, 0], "u": hits[:, 1], "v": hits[:, 2], "prim": u[:, 3], "shape": u[:, 4], "occluded": u[:, 5]}
