@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+A "step" is one full forward render of BASELINE config C2: Cornell box (mi.cornell_box(), util.py:565-699),
+512x512 @ 256 spp, path integrator max_depth=6 / rr_depth=5, seed = step index: 67 108 864 camera paths through
+PathIntegrator::sample + film splat + develop, scene already resident in HBM.  value = Msamples/s =
+W*H*spp / wall-seconds, whole job.  With N > 1 ranks the sample plane is cut into 16-row tiles dealt round-robin
+to the ranks (strong scaling, total work fixed); the only exchange is one all-reduce (RCCL) of the 4 MB RGBW
+accumulator before develop.
+
+The same JSON line carries
+  roofline      algorithmic bytes (88 N_gen + 48 N_isect + 196 N_shade + 104 N_shadow + 20 N_splat
+                + 60 H W, from the engine's device counters) / HIP-event time of the path kernel, vs 8 TB/s HBM3E
+  cpu_baseline  the CPU oracle (scalar C restatement, OpenMP over all host cores) on a bounded sample of the same
+                workload (512x512 at a few spp), rank 0, N = 1 only
+  prb           PRB backward (BASELINE config C3: 512x512 @ 64 spp, gradient w.r.t. a 256x256x3 albedo texture on the
+                back wall + all constant albedos / the emitter) in Msamples/s -- measured after the timed steps.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package, load_oracle  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6.3 TB/s
+TILE_ROWS = 16
+
+
+def algorithmic_bytes(c, n_pixels_developed):
+    return (88 * c["n_gen"] + 48 * c["n_isect"] + 196 * c["n_shade"] + 104 * c["n_shadow"] + 20 * c["n_splat"]
+            + 60 * n_pixels_developed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--prb-spp", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mi = load_package()
+    lib = mi.abi.lib()
+    d = mi.cornell_box()
+    d["sensor"]["film"]["width"] = args.res; d["sensor"]["film"]["height"] = args.res
+    scene = mi.load_dict(d)
+    integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+    integ.timing = True
+    h = scene.handle(local_rank)
+    dev = torch.device("cuda", local_rank)
+    W = H = args.res
+    npix = W * H
+    n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
+    my_tiles = [t for t in range(n_tiles) if t % world == rank]
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    img = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step(seed):
+        film.zero_()
+        if world == 1:
+            p = integ._params(scene, seed, args.spp)
+            mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
+        else:
+            for t in my_tiles:
+                b = t * TILE_ROWS * W; n = min(TILE_ROWS * W, npix - b)
+                p = integ._params(scene, seed, args.spp, shard=(b, n))
+                mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
+            dist.all_reduce(film, op=dist.ReduceOp.SUM)
+        mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    barrier()
+    integ.counters(scene, reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    cnt = integ.counters(scene, reset=True)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(img).all()
+    lanes_per_step = npix * args.spp
+    value = lanes_per_step * args.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (this rank's launches) ------------------------------------
+    launches = max(cnt["kernel_launches"], 1)
+    kernel_ms = cnt["kernel_ms"] / launches
+    alg = algorithmic_bytes(cnt, npix * args.steps * (len(my_tiles) / n_tiles if world > 1 else 1.0)) / launches
+    achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_render<path,film>", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                "algorithmic_bytes_per_launch": int(alg),
+                "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}
+
+    # ---- PRB backward leg (config C3) ------------------------------------------------------------------
+    prb = None
+    if not args.no_prb:
+        d3 = mi.cornell_box()
+        d3["sensor"]["film"]["width"] = args.res; d3["sensor"]["film"]["height"] = args.res
+        rng = np.random.default_rng(12345)
+        d3["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
+                                                         "data": rng.uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
+        d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+        scene3 = mi.load_dict(d3)
+        prb_i = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb_i.timing = True
+        params = mi.traverse(scene3)
+        gin = torch.ones((H, W, 3), dtype=torch.float32, device=dev)
+        shard = (rank, world) if world > 1 else None
+        n_prb = max(2, args.steps // 2)
+        prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(0, 1)[0], spp=args.prb_spp, shard=shard)
+        barrier(); prb_i.counters(scene3, reset=True)
+        t0 = time.perf_counter()
+        for i in range(n_prb):
+            params.zero_grad()
+            prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(i, 1)[0], spp=args.prb_spp, shard=shard)
+        barrier()
+        dtb = time.perf_counter() - t0
+        c3 = prb_i.counters(scene3, reset=True)
+        if dist is not None:
+            tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
+        g = params.grad("tex.reflectance.data")
+        prb = {"metric": "Msamples/s PRB backward (primal replay + adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
+               "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
+               "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
+               "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
+        scene3.release()
+
+    # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        orc = load_oracle()
+        o = orc.OracleScene(scene, mi.abi)
+        threads = o.l.orc_num_threads()
+        t0 = time.perf_counter(); _, n = o.render(o.params(integ, 0, 1)); t1 = time.perf_counter() - t0
+        spp_cpu = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
+        t0 = time.perf_counter(); _, n = o.render(o.params(integ, 0, spp_cpu)); t2 = time.perf_counter() - t0
+        cpu = {"value": round(n / t2 / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
+               "sample": "same scene/integrator, %dx%d @ %d spp (%d lanes, %.1f s), oracle/mi_oracle.c with OpenMP" % (W, H, spp_cpu, n, t2)}
+
+    if rank == 0:
+        out = {"metric": "Msamples/sec fwd + PRB grad, Cornell 512^2 @256spp", "value": round(value, 2), "unit": "Msamples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
+                          "lanes_per_step": lanes_per_step, "mode": "fused", "sharding": "16-row tiles round-robin, film all-reduce" if world > 1 else "none"},
+               "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
+        print(json.dumps(out), flush=True)
+    scene.release()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

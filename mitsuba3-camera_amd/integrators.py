@@ -49,6 +49,36 @@ def shard_pixels(n_pixels, rank, world):
     return b, e - b
 
 
+class HipBackend:
+    """The product back-end: every call goes to libmi355.so through the C ABI (no fallback).  Tests may
+    substitute an object with the same five methods to exercise the sharding / collective logic on CPU."""
+    name = "hip"
+
+    def device(self, scene):
+        torch = _torch()
+        scene.handle()
+        return torch.device("cuda", scene._device)
+
+    def accumulate(self, scene, p, film):
+        abi.check(abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), _stream_ptr(film.device)))
+
+    def develop(self, scene, film, img):
+        abi.check(abi.lib().mi355_film_develop(scene.handle(), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), _stream_ptr(film.device)))
+
+    def splat_weights(self, scene, p, weight):
+        abi.check(abi.lib().mi355_prb_splat_weights(scene.handle(), C.byref(p), C.c_void_p(weight.data_ptr()), _stream_ptr(weight.device)))
+
+    def backward(self, scene, p, grad_in, weight, grads):
+        abi.check(abi.lib().mi355_render_backward(scene.handle(), C.byref(p), C.c_void_p(grad_in.data_ptr()),
+                                                  C.c_void_p(weight.data_ptr()), C.c_void_p(grads.data_ptr()), _stream_ptr(grads.device)))
+
+    def param_total(self, scene):
+        return scene_param_total(scene)
+
+    def synchronize(self, device):
+        _torch().cuda.current_stream(device).synchronize()
+
+
 class Integrator:
     """Common part of MonteCarloIntegrator (integrator.cpp:505-522) and ADIntegrator (common.py:20-60)."""
     integrator_id = abi.INTEGRATOR_PATH
@@ -66,6 +96,7 @@ class Integrator:
         self.hide_emitters = bool(props.get("hide_emitters", False))
         self.mode = abi.MODE_FUSED
         self.timing = False
+        self.backend = HipBackend()
 
     default_max_depth = -1
 
@@ -99,8 +130,8 @@ class Integrator:
         RGBW accumulator.  `shard=(rank, world)`: this process renders its pixel band and the accumulators are
         summed over `group` (torch.distributed) before develop."""
         torch = _torch()
-        h = scene.handle()
-        dev = torch.device("cuda", scene._device)
+        be = self.backend
+        dev = be.device(scene)
         f = scene.sensor.film
         spp = self._resolve_spp(scene, spp)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
@@ -108,18 +139,17 @@ class Integrator:
         if shard is not None:
             band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1])
         p = self._params(scene, seed, spp, shard=band)
-        st = _stream_ptr(dev)
         if band is None or band[1] > 0:
-            abi.check(abi.lib().mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), st))
+            be.accumulate(scene, p, film)
         if shard is not None and shard[1] > 1:
             import torch.distributed as dist
             dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
         if not develop:
             return film
         img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
-        abi.check(abi.lib().mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), st))
+        be.develop(scene, film, img)
         if evaluate:
-            torch.cuda.current_stream(dev).synchronize()
+            be.synchronize(dev)
         return img
 
     # ---- Integrator::render_backward ---------------------------------------------------------------
@@ -128,8 +158,8 @@ class Integrator:
         (and returns it).  Default implementation of the reference (integrator.cpp:65-84) records the whole
         primal with AD; the path integrator here shares PRB's adjoint kernels instead."""
         torch = _torch()
-        h = scene.handle()
-        dev = torch.device("cuda", scene._device)
+        be = self.backend
+        dev = be.device(scene)
         f = scene.sensor.film
         spp = self._resolve_spp(scene, spp)
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
@@ -138,22 +168,21 @@ class Integrator:
         band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1]) if shard is not None else None
         p = self._params(scene, seed, spp, shard=band)
         p.integrator = abi.INTEGRATOR_PRB
-        st = _stream_ptr(dev)
         weight = torch.zeros((f.crop_height, f.crop_width), dtype=torch.float32, device=dev)
         active = band is None or band[1] > 0
+        multi = shard is not None and shard[1] > 1
         if active:
-            abi.check(abi.lib().mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(weight.data_ptr()), st))
-        if shard is not None and shard[1] > 1:
+            be.splat_weights(scene, p, weight)
+        if multi:
             import torch.distributed as dist
-            dist.all_reduce(weight, op=dist.ReduceOp.SUM, group=group)
-        grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(scene_param_total(scene), 1), device=dev)
-        local = torch.zeros_like(grads) if (shard is not None and shard[1] > 1) else grads
+            dist.all_reduce(weight, op=dist.ReduceOp.SUM, group=group)      # every rank needs the same W[p] (common.py:741-758)
+        grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(be.param_total(scene), 1), dtype=torch.float32, device=dev)
+        local = torch.zeros_like(grads) if multi else grads
         if active:
-            abi.check(abi.lib().mi355_render_backward(h, C.byref(p), C.c_void_p(grad_in.data_ptr()),
-                                                      C.c_void_p(weight.data_ptr()), C.c_void_p(local.data_ptr()), st))
-        if shard is not None and shard[1] > 1:
+            be.backward(scene, p, grad_in, weight, local)
+        if multi:
             import torch.distributed as dist
-            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)      # the ONE collective of the adjoint path
+            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)       # the ONE collective of the adjoint data path
             grads += local
         return grads
 

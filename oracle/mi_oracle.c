@@ -808,7 +808,9 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
                 float *gb = g->grad + g->layout[g->em_slot[emitter]].offset;
                 gb[0] += dL.x * beta_pre.x * le_mis; gb[1] += dL.y * beta_pre.y * le_mis; gb[2] += dL.z * beta_pre.z * le_mis;
             }
-            if (active_em && ds.emitter >= 0 && g->em_slot[ds.emitter] >= 0) {
+            /* eval_emitter_direction masks back-facing samples (area.cpp:199-209): their ds.pdf is non-zero
+               (only occlusion zeroes it, scene.cpp:343-345) but em_val = 0, so they carry no gradient */
+            if (active_em && ds.emitter >= 0 && g->em_slot[ds.emitter] >= 0 && dot3(ds.d, ds.n) < 0.f) {
                 float *gb = g->grad + g->layout[g->em_slot[ds.emitter]].offset;
                 /* em_weight = em_val / ds.pdf (prb.py:154-155); ds.pdf already carries the emitter pmf (scene.cpp:324) */
                 v3 w = scale3(mul3(scale3(beta_pre, mis_em), bsdf_value_em), rcpf_(ds.pdf));

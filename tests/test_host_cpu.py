@@ -1,0 +1,162 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every declared symbol, the dict
+loader mirrors Mitsuba's error behaviour, and the multi-GPU decomposition (pixel bands + all-reduce of film,
+weights and gradients) is correct with world_size = 2 over gloo."""
+import ctypes as C
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(mi):
+    lib = mi.abi.lib()
+    hdr = open(os.path.join(ROOT, "include", "mi355.h")).read()
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    bound = {name for name, _, _ in mi.abi.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mi355_abi_version() == mi.abi.ABI_VERSION
+
+
+def test_struct_layouts_match_header(mi):
+    """ctypes mirrors vs the C compiler's view of include/mi355.h (sizes + a few offsets)."""
+    import subprocess, tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "mi355.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi355_texture_desc), sizeof(mi355_bsdf_desc), sizeof(mi355_emitter_desc),
+         sizeof(mi355_shape_desc), sizeof(mi355_sensor_desc), sizeof(mi355_scene_desc), sizeof(mi355_render_params),
+         sizeof(mi355_counters), sizeof(mi355_param_info));
+  printf("%zu %zu %zu\n", offsetof(mi355_shape_desc, faces), offsetof(mi355_scene_desc, sensor), offsetof(mi355_sensor_desc, lens_data));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", os.path.join(td, "t")])
+        out = subprocess.check_output([os.path.join(td, "t")]).decode().split()
+    a = mi.abi
+    sizes = [C.sizeof(x) for x in (a.TextureDesc, a.BsdfDesc, a.EmitterDesc, a.ShapeDesc, a.SensorDesc, a.SceneDesc, a.RenderParams, a.Counters, a.ParamInfo)]
+    assert [int(x) for x in out[:9]] == sizes
+    assert [int(x) for x in out[9:]] == [a.ShapeDesc.faces.offset, a.SceneDesc.sensor.offset, a.SensorDesc.lens_data.offset]
+
+
+def test_no_gpu_means_loud_failure(mi):
+    """Without a device the product path must refuse to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    scene = mi.load_dict(mi.cornell_box())
+    with pytest.raises(mi.Mi355Error) as e:
+        scene.handle(0)
+    assert e.value.code == mi.abi.ERR_NO_DEVICE
+
+
+def test_load_dict_errors_and_scope(mi):
+    d = mi.cornell_box()
+    sc = mi.load_dict(d)
+    assert len(sc.shapes) == 8 and len(sc.bsdfs) == 3 and len(sc.emitters) == 1
+    assert sc.sensor.film.size() == (256, 256) and sc.sensor.sample_count == 64
+    assert abs(sc.sensor.x_fov - 39.3077) < 1e-4
+    assert sc.integrator().max_depth == 8 and sc.integrator().rr_depth == 5
+    assert mi.PRBIntegrator().max_depth == 6                        # common.py:31
+    for bad in ({"type": "sphere"}, {"type": "frobnicator"}):
+        with pytest.raises(mi.PluginError):
+            mi.load_dict({"type": "scene", "x": bad})
+    with pytest.raises(mi.PluginError):                             # reflectance outside [0,1] (srgb.cpp:52-66)
+        mi.load_dict({"type": "scene", "b": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.5, 0, 0]}}})
+    with pytest.raises(mi.PluginError):                             # dangling reference
+        mi.load_dict({"type": "scene", "r": {"type": "rectangle", "bsdf": {"type": "ref", "id": "nope"}}})
+    with pytest.raises(mi.PluginError):                             # camera scale (perspective.cpp:144-145)
+        mi.load_dict({"type": "scene", "sensor": {"type": "perspective", "to_world": mi.ScalarTransform4f.scale(2.0)}})
+    with pytest.raises(mi.PluginError):
+        mi.PathIntegrator({"rr_depth": 0})
+    with pytest.raises(mi.PluginError):
+        mi.load_dict({"type": "scene", "t": {"type": "diffuse", "reflectance": {"type": "bitmap", "data": np.zeros((1, 4, 3))}}})
+    # Appendix C of SURVEY.md: resolved world-space geometry of the fixture
+    light = [s for s in sc.shapes if s.id == "light"][0]
+    assert np.allclose(light.to_world.transform_affine([0, 0, 0]), [0, 0.99, 0.01], atol=1e-6)
+    assert np.allclose(light.to_world.transform_normal([0, 0, 1]) / np.linalg.norm(light.to_world.transform_normal([0, 0, 1])), [0, -1, 0], atol=1e-6)
+    assert abs(light.surface_area() - 0.1748) < 1e-4
+    lb = [s for s in sc.shapes if s.id == "large-box"][0]
+    lo, hi = lb.bbox()
+    assert abs(lo[1] + 1.01) < 1e-5 and abs(hi[1] - 0.21) < 1e-5
+
+
+def test_obj_loader(mi, tmp_path):
+    p = tmp_path / "quad.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    sc = mi.load_dict({"type": "scene", "q": {"type": "obj", "filename": str(p), "to_world": mi.ScalarTransform4f.translate([0, 0, 2])}})
+    s = sc.shapes[0]
+    assert s.primitive_count() == 2 and s.vertex_positions.shape == (4, 3) and np.allclose(s.vertex_positions[:, 2], 2)
+    assert np.isclose(s.surface_area(), 1.0) and s.vertex_normals is not None and s.vertex_texcoords is not None
+
+
+def test_shard_pixels_partition(mi):
+    for n, w in [(1024, 1), (1024, 3), (1000, 8), (7, 8)]:
+        cover = np.zeros(n, dtype=int)
+        for r in range(w):
+            b, c = mi.shard_pixels(n, r, w)
+            cover[b:b + c] += 1
+        assert (cover == 1).all()
+
+
+# ---- world_size = 2 over gloo --------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from __graft_entry__ import load_package, load_oracle
+    from conftest import small_cbox
+    mi = load_package(); orc = load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = small_cbox(mi, 16)
+    tex = np.random.default_rng(12345).uniform(0.2, 0.8, (4, 4, 3)).astype(np.float32)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    scene = mi.load_dict(d)
+    o = orc.OracleScene(scene, mi.abi)
+
+    class OracleBackend:
+        """Stands in for the HIP back-end so that the sharding + collectives of integrators.py run on CPU."""
+        name = "oracle-test"
+        def device(self, scene): return torch.device("cpu")
+        def accumulate(self, scene, p, film): film += torch.from_numpy(o.render(p, threads=2, develop=False)[0])
+        def develop(self, scene, film, img): img.copy_(torch.from_numpy(o.develop(film.numpy())))
+        def splat_weights(self, scene, p, weight): weight += torch.from_numpy(o.splat_weights(p))
+        def backward(self, scene, p, grad_in, weight, grads): grads += torch.from_numpy(o.render_backward(p, grad_in.numpy(), weight.numpy(), threads=2))
+        def param_total(self, scene): return o.param_layout()[1]
+        def synchronize(self, device): pass
+
+    integ = mi.PRBIntegrator({"max_depth": 4}); integ.backend = OracleBackend()
+    img = integ.render(scene, seed=3, spp=8, shard=(rank, world))
+    gin = np.random.default_rng(5).normal(size=(16, 16, 3)).astype(np.float32)
+    g = integ.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=8, shard=(rank, world))
+    np.save(os.path.join(out_dir, "img%d.npy" % rank), img.numpy()); np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
+    if rank == 0:
+        whole = mi.PRBIntegrator({"max_depth": 4}); whole.backend = OracleBackend()
+        np.save(os.path.join(out_dir, "img_ref.npy"), whole.render(scene, seed=3, spp=8).numpy())
+        np.save(os.path.join(out_dir, "g_ref.npy"), whole.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=8).numpy())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_sharding_over_gloo(mi, orc, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    img_ref = np.load(tmp_path / "img_ref.npy"); g_ref = np.load(tmp_path / "g_ref.npy")
+    for r in range(2):
+        assert np.allclose(np.load(tmp_path / ("img%d.npy" % r)), img_ref, rtol=1e-5, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / ("g%d.npy" % r)), g_ref, rtol=1e-4, atol=1e-6)
+    assert np.abs(g_ref).max() > 0

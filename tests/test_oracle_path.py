@@ -1,0 +1,177 @@
+"""Self-consistency of the CPU oracle's path / PRB estimators (CPU only).
+
+The reference's EXR images are absent, so the whole-path behaviour is pinned the way the reference's own
+AD tests do it (src/integrators/tests/test_ad_integrators.py:742-828): gradients against finite differences of
+the primal, plus exact identities of the estimator:
+  * radiance is linear in the emitter's `radiance`  =>  d<gin, image>/d rad_c = <gin_c, image_c> / rad_c   (exact)
+  * with Russian roulette disabled the estimator is, for fixed random numbers, a polynomial in every albedo
+    =>  PRB gradient == central finite difference with the SAME seeds                                      (exact to O(eps^2))
+  * path and prb are two estimators of the same integral (they differ only in when RR starts, path.cpp:266-271 vs
+    prb.py:192-198) => image means agree within Monte Carlo error; with RR disabled they are lane-identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import small_cbox
+
+
+def _scene(mi, orc, res=16, **kw):
+    sc = mi.load_dict(small_cbox(mi, res, **kw))
+    return sc, orc.OracleScene(sc, mi.abi)
+
+
+def test_cornell_image_sanity(mi, orc):
+    sc, o = _scene(mi, orc, 32)
+    integ = mi.PathIntegrator({"max_depth": 6})
+    img, n = o.render(o.params(integ, 0, 16))
+    assert n == 32 * 32 * 16 and np.isfinite(img).all() and (img >= 0).all()
+    # red wall on the left, green on the right (camera flips x: sensor.h:261), light visible at the top centre
+    left, right = img[12:20, 1:4].mean((0, 1)), img[12:20, 28:31].mean((0, 1))
+    assert left[0] > 3 * left[1] and right[1] > 2 * right[0]
+    assert img[3:5, 14:18].max() > 5.0
+    # max_depth = 1: only directly visible emitters
+    img1, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 1}), 0, 4))
+    assert (img1[16:] == 0).all() and img1.max() > 5.0
+
+
+def test_depth_is_monotone(mi, orc):
+    sc, o = _scene(mi, orc, 16)
+    means = [o.render(o.params(mi.PathIntegrator({"max_depth": d, "rr_depth": 50}), 1, 32))[0].mean() for d in (1, 2, 3, 5)]
+    assert means[0] < means[1] < means[2] < means[3]
+
+
+def test_path_and_prb_agree(mi, orc):
+    sc, o = _scene(mi, orc, 16)
+    # RR disabled: identical lanes (same RNG consumption order, integrator.cpp:435 / path.cpp / prb.py)
+    a = o.lane_radiance(o.params(mi.PathIntegrator({"max_depth": 5, "rr_depth": 99}), 3, 8), 0, 16 * 16 * 8)
+    b = o.lane_radiance(o.params(mi.PRBIntegrator({"max_depth": 5, "rr_depth": 99}), 3, 8), 0, 16 * 16 * 8)
+    assert np.allclose(a[:, :3], b[:, :3], rtol=1e-5, atol=1e-6)
+    # RR enabled: same expectation
+    ia, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 8, "rr_depth": 2}), 3, 256))
+    ib, _ = o.render(o.params(mi.PRBIntegrator({"max_depth": 8, "rr_depth": 2}), 3, 256))
+    assert abs(ia.mean() - ib.mean()) < 0.02 * ia.mean()
+
+
+def test_seed_and_shard_semantics(mi, orc):
+    """Lanes are a pure function of (seed, global lane id): shards of the sample plane add up to the whole film, and
+    the sampler's base seed adds to the render seed (sampler.cpp:120)."""
+    sc, o = _scene(mi, orc, 16)
+    integ = mi.PathIntegrator({"max_depth": 4})
+    whole, n = o.render(o.params(integ, 5, 8), develop=False)
+    acc = np.zeros_like(whole)
+    for r in range(3):
+        f, _ = o.render(o.params(integ, 5, 8, shard=mi.shard_pixels(256, r, 3)), develop=False)
+        acc += f
+    assert np.allclose(acc, whole, rtol=1e-5, atol=1e-5)
+    acc = np.zeros_like(whole)
+    for r in range(4):
+        f, _ = o.render(o.params(integ, 5, 8, spp_shard=(2 * r, 2)), develop=False)
+        acc += f
+    assert np.allclose(acc, whole, rtol=1e-5, atol=1e-5)
+    d = small_cbox(mi, 16); d["sensor"]["sampler"]["seed"] = 7
+    sc2 = mi.load_dict(d); o2 = orc.OracleScene(sc2, mi.abi)
+    assert o2.params(integ, 5, 8).seed == 12
+    a, _ = o2.render(o2.params(integ, 5, 8)); b, _ = o.render(o.params(integ, 12, 8))
+    assert np.array_equal(a, b)
+
+
+def test_emitter_gradient_linearity_identity(mi, orc):
+    sc, o = _scene(mi, orc, 16)
+    integ = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 3})
+    gin = np.random.default_rng(7).normal(size=(16, 16, 3)).astype(np.float32)
+    p = o.params(integ, 21, 16)
+    g = o.render_backward(p, gin)
+    img, _ = o.render(p)
+    lay, total = o.param_layout()
+    off = [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_EMITTER_RADIANCE][0]
+    expect = (gin * img).sum((0, 1)) / sc.emitters[0].radiance
+    assert np.allclose(g[off:off + 3], expect, rtol=2e-4, atol=1e-5)
+
+
+def _objective(o, p, gin):
+    img, _ = o.render(p)
+    return float((gin.astype(np.float64) * img).sum())
+
+
+@pytest.mark.parametrize("name", ["white", "green", "red"])
+def test_albedo_gradient_matches_finite_differences(mi, orc, name):
+    sc, o = _scene(mi, orc, 16)
+    integ = mi.PRBIntegrator({"max_depth": 5, "rr_depth": 99})        # RR off => polynomial in the albedo
+    gin = np.random.default_rng(3).uniform(0.5, 1.5, size=(16, 16, 3)).astype(np.float32)
+    p = o.params(integ, 9, 8)
+    g = o.render_backward(p, gin)
+    lay, _ = o.param_layout()
+    bi = [i for i, b in enumerate(sc.bsdfs) if b.id == name][0]
+    off = [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_BSDF_REFLECTANCE and i == bi][0]
+    base = sc.bsdfs[bi].reflectance.copy()
+    for c in range(3):
+        eps = 2e-2
+        hi = base.copy(); hi[c] += eps; lo = base.copy(); lo[c] -= eps
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, hi); fp = _objective(o, p, gin)
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, lo); fm = _objective(o, p, gin)
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, base)
+        fd = (fp - fm) / (2 * eps)
+        assert abs(g[off + c] - fd) < 2e-2 * max(abs(fd), 1.0), (name, c, g[off + c], fd)
+
+
+def test_texture_gradient_matches_finite_differences(mi, orc):
+    d = small_cbox(mi, 16)
+    rng = np.random.default_rng(12345)
+    tex = rng.uniform(0.2, 0.8, (4, 4, 3)).astype(np.float32)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    d["large-box"]["bsdf"] = {"type": "ref", "id": "tex"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 99})
+    gin = np.ones((16, 16, 3), dtype=np.float32)
+    p = o.params(integ, 4, 16)
+    g = o.render_backward(p, gin)
+    lay, _ = o.param_layout()
+    off, size = [(o_, s) for k, i, o_, s in lay if k == mi.abi.PARAM_TEXTURE_DATA][0]
+    gt = g[off:off + size].reshape(4, 4, 3)
+    assert np.abs(gt).max() > 0
+    for (y, x, c) in [(0, 0, 0), (1, 2, 1), (3, 3, 2), (2, 1, 0)]:
+        eps = 2e-2
+        hi = tex.copy(); hi[y, x, c] += eps; lo = tex.copy(); lo[y, x, c] -= eps
+        o.set_param(mi.abi.PARAM_TEXTURE_DATA, 0, hi); fp = _objective(o, p, gin)
+        o.set_param(mi.abi.PARAM_TEXTURE_DATA, 0, lo); fm = _objective(o, p, gin)
+        o.set_param(mi.abi.PARAM_TEXTURE_DATA, 0, tex)
+        fd = (fp - fm) / (2 * eps)
+        assert abs(gt[y, x, c] - fd) < 2e-2 * max(abs(fd), 0.5), ((y, x, c), gt[y, x, c], fd)
+
+
+def test_backward_with_rr_is_unbiased_estimate_of_fd(mi, orc):
+    """test_ad_integrators.py:792-828 protocol at small scale: uniform grad_in, PRB gradient (RR on) vs the finite
+    difference of a high-spp primal, within a generous statistical tolerance."""
+    sc, o = _scene(mi, orc, 8)
+    integ = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 2})
+    gin = np.full((8, 8, 3), 1e-3, dtype=np.float32)
+    lay, _ = o.param_layout()
+    bi = [i for i, b in enumerate(sc.bsdfs) if b.id == "white"][0]
+    off = [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_BSDF_REFLECTANCE and i == bi][0]
+    g = np.mean([o.render_backward(o.params(integ, s, 256), gin)[off:off + 3] for s in range(4)], axis=0)
+    base = sc.bsdfs[bi].reflectance.copy()
+    fd = np.zeros(3)
+    eps = 0.03
+    for c in range(3):
+        hi = base.copy(); hi[c] += eps; lo = base.copy(); lo[c] -= eps
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, hi); fp = np.mean([_objective(o, o.params(integ, 100 + s, 512), gin) for s in range(2)])
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, lo); fm = np.mean([_objective(o, o.params(integ, 100 + s, 512), gin) for s in range(2)])
+        o.set_param(mi.abi.PARAM_BSDF_REFLECTANCE, bi, base)
+        fd[c] = (fp - fm) / (2 * eps)
+    assert np.all(np.abs(g - fd) < 0.15 * np.abs(fd)), (g, fd)
+
+
+def test_texture_lookup(mi, orc):
+    """dr::Texture2f convention [Dr.Jit, recalled; parity unpinned in-tree]: texel centres at (i+0.5)/res, repeat wrap."""
+    d = small_cbox(mi, 8)
+    tex = np.arange(2 * 4 * 3, dtype=np.float32).reshape(2, 4, 3)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex / 100, "raw": True}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    centres = np.array([[(x + 0.5) / 4, (y + 0.5) / 2] for y in range(2) for x in range(4)], dtype=np.float32)
+    assert np.allclose(o.texture_eval(0, centres), (tex / 100).reshape(-1, 3), atol=1e-6)
+    mid = o.texture_eval(0, np.array([[0.25, 0.25]], dtype=np.float32))[0]      # halfway between texels (0,0) and (1,0)
+    assert np.allclose(mid, (tex[0, 0] + tex[0, 1]) / 200, atol=1e-6)
+    wrap = o.texture_eval(0, np.array([[0.0, 0.25]], dtype=np.float32))[0]      # repeat: between texel 3 and texel 0
+    assert np.allclose(wrap, (tex[0, 3] + tex[0, 0]) / 200, atol=1e-6)
