@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355.so")
+LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
 ABI_VERSION = 1
 

@@ -29,11 +29,11 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in SRC + HDR + [os.path.abspath(__file__)])
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB] + SRC
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", out or LIB] + SRC
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -45,6 +45,7 @@ def build(force=False, verbose=False, extra_flags=()):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
-    print(LIB)
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    build(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None,
+          extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force" and not a.startswith("--out=")])
+    print(outs[0] if outs else LIB)

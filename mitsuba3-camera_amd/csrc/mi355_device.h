@@ -44,6 +44,22 @@ struct DShape {                      // 176 B, read through the scalar cache
     uint32_t pad[2];
 };
 struct DTri { float p0[3], e1[3], e2[3]; };               // mesh.h:438: e1 = p1-p0, e2 = p2-p0 precomputed (same arithmetic)
+// Flat, wave-uniform primitive: a parallelogram frame P0 + s*Es + t*Et, stored as the affine map world -> (s, t, h)
+// (h = signed distance along Es x Et in that basis).  One 64-byte record = one s_load_dwordx16.
+//   rectangle shape : m = the shape's to_object, bounds s,t in [-1,1]               (rectangle.cpp:446-468, same formula)
+//   two coplanar triangles that form a parallelogram (cube faces, OBJ quads): bounds s,t in [0,1]
+//   single triangle : Es = e1, Et = e2, (s,t) are its barycentrics, bounds s,t >= 0, s+t <= 1
+struct DPrim {
+    float m[12];
+    float lo;        // lower bound of s and t (-1 or 0)
+    float smax;      // upper bound of s+t (1 = single triangle, 2 = never binding)
+    uint32_t shape;
+    uint32_t fin;    // index into DScene::fins (mesh) or 0xffffffff (rectangle)
+};
+struct DPrimFin {    // (b1, b2) = A (s, t) + c for each of the two triangles of a mesh primitive
+    uint32_t tri_a, tri_b;      // ORIGINAL face ids (the reference's prim_index)
+    float a[6], b[6];
+};
 struct DBvhNode {                                          // binary BVH over one mesh's triangles
     float lo[3]; uint32_t left;                            // inner: children = left, left+1; leaf: first triangle
     float hi[3]; uint32_t count;                           // 0 = inner node, else number of triangles
@@ -62,6 +78,10 @@ struct DScene {
     const float    *normals;      // 3 per vertex (zeros when the mesh has none)
     const float    *texcoords;    // 2 per vertex
     const DBvhNode *bvh;
+    const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
+    const DPrimFin *fins;
+    const uint32_t *bvh_shapes;   // shapes traversed through their BVH
+    uint32_t n_prims, n_bvh_shapes;
     const DBsdf    *bsdfs;
     const DEmitter *emitters;
     const DTexture *textures;
@@ -92,10 +112,23 @@ MI_DEV float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))
 MI_DEV v3 cross3(v3 a, v3 b) {
     return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
+// dr::rcp / dr::rsqrt / dr::sqrt are approximate-plus-Newton in the reference's LLVM back-end too; here they map to
+// the hardware transcendentals (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32, 1 ulp) instead of the ~10-instruction IEEE expansions.
+#ifndef MI_EXACT_MATH
+MI_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+MI_DEV float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+MI_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+MI_DEV float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+MI_DEV void sincos_(float x, float &sn, float &cs) { sn = __sinf(x); cs = __cosf(x); }
+#else
 MI_DEV float rcp_(float x) { return 1.0f / x; }
 MI_DEV float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+MI_DEV float sqrt_(float x) { return sqrtf(x); }
+MI_DEV float div_(float a, float b) { return a / b; }
+MI_DEV void sincos_(float x, float &sn, float &cs) { sincosf(x, &sn, &cs); }
+#endif
 MI_DEV float sqnorm3(v3 a) { return dot3(a, a); }
-MI_DEV float norm3(v3 a) { return sqrtf(dot3(a, a)); }
+MI_DEV float norm3(v3 a) { return sqrt_(dot3(a, a)); }
 MI_DEV v3 normalize3(v3 a) { return a * rsqrt_(sqnorm3(a)); }
 MI_DEV float max3(v3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 MI_DEV float mulsign(float a, float b) {
@@ -159,13 +192,13 @@ MI_DEV v3 square_to_cosine_hemisphere(float sx, float sy) {
     float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
     bool is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
     float r = q13 ? y : x, rp = q13 ? x : y;
-    float phi = 0.25f * MI_PI * rp / r;
+    float phi = div_(0.25f * MI_PI * rp, r);
     if (q13) phi = 0.5f * MI_PI - phi;
     if (is_zero) phi = 0.f;
-    float sn, cs; sincosf(phi, &sn, &cs);
+    float sn, cs; sincos_(phi, sn, cs);
     float px = r * cs, py = r * sn;
     float sq = fmaf(py, py, px * px);
-    return V3(px, py, sqrtf(fmaxf(1.f - sq, 0.f)));
+    return V3(px, py, sqrt_(fmaxf(1.f - sq, 0.f)));
 }
 // Dr.Jit estrin_impl for 10 coefficients; src/rfilters/gaussian.cpp:88-98
 MI_DEV float estrin10(float x, const float *c) {
@@ -181,7 +214,7 @@ MI_DEV float filter_eval(const DScene &sc, float x) {
     return fmaxf(0.f, 1.f - fabsf(x * (1.f / sc.filter_radius)));       // tent
 }
 MI_DEV float mis_weight(float a, float b) {                              // path.cpp:300-305
-    a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f;
+    a *= a; b *= b; float w = div_(a, a + b); return isfinite(w) ? w : 0.f;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -194,13 +227,6 @@ struct SI {                                                             // Surfa
 };
 MI_DEV v3 ray_at(const Ray &r, float t) { return fma3s(r.d, t, r.o); }
 
-// Rectangle::ray_intersect_preliminary_impl, rectangle.cpp:446-468
-MI_DEV bool rect_intersect(const DShape &sh, const Ray &ray, float &t, float &u, float &v) {
-    v3 o = xf_point(sh.to_object, ray.o), d = xf_vector(sh.to_object, ray.d);
-    t = -o.z / d.z;
-    u = fmaf(d.x, t, o.x); v = fmaf(d.y, t, o.y);
-    return t >= 0.f && t <= ray.maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
-}
 // Mesh::moeller_trumbore, mesh.h:430-453
 MI_DEV bool tri_intersect(const DTri &tr, const Ray &ray, float &t, float &u, float &v) {
     v3 p0 = ld3(tr.p0), e1 = ld3(tr.e1), e2 = ld3(tr.e2);
@@ -224,24 +250,20 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
 }
 
 #define MI_BVH_STACK 24
-// Per-lane BVH traversal of one mesh.  The short stack lives in LDS, laid out [level][lane] so that
+#ifndef MI_PRIM_UNROLL
+#define MI_PRIM_UNROLL 1
+#endif
+#define MI_STR2(x) #x
+#define MI_STR(x) MI_STR2(x)
+#define MI_UNROLL_PRIMS _Pragma(MI_STR(unroll MI_PRIM_UNROLL))
+#define MI_FLAT_MAX 64      // meshes up to this many triangles are expanded into the flat primitive list
+// Per-lane BVH traversal of one (large) mesh.  The short stack lives in LDS, laid out [level][lane] so that
 // the 64 lanes of a wave touch 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32);
 // `stk` already points at this lane's column.  Node boxes are re-tested on pop against the
 // current ray.maxt, so a closer hit prunes everything behind it.
 #define MI_STK(i) stk[(i) * 64]
 MI_DEV void mesh_closest(const DScene &sc, const DShape &sh, uint32_t shape_index, Ray &ray, v3 inv_d, Hit &hit,
                          bool active, uint32_t *stk) {
-    if (sh.bvh_root < 0) {
-        bool in_box = active && box_overlap(sh.bbox_min, sh.bbox_max, ray, inv_d);
-        if (!__any(in_box)) return;
-        for (uint32_t f = 0; f < sh.tri_count; ++f) {
-            float t, u, v;
-            if (in_box && tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v) && t < hit.t) {
-                hit.t = t; hit.u = u; hit.v = v; hit.prim = f; hit.shape = shape_index; ray.maxt = t;
-            }
-        }
-        return;
-    }
     int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
     while (have) {
         DBvhNode nd = sc.bvh[node];
@@ -251,7 +273,7 @@ MI_DEV void mesh_closest(const DScene &sc, const DShape &sh, uint32_t shape_inde
                 for (uint32_t k = 0; k < nd.count; ++k) {
                     uint32_t f = nd.left + k; float t, u, v;
                     if (tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v) && t < hit.t) {
-                        hit.t = t; hit.u = u; hit.v = v; hit.prim = f; hit.shape = shape_index; ray.maxt = t;
+                        hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[sh.tri_offset + f]; hit.shape = shape_index; ray.maxt = t;
                     }
                 }
             } else if (sp < MI_BVH_STACK) { MI_STK(sp) = nd.left + 1; sp++; node = nd.left; descend = true; }
@@ -261,15 +283,6 @@ MI_DEV void mesh_closest(const DScene &sc, const DShape &sh, uint32_t shape_inde
 }
 MI_DEV bool mesh_any(const DScene &sc, const DShape &sh, const Ray &ray, v3 inv_d, bool active, uint32_t *stk) {
     bool occluded = false;
-    if (sh.bvh_root < 0) {
-        bool in_box = active && box_overlap(sh.bbox_min, sh.bbox_max, ray, inv_d);
-        if (!__any(in_box)) return false;
-        for (uint32_t f = 0; f < sh.tri_count; ++f) {
-            float t, u, v;
-            if (in_box && !occluded && tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v)) occluded = true;
-        }
-        return occluded;
-    }
     int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
     while (have) {
         DBvhNode nd = sc.bvh[node];
@@ -288,34 +301,76 @@ MI_DEV bool mesh_any(const DScene &sc, const DShape &sh, const Ray &ray, v3 inv_
     return occluded;
 }
 
+// One flat primitive against one ray: 18 fma for the affine map, one v_rcp, two fma, then a branch-free
+// bounds test.  `tlim` is an EXCLUSIVE upper bound on t (next float above ray.maxt, or the closest hit so far).
+MI_DEV bool prim_test(const DPrim &pr, const Ray &ray, float tlim, float &t, float &s, float &u) {
+    const float *m = pr.m;
+    float os = fmaf(m[2], ray.o.z, fmaf(m[1], ray.o.y, fmaf(m[0], ray.o.x, m[3])));
+    float ot = fmaf(m[6], ray.o.z, fmaf(m[5], ray.o.y, fmaf(m[4], ray.o.x, m[7])));
+    float oh = fmaf(m[10], ray.o.z, fmaf(m[9], ray.o.y, fmaf(m[8], ray.o.x, m[11])));
+    float ds = fmaf(m[2], ray.d.z, fmaf(m[1], ray.d.y, m[0] * ray.d.x));
+    float dt = fmaf(m[6], ray.d.z, fmaf(m[5], ray.d.y, m[4] * ray.d.x));
+    float dh = fmaf(m[10], ray.d.z, fmaf(m[9], ray.d.y, m[8] * ray.d.x));
+    t = -oh * rcp_(dh);
+    s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
+    return (t >= 0.f) & (t < tlim) & (fminf(s, u) >= pr.lo) & (fmaxf(s, u) <= 1.f) & (s + u <= pr.smax);
+}
+MI_DEV float excl_limit(float maxt) { return maxt >= MI_LARGEST ? MI_INF : __uint_as_float(__float_as_uint(maxt) + 1u); }
+
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
 MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
     Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
-    v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
-    for (uint32_t i = 0; i < sc.n_shapes; ++i) {
-        const DShape &sh = sc.shapes[i];
-        if (sh.type == MI355_SHAPE_RECTANGLE) {
-            float t, u, v;
-            if (active && rect_intersect(sh, ray, t, u, v) && t < hit.t) {
-                hit.t = t; hit.u = u; hit.v = v; hit.prim = 0; hit.shape = i; ray.maxt = t;
-            }
-        } else mesh_closest(sc, sh, i, ray, inv_d, hit, active, stk);
+    float tlim = active ? excl_limit(ray.maxt) : 0.f;
+    uint32_t best = 0xffffffffu;
+    const uint32_t n = sc.n_prims;
+    if (n) {
+        MI_UNROLL_PRIMS
+        for (uint32_t k = 0; k < n; ++k) {                             // unrolled: the scalar loads of several records issue together
+            float t, s, u;
+            bool h = prim_test(sc.prims[k], ray, tlim, t, s, u);
+            tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
+        }
     }
-    if (hit.shape != 0xffffffffu && sc.shapes[hit.shape].type == MI355_SHAPE_MESH)
-        hit.prim = sc.tri_face[sc.shapes[hit.shape].tri_offset + hit.prim];
+    if (best != 0xffffffffu) {                                          // per-lane finalize (divergent gather, once per ray)
+        const DPrim &pr = sc.prims[best];
+        hit.t = tlim; hit.shape = pr.shape; ray.maxt = tlim;
+        if (pr.fin != 0xffffffffu) {
+            const DPrimFin &f = sc.fins[pr.fin];
+            float s = hit.u, u = hit.v;
+            float b1 = fmaf(f.a[0], s, fmaf(f.a[1], u, f.a[2])), b2 = fmaf(f.a[3], s, fmaf(f.a[4], u, f.a[5]));
+            hit.prim = f.tri_a;
+            if (f.tri_b != f.tri_a && fminf(fminf(b1, b2), 1.f - b1 - b2) < 0.f) {
+                b1 = fmaxf(fmaf(f.b[0], s, fmaf(f.b[1], u, f.b[2])), 0.f); b2 = fmaxf(fmaf(f.b[3], s, fmaf(f.b[4], u, f.b[5])), 0.f);
+                hit.prim = f.tri_b;
+            }
+            hit.u = b1; hit.v = b2;
+        }
+    }
+    if (sc.n_bvh_shapes) {
+        v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+        for (uint32_t i = 0; i < sc.n_bvh_shapes; ++i) {
+            uint32_t si = sc.bvh_shapes[i];
+            mesh_closest(sc, sc.shapes[si], si, ray, inv_d, hit, active, stk);
+        }
+    }
     return hit;
 }
 // Scene::ray_test (scene.cpp:201-210): any hit.
 MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32_t *stk) {
     bool occluded = false;
-    v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
-    for (uint32_t i = 0; i < sc.n_shapes; ++i) {
-        if (!__any(active && !occluded)) break;
-        const DShape &sh = sc.shapes[i];
-        if (sh.type == MI355_SHAPE_RECTANGLE) {
-            float t, u, v;
-            if (active && !occluded && rect_intersect(sh, ray, t, u, v)) occluded = true;
-        } else occluded = mesh_any(sc, sh, ray, inv_d, active && !occluded, stk) || occluded;
+    float tlim = active ? excl_limit(ray.maxt) : 0.f;
+    const uint32_t n = sc.n_prims;
+    if (n) {
+        MI_UNROLL_PRIMS
+        for (uint32_t k = 0; k < n; ++k) {
+            float t, s, u;
+            if (prim_test(sc.prims[k], ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
+        }
+    }
+    if (sc.n_bvh_shapes) {
+        v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+        for (uint32_t i = 0; i < sc.n_bvh_shapes; ++i)
+            occluded = mesh_any(sc, sc.shapes[sc.bvh_shapes[i]], ray, inv_d, active && !occluded, stk) || occluded;
     }
     return occluded;
 }
@@ -454,10 +509,10 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
     ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
     ds.d = ds.p - si.p;
-    float dist2 = sqnorm3(ds.d); ds.dist = sqrtf(dist2);
+    float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2);
     ds.d = ds.d * rcp_(ds.dist);
     float dp = fabsf(dot3(ds.d, ds.n));
-    float x = dist2 / dp;
+    float x = div_(dist2, dp);
     ds.pdf *= isfinite(x) ? x : 0.f;
     active = active && dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;            // area.cpp:136
     spec = active ? ld3(em.radiance) * rcp_(ds.pdf) : V3(0.f, 0.f, 0.f);
@@ -472,7 +527,7 @@ MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 d, v3 n
     float dp = dot3(d, n);
     if (!(dp < 0.f)) return 0.f;
     float adp = fabsf(dp);
-    float pdf = sh.inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    float pdf = sh.inv_area * (adp != 0.f ? div_(dist * dist, adp) : 0.f);
     return pdf * sc.inv_emitter_count;
 }
 

@@ -21,6 +21,12 @@
 
 #define BLOCK 256
 #define WAVES (BLOCK / 64)
+#ifndef MI_MIN_WAVES
+#define MI_MIN_WAVES 5                      // k_render: waves per SIMD the register allocator must leave room for (LDS allows 5 blocks/CU)
+#endif
+#ifndef MI_MIN_WAVES_BWD
+#define MI_MIN_WAVES_BWD 4                  // k_prb_backward spills at 5 (measured slower)
+#endif
 #define ROW_STRIDE 68                       // 64 lanes + 4 pad floats: 16-B aligned rows, shifts banks by 4 per row
 #define SPLAT_ROWS 29                       // 25 tap weights + 4 channel values
 #define WAVE_FLOATS (SPLAT_ROWS * ROW_STRIDE)
@@ -97,13 +103,16 @@ MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, 
         }
     }
     if (li.act && !(lds_path && nominal)) {                                // imageblock.cpp:478-493
-        for (int ty = 0; ty < sp.count; ++ty) for (int tx = 0; tx < sp.count; ++tx) {
-            int32_t x = sp.x0 + tx, y = sp.y0 + ty;
-            if (x < 0 || y < 0 || x >= W || y >= H) continue;
-            float w = sp.wy[ty] * sp.wx[tx];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) atomicAdd(film + ((size_t) y * W + x) * CH + c, values[c] * w);
-        }
+        for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {                      // static indices: keeps Splat in registers
+                int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+                if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+                float w = sp.wy[ty] * sp.wx[tx];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) atomicAdd(film + ((size_t) y * W + x) * CH + c, values[c] * w);
+            }
     }
 }
 
@@ -115,7 +124,7 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
 }
 
 template <int INTEGRATOR, int OUT>
-__global__ __launch_bounds__(BLOCK) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
+__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
     __shared__ uint32_t s_cnt[4];
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(BLOCK) void k_splat_weights(DScene sc, RenderArgs a
 }
 
 // RBIntegrator.render_backward steps 1b-3: common.py:741-796
-__global__ __launch_bounds__(BLOCK) void k_prb_backward(DScene sc, RenderArgs a, const float *grad_in, const float *weight,
+__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float *grad_in, const float *weight,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
@@ -187,12 +196,17 @@ __global__ __launch_bounds__(BLOCK) void k_prb_backward(DScene sc, RenderArgs a,
     Splat sp = splat_weights(sc, pos_x, pos_y);
     v3 dL = V3(0.f, 0.f, 0.f);
     const int W = (int) sc.crop_w, H = (int) sc.crop_h;
-    if (li.act) for (int ty = 0; ty < sp.count; ++ty) for (int tx = 0; tx < sp.count; ++tx) {
-        int32_t x = sp.x0 + tx, y = sp.y0 + ty;
-        if (x < 0 || y < 0 || x >= W || y >= H) continue;
-        size_t p = (size_t) y * W + x; float wv = weight[p]; float dv = wv == 0.f ? 1.f : wv;
-        float w = sp.wy[ty] * sp.wx[tx] / dv;
-        dL.x += grad_in[3 * p] * w; dL.y += grad_in[3 * p + 1] * w; dL.z += grad_in[3 * p + 2] * w;
+    if (li.act) {
+#pragma unroll
+        for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+                int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+                if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+                size_t p = (size_t) y * W + x; float wv = weight[p]; float dv = wv == 0.f ? 1.f : wv;
+                float w = sp.wy[ty] * sp.wx[tx] / dv;
+                dL.x += grad_in[3 * p] * w; dL.y += grad_in[3 * p + 1] * w; dL.z += grad_in[3 * p + 2] * w;
+            }
     }
     Counters3 cnt = { 0, 0, 0 };
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
@@ -318,12 +332,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
-    DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow
@@ -361,6 +377,101 @@ static void bvh_build(std::vector<DBvhNode> &nodes, std::vector<BuildTri> &bt, u
     nodes[node].left = left; nodes[node].count = 0;
     bvh_build(nodes, bt, left, begin, mid);
     bvh_build(nodes, bt, left + 1, mid, end);
+}
+
+// ---- flat primitive list ------------------------------------------------------------------------------
+// world -> (s, t, h) for the frame P0 + s*Es + t*Et (h along Es x Et), computed in double, stored in float
+static bool frame_matrix(const double P0[3], const double Es[3], const double Et[3], float m[12]) {
+    double N[3] = { Es[1] * Et[2] - Es[2] * Et[1], Es[2] * Et[0] - Es[0] * Et[2], Es[0] * Et[1] - Es[1] * Et[0] };
+    double B[3][3] = { { Es[0], Et[0], N[0] }, { Es[1], Et[1], N[1] }, { Es[2], Et[2], N[2] } };
+    double det = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                 B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+    if (!(fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    double inv[3][3];
+    inv[0][0] = (B[1][1] * B[2][2] - B[1][2] * B[2][1]) / det; inv[0][1] = (B[0][2] * B[2][1] - B[0][1] * B[2][2]) / det; inv[0][2] = (B[0][1] * B[1][2] - B[0][2] * B[1][1]) / det;
+    inv[1][0] = (B[1][2] * B[2][0] - B[1][0] * B[2][2]) / det; inv[1][1] = (B[0][0] * B[2][2] - B[0][2] * B[2][0]) / det; inv[1][2] = (B[0][2] * B[1][0] - B[0][0] * B[1][2]) / det;
+    inv[2][0] = (B[1][0] * B[2][1] - B[1][1] * B[2][0]) / det; inv[2][1] = (B[0][1] * B[2][0] - B[0][0] * B[2][1]) / det; inv[2][2] = (B[0][0] * B[1][1] - B[0][1] * B[1][0]) / det;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[r * 4 + c] = (float) inv[r][c];
+        m[r * 4 + 3] = (float) -(inv[r][0] * P0[0] + inv[r][1] * P0[1] + inv[r][2] * P0[2]);
+    }
+    return true;
+}
+// affine map (s,t) -> (b1,b2) of a triangle whose vertices have frame coordinates (sv[i], tv[i])
+static bool bary_map(const double sv[3], const double tv[3], float out[6]) {
+    double S[3][3] = { { sv[0], tv[0], 1 }, { sv[1], tv[1], 1 }, { sv[2], tv[2], 1 } };
+    double det = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) - S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+                 S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+    if (!(fabs(det) > 1e-300)) return false;
+    for (int which = 0; which < 2; ++which) {           // b1: rhs (0,1,0); b2: rhs (0,0,1)
+        double rhs[3] = { 0, which == 0 ? 1.0 : 0.0, which == 1 ? 1.0 : 0.0 };
+        for (int c = 0; c < 3; ++c) {                   // Cramer
+            double M[3][3]; memcpy(M, S, sizeof(M));
+            for (int r = 0; r < 3; ++r) M[r][c] = rhs[r];
+            double dc = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                        M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+            out[which * 3 + c] = (float) (dc / det);
+        }
+    }
+    return true;
+}
+static void frame_coords(const float m[12], const float *p, double &s, double &t) {
+    s = (double) m[0] * p[0] + (double) m[1] * p[1] + (double) m[2] * p[2] + m[3];
+    t = (double) m[4] * p[0] + (double) m[5] * p[1] + (double) m[6] * p[2] + m[7];
+}
+// Expand a small mesh into flat primitives: coplanar triangle pairs that form a parallelogram become ONE primitive.
+static void flatten_mesh(mi355_scene *s, uint32_t shape_index, const mi355_shape_desc &sd) {
+    const uint32_t F = sd.face_count; const float *P = sd.vertex_positions;
+    std::vector<char> used(F, 0);
+    auto V = [&](uint32_t f, int k) { return P + 3 * (size_t) sd.faces[3 * (size_t) f + k]; };
+    auto same = [&](const float *a, const float *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
+    for (uint32_t f = 0; f < F; ++f) {
+        if (used[f]) continue;
+        used[f] = 1;
+        int partner = -1; int ua = 0, ub = 0;           // indices (within each triangle) of the UNSHARED vertex
+        for (uint32_t g = f + 1; g < F && partner < 0; ++g) {
+            if (used[g]) continue;
+            int shared_f[3] = { 0, 0, 0 }, shared_g[3] = { 0, 0, 0 }, ns = 0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (same(V(f, i), V(g, j))) { shared_f[i] = 1; shared_g[j] = 1; ns++; }
+            if (ns != 2) continue;
+            int a = !shared_f[0] ? 0 : (!shared_f[1] ? 1 : 2), b = !shared_g[0] ? 0 : (!shared_g[1] ? 1 : 2);
+            const float *pa = V(f, a), *pb = V(g, b), *pu = V(f, (a + 1) % 3), *pv = V(f, (a + 2) % 3);
+            double scale = 0, err = 0;
+            for (int k = 0; k < 3; ++k) { double e = (double) pa[k] + pb[k] - pu[k] - pv[k]; err += e * e; scale += (double) (pa[k] - pu[k]) * (pa[k] - pu[k]) + (double) (pb[k] - pu[k]) * (pb[k] - pu[k]); }
+            if (err > 1e-10 * scale) continue;          // not a parallelogram (this also implies coplanarity)
+            // same orientation? normals of f and g must agree
+            auto nrm = [&](uint32_t q, double n[3]) { const float *x = V(q, 0), *y = V(q, 1), *z = V(q, 2);
+                double e1[3] = { (double) y[0] - x[0], (double) y[1] - x[1], (double) y[2] - x[2] }, e2[3] = { (double) z[0] - x[0], (double) z[1] - x[1], (double) z[2] - x[2] };
+                n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0]; };
+            double nf[3], ng[3]; nrm(f, nf); nrm(g, ng);
+            if (nf[0] * ng[0] + nf[1] * ng[1] + nf[2] * ng[2] <= 0) continue;
+            partner = (int) g; ua = a; ub = b;
+        }
+        DPrim pr; memset(&pr, 0, sizeof(pr)); pr.shape = shape_index; pr.fin = (uint32_t) s->fins.size();
+        DPrimFin fin; memset(&fin, 0, sizeof(fin));
+        bool ok = false;
+        if (partner >= 0) {
+            const float *pa = V(f, ua), *pb = V((uint32_t) partner, ub), *pu = V(f, (ua + 1) % 3);
+            double P0[3] = { pu[0], pu[1], pu[2] }, Es[3] = { (double) pa[0] - pu[0], (double) pa[1] - pu[1], (double) pa[2] - pu[2] },
+                   Et[3] = { (double) pb[0] - pu[0], (double) pb[1] - pu[1], (double) pb[2] - pu[2] };
+            if (frame_matrix(P0, Es, Et, pr.m)) {
+                double sv[3], tv[3], sw[3], tw[3];
+                for (int k = 0; k < 3; ++k) { frame_coords(pr.m, V(f, k), sv[k], tv[k]); frame_coords(pr.m, V((uint32_t) partner, k), sw[k], tw[k]); }
+                if (bary_map(sv, tv, fin.a) && bary_map(sw, tw, fin.b)) {
+                    pr.lo = 0.f; pr.smax = 2.f; fin.tri_a = f; fin.tri_b = (uint32_t) partner; used[partner] = 1; ok = true;
+                }
+            }
+        }
+        if (!ok) {                                       // single triangle: (s,t) = barycentrics
+            const float *p0 = V(f, 0), *p1 = V(f, 1), *p2 = V(f, 2);
+            double P0[3] = { p0[0], p0[1], p0[2] }, Es[3] = { (double) p1[0] - p0[0], (double) p1[1] - p0[1], (double) p1[2] - p0[2] },
+                   Et[3] = { (double) p2[0] - p0[0], (double) p2[1] - p0[1], (double) p2[2] - p0[2] };
+            if (!frame_matrix(P0, Es, Et, pr.m)) continue;   // degenerate triangle: can never be hit (mesh.h:439 would give inf)
+            pr.lo = 0.f; pr.smax = 1.f; fin.tri_a = fin.tri_b = f;
+            fin.a[0] = 1; fin.a[4] = 1; fin.b[0] = 1; fin.b[4] = 1;
+        }
+        s->prims.push_back(pr); s->fins.push_back(fin);
+    }
 }
 
 static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
@@ -406,6 +517,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             o.frame_s[0] = fs.x; o.frame_s[1] = fs.y; o.frame_s[2] = fs.z; o.frame_t[0] = ft.x; o.frame_t[1] = ft.y; o.frame_t[2] = ft.z;
             o.frame_n[0] = n.x; o.frame_n[1] = n.y; o.frame_n[2] = n.z;
             h3 cr = hcross(fs, ft); o.inv_area = 1.0f / sqrtf(hdot(cr, cr));
+            DPrim pr; memset(&pr, 0, sizeof(pr)); memcpy(pr.m, o.to_object, 48);   // rectangle.cpp:457-465: local = to_object * ray
+            pr.lo = -1.f; pr.smax = 2.f; pr.shape = i; pr.fin = 0xffffffffu;
+            s->prims.push_back(pr);
         } else if (sd.type == MI355_SHAPE_MESH) {
             if (!sd.vertex_positions || !sd.faces || !sd.face_count || !sd.vertex_count) return fail(MI355_ERR_INVALID, "mesh without vertices/faces");
             o.tri_offset = (uint32_t) s->tris.size(); o.tri_count = sd.face_count; o.vtx_offset = (uint32_t) (s->positions.size() / 3);
@@ -434,7 +548,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
                 s->faces.push_back(fi[0]); s->faces.push_back(fi[1]); s->faces.push_back(fi[2]);
             }
             o.inv_area = (float) (1.0 / area);
-            if (sd.face_count > 16) {
+            if (sd.face_count <= MI_FLAT_MAX) flatten_mesh(s, i, sd);
+            else {
+                s->bvh_shapes.push_back(i);
                 uint32_t root = (uint32_t) s->bvh.size(); s->bvh.push_back(DBvhNode());
                 std::vector<DBvhNode> &nodes = s->bvh;
                 bvh_build(nodes, bt, root, 0, sd.face_count);
@@ -499,6 +615,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_normals, s->normals))) return rc;
     if ((rc = upload(&s->d_texcoords, s->texcoords))) return rc;
     if ((rc = upload(&s->d_bvh, s->bvh))) return rc;
+    if ((rc = upload(&s->d_prims, s->prims))) return rc;
+    if ((rc = upload(&s->d_fins, s->fins))) return rc;
+    if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
     if ((rc = upload(&s->d_textures, s->textures))) return rc;
@@ -507,7 +626,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
-    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
+    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes;
+    ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
     return MI355_OK;
 }
@@ -529,7 +649,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
