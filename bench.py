@@ -125,8 +125,14 @@ def main():
     kernel_ms = cnt["kernel_ms"] / launches
     alg = algorithmic_bytes(cnt, npix * args.steps * (len(my_tiles) / n_tiles if world > 1 else 1.0)) / launches
     achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None                      # measured HBM bytes per launch of this kernel: a separate --pmc run (tools/pmc.sh), committed
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f)["k_render<path,film>"]["bytes_per_launch"] if (world == 1 and args.res == 512 and args.spp == 256) else None
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_render<path,film>", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg),
                 "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}

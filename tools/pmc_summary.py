@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Summarise tools/pmc.sh output into one text file (per-kernel mean of every counter + derived figures)."""
+import collections, csv, glob, os, sys
+
+def main(d, out):
+    lines = []
+    stats = glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv"))
+    if stats:
+        lines.append("# rocprofv3 --kernel-trace --stats (top kernels)")
+        for i, r in enumerate(csv.DictReader(open(stats[0]))):
+            if i < 6:
+                lines.append("%-60s calls=%s avg_ms=%.4f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in sorted(glob.glob(os.path.join(d, "pass*", "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][-40:]
+            if not ("k_render" in k or "k_prb" in k or "k_splat" in k or "k_wf" in k):
+                continue
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    for k, c in agg.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        lines.append("")
+        lines.append("# kernel %s  grid=%s wg=%s lds=%s scratch=%s vgpr=%s sgpr=%s" % ((k,) + meta[k]))
+        for n in sorted(m):
+            lines.append("%-28s %.6g" % (n, m[n]))
+        w = m.get("SQ_WAVES")
+        if w:
+            for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU_TRANS_F32"):
+                if n in m:
+                    lines.append("per-wave %-22s %.1f" % (n, m[n] / w))
+        if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+            lines.append("VALU lane utilisation        %.3f" % (m["SQ_THREAD_CYCLES_VALU"] / (64 * m["SQ_ACTIVE_INST_VALU"])))
+        if "FETCH_SIZE" in m:   # KiB units; gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2 upper bound
+            lines.append("HBM read bytes (FETCH_SIZE*1024, x2 corrected) %.4g .. %.4g" % (m["FETCH_SIZE"] * 1024, 2 * m["FETCH_SIZE"] * 1024))
+        if "WRITE_SIZE" in m:
+            lines.append("HBM write bytes (WRITE_SIZE*1024)              %.4g" % (m["WRITE_SIZE"] * 1024))
+        if "GRBM_GUI_ACTIVE" in m:
+            lines.append("GRBM_GUI_ACTIVE/8 (cycles)   %.4g" % (m["GRBM_GUI_ACTIVE"] / 8))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
