@@ -244,6 +244,11 @@ int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 
+/* How the replica's geometry was organised (cf. the accel statistics Scene logs, scene.cpp:108-118):
+   out[0] flat parallelogram records, out[1] oriented-box records, out[2] meshes traversed through a BVH,
+   out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6..7] reserved. */
+int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
+
 /* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):
    d_out = count x 4 (r,g,b,valid).  Used by the lane-exact parity tests
    (check_vectorization, src/python/python/test/util.py:88-175). */

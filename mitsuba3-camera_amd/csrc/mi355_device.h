@@ -56,6 +56,15 @@ struct DPrim {
     uint32_t shape;
     uint32_t fin;    // index into DScene::fins (mesh) or 0xffffffff (rectangle)
 };
+// A mesh whose 12 triangles form a parallelepiped (the `cube` plugin under any affine to_world, OBJ boxes) is ONE record:
+// the affine map world -> box-local with the box = [0,1]^3; a slab test replaces six parallelogram tests.
+// Faces are numbered 2*axis + side (side 0: u_axis = 0, side 1: u_axis = 1); in-face coordinates are the two other
+// local coordinates in increasing axis order, mapped to (prim_index, b1, b2) by fins[fin + face].
+struct DBox {
+    float m[12];
+    uint32_t shape, fin;
+    uint32_t pad[2];
+};
 struct DPrimFin {    // (b1, b2) = A (s, t) + c for each of the two triangles of a mesh primitive
     uint32_t tri_a, tri_b;      // ORIGINAL face ids (the reference's prim_index)
     float a[6], b[6];
@@ -80,8 +89,9 @@ struct DScene {
     const DBvhNode *bvh;
     const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
     const DPrimFin *fins;
+    const DBox     *boxes;        // parallelepiped meshes
     const uint32_t *bvh_shapes;   // shapes traversed through their BVH
-    uint32_t n_prims, n_bvh_shapes;
+    uint32_t n_prims, n_bvh_shapes, n_boxes;
     const DBsdf    *bsdfs;
     const DEmitter *emitters;
     const DTexture *textures;
@@ -317,26 +327,71 @@ MI_DEV bool prim_test(const DPrim &pr, const Ray &ray, float tlim, float &t, flo
 }
 MI_DEV float excl_limit(float maxt) { return maxt >= MI_LARGEST ? MI_INF : __uint_as_float(__float_as_uint(maxt) + 1u); }
 
+// Slab test of one oriented box: entering distance if the origin is outside, exiting distance if it is inside
+// (the reference's triangles are two-sided for the intersection routine, mesh.h:430-453).
+struct BoxLocal { v3 o, d; float tnear, tfar; v3 tn, tf; };
+MI_DEV BoxLocal box_local(const DBox &bx, const Ray &ray) {
+    const float *m = bx.m; BoxLocal b;
+    b.o = V3(fmaf(m[2], ray.o.z, fmaf(m[1], ray.o.y, fmaf(m[0], ray.o.x, m[3]))),
+             fmaf(m[6], ray.o.z, fmaf(m[5], ray.o.y, fmaf(m[4], ray.o.x, m[7]))),
+             fmaf(m[10], ray.o.z, fmaf(m[9], ray.o.y, fmaf(m[8], ray.o.x, m[11]))));
+    b.d = V3(fmaf(m[2], ray.d.z, fmaf(m[1], ray.d.y, m[0] * ray.d.x)),
+             fmaf(m[6], ray.d.z, fmaf(m[5], ray.d.y, m[4] * ray.d.x)),
+             fmaf(m[10], ray.d.z, fmaf(m[9], ray.d.y, m[8] * ray.d.x)));
+    v3 inv = V3(rcp_(b.d.x), rcp_(b.d.y), rcp_(b.d.z));
+    v3 t0 = V3(-b.o.x * inv.x, -b.o.y * inv.y, -b.o.z * inv.z);
+    v3 t1 = V3((1.f - b.o.x) * inv.x, (1.f - b.o.y) * inv.y, (1.f - b.o.z) * inv.z);
+    b.tn = V3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+    b.tf = V3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+    b.tnear = fmaxf(fmaxf(b.tn.x, b.tn.y), b.tn.z);
+    b.tfar = fminf(fminf(b.tf.x, b.tf.y), b.tf.z);
+    return b;
+}
+MI_DEV bool box_test(const DBox &bx, const Ray &ray, float tlim, float &t) {
+    BoxLocal b = box_local(bx, ray);
+    t = b.tnear < 0.f ? b.tfar : b.tnear;
+    return (b.tnear <= b.tfar) & (t >= 0.f) & (t < tlim);
+}
+
+#define MI_BOX_FLAG 0x40000000u
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
 MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
     Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     uint32_t best = 0xffffffffu;
     const uint32_t n = sc.n_prims;
-    if (n) {
-        MI_UNROLL_PRIMS
-        for (uint32_t k = 0; k < n; ++k) {                             // unrolled: the scalar loads of several records issue together
-            float t, s, u;
-            bool h = prim_test(sc.prims[k], ray, tlim, t, s, u);
-            tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
-        }
+    MI_UNROLL_PRIMS
+    for (uint32_t k = 0; k < n; ++k) {
+        float t, s, u;
+        bool h = prim_test(sc.prims[k], ray, tlim, t, s, u);
+        tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
+    }
+    for (uint32_t k = 0; k < sc.n_boxes; ++k) {
+        float t;
+        bool h = box_test(sc.boxes[k], ray, tlim, t);
+        tlim = h ? t : tlim; best = h ? (MI_BOX_FLAG | k) : best;
     }
     if (best != 0xffffffffu) {                                          // per-lane finalize (divergent gather, once per ray)
-        const DPrim &pr = sc.prims[best];
-        hit.t = tlim; hit.shape = pr.shape; ray.maxt = tlim;
-        if (pr.fin != 0xffffffffu) {
-            const DPrimFin &f = sc.fins[pr.fin];
-            float s = hit.u, u = hit.v;
+        hit.t = tlim; ray.maxt = tlim;
+        uint32_t fin = 0xffffffffu; float s = hit.u, u = hit.v;
+        if (best & MI_BOX_FLAG) {
+            const DBox &bx = sc.boxes[best & ~MI_BOX_FLAG];
+            BoxLocal b = box_local(bx, ray);                           // same arithmetic as in the loop -> same face decision
+            bool inside = b.tnear < 0.f;
+            v3 key = inside ? V3(-b.tf.x, -b.tf.y, -b.tf.z) : b.tn;   // entering: arg max tn, exiting: arg min tf
+            uint32_t axis = (key.x >= key.y && key.x >= key.z) ? 0u : (key.y >= key.z ? 1u : 2u);
+            float da = axis == 0 ? b.d.x : (axis == 1 ? b.d.y : b.d.z);
+            uint32_t side = (da > 0.f) == inside ? 1u : 0u;            // entering through the low face iff d > 0
+            v3 pl = fma3s(b.d, tlim, b.o);
+            s = axis == 0 ? pl.y : pl.x; u = axis == 2 ? pl.y : pl.z;
+            s = fminf(fmaxf(s, 0.f), 1.f); u = fminf(fmaxf(u, 0.f), 1.f);
+            hit.shape = bx.shape; fin = bx.fin + 2u * axis + side;
+        } else {
+            const DPrim &pr = sc.prims[best];
+            hit.shape = pr.shape; fin = pr.fin;
+        }
+        if (fin != 0xffffffffu) {
+            const DPrimFin &f = sc.fins[fin];
             float b1 = fmaf(f.a[0], s, fmaf(f.a[1], u, f.a[2])), b2 = fmaf(f.a[3], s, fmaf(f.a[4], u, f.a[5]));
             hit.prim = f.tri_a;
             if (f.tri_b != f.tri_a && fminf(fminf(b1, b2), 1.f - b1 - b2) < 0.f) {
@@ -360,12 +415,14 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
     bool occluded = false;
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     const uint32_t n = sc.n_prims;
-    if (n) {
-        MI_UNROLL_PRIMS
-        for (uint32_t k = 0; k < n; ++k) {
-            float t, s, u;
-            if (prim_test(sc.prims[k], ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
-        }
+    MI_UNROLL_PRIMS
+    for (uint32_t k = 0; k < n; ++k) {
+        float t, s, u;
+        if (prim_test(sc.prims[k], ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
+    }
+    for (uint32_t k = 0; k < sc.n_boxes; ++k) {
+        float t;
+        if (box_test(sc.boxes[k], ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
     if (sc.n_bvh_shapes) {
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <algorithm>
 #include <numeric>
+#include <array>
 
 #define BLOCK 256
 #define WAVES (BLOCK / 64)
@@ -332,14 +333,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow
@@ -474,6 +475,74 @@ static void flatten_mesh(mi355_scene *s, uint32_t shape_index, const mi355_shape
     }
 }
 
+// Recognise a parallelepiped: 8 distinct corners P0 + {0,1}E0 + {0,1}E1 + {0,1}E2, every face covered by exactly two triangles.
+static bool try_make_box(mi355_scene *s, uint32_t shape_index, const mi355_shape_desc &sd) {
+    if (sd.face_count != 12) return false;
+    const float *P = sd.vertex_positions;
+    std::vector<std::array<double, 3>> pts;
+    for (uint32_t v = 0; v < sd.vertex_count; ++v) {
+        std::array<double, 3> q = { P[3 * v], P[3 * v + 1], P[3 * v + 2] };
+        bool dup = false; for (auto &r : pts) if (r == q) { dup = true; break; }
+        if (!dup) pts.push_back(q);
+        if (pts.size() > 8) return false;
+    }
+    if (pts.size() != 8) return false;
+    double scale = 0; std::array<double, 3> v[7];
+    for (int i = 0; i < 7; ++i) for (int k = 0; k < 3; ++k) { v[i][k] = pts[i + 1][k] - pts[0][k]; scale = std::max(scale, fabs(v[i][k])); }
+    auto has = [&](const double q[3]) { for (int i = 0; i < 7; ++i) { double e = 0; for (int k = 0; k < 3; ++k) e = std::max(e, fabs(v[i][k] - q[k])); if (e <= 1e-5 * scale) return true; } return false; };
+    int E[3] = { -1, -1, -1 };
+    for (int a = 0; a < 7 && E[0] < 0; ++a) for (int b = a + 1; b < 7 && E[0] < 0; ++b) for (int c = b + 1; c < 7 && E[0] < 0; ++c) {
+        double ab[3], ac[3], bc[3], abc[3];
+        for (int k = 0; k < 3; ++k) { ab[k] = v[a][k] + v[b][k]; ac[k] = v[a][k] + v[c][k]; bc[k] = v[b][k] + v[c][k]; abc[k] = ab[k] + v[c][k]; }
+        if (has(ab) && has(ac) && has(bc) && has(abc)) { E[0] = a; E[1] = b; E[2] = c; }
+    }
+    if (E[0] < 0) return false;
+    DBox bx; memset(&bx, 0, sizeof(bx));
+    {   // world -> local: rows of [E0 E1 E2]^-1
+        double B[3][3]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[r][c] = v[E[c]][r];
+        double det = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) + B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+        if (!(fabs(det) > 1e-12 * scale * scale * scale)) return false;
+        double inv[3][3];
+        inv[0][0] = (B[1][1] * B[2][2] - B[1][2] * B[2][1]) / det; inv[0][1] = (B[0][2] * B[2][1] - B[0][1] * B[2][2]) / det; inv[0][2] = (B[0][1] * B[1][2] - B[0][2] * B[1][1]) / det;
+        inv[1][0] = (B[1][2] * B[2][0] - B[1][0] * B[2][2]) / det; inv[1][1] = (B[0][0] * B[2][2] - B[0][2] * B[2][0]) / det; inv[1][2] = (B[0][2] * B[1][0] - B[0][0] * B[1][2]) / det;
+        inv[2][0] = (B[1][0] * B[2][1] - B[1][1] * B[2][0]) / det; inv[2][1] = (B[0][1] * B[2][0] - B[0][0] * B[2][1]) / det; inv[2][2] = (B[0][0] * B[1][1] - B[0][1] * B[1][0]) / det;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) bx.m[r * 4 + c] = (float) inv[r][c];
+            bx.m[r * 4 + 3] = (float) -(inv[r][0] * pts[0][0] + inv[r][1] * pts[0][1] + inv[r][2] * pts[0][2]);
+        }
+    }
+    // classify triangles by face; local coordinates of their vertices must be 0/1
+    int face_tris[6][2]; int face_n[6] = { 0, 0, 0, 0, 0, 0 };
+    double loc[12][3][3];
+    for (uint32_t f = 0; f < 12; ++f) {
+        for (int k = 0; k < 3; ++k) {
+            const float *q = P + 3 * (size_t) sd.faces[3 * f + k];
+            for (int r = 0; r < 3; ++r) {
+                double x = (double) bx.m[r * 4] * q[0] + (double) bx.m[r * 4 + 1] * q[1] + (double) bx.m[r * 4 + 2] * q[2] + bx.m[r * 4 + 3];
+                double rx = x < 0.5 ? 0.0 : 1.0; if (fabs(x - rx) > 1e-4) return false;
+                loc[f][k][r] = rx;
+            }
+        }
+        int face = -1;
+        for (int a = 0; a < 3; ++a) if (loc[f][0][a] == loc[f][1][a] && loc[f][1][a] == loc[f][2][a]) face = 2 * a + (int) loc[f][0][a];
+        if (face < 0 || face_n[face] >= 2) return false;
+        face_tris[face][face_n[face]++] = (int) f;
+    }
+    for (int k = 0; k < 6; ++k) if (face_n[k] != 2) return false;
+    bx.shape = shape_index; bx.fin = (uint32_t) s->fins.size();
+    for (int face = 0; face < 6; ++face) {
+        int a = face / 2, b = a == 0 ? 1 : 0, c = a == 2 ? 1 : 2;
+        DPrimFin fin; memset(&fin, 0, sizeof(fin));
+        fin.tri_a = (uint32_t) face_tris[face][0]; fin.tri_b = (uint32_t) face_tris[face][1];
+        double sv[3], tv[3], sw[3], tw[3];
+        for (int k = 0; k < 3; ++k) { sv[k] = loc[fin.tri_a][k][b]; tv[k] = loc[fin.tri_a][k][c]; sw[k] = loc[fin.tri_b][k][b]; tw[k] = loc[fin.tri_b][k][c]; }
+        if (!bary_map(sv, tv, fin.a) || !bary_map(sw, tw, fin.b)) return false;
+        s->fins.push_back(fin);
+    }
+    s->boxes.push_back(bx);
+    return true;
+}
+
 static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     const mi355_sensor_desc &se = d->sensor;
     if (se.type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build");
@@ -548,7 +617,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
                 s->faces.push_back(fi[0]); s->faces.push_back(fi[1]); s->faces.push_back(fi[2]);
             }
             o.inv_area = (float) (1.0 / area);
-            if (sd.face_count <= MI_FLAT_MAX) flatten_mesh(s, i, sd);
+            size_t fins_before = s->fins.size();
+            if (try_make_box(s, i, sd)) { }
+            else if (sd.face_count <= MI_FLAT_MAX) { s->fins.resize(fins_before); flatten_mesh(s, i, sd); }
             else {
                 s->bvh_shapes.push_back(i);
                 uint32_t root = (uint32_t) s->bvh.size(); s->bvh.push_back(DBvhNode());
@@ -617,6 +688,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_bvh, s->bvh))) return rc;
     if ((rc = upload(&s->d_prims, s->prims))) return rc;
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
+    if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
@@ -626,7 +698,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
-    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes;
+    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes; ds.boxes = s->d_boxes; ds.n_boxes = (uint32_t) s->boxes.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
     return MI355_OK;
@@ -649,7 +721,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -807,6 +879,12 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
     out->n_gen = s->n_gen; out->n_isect = h[1]; out->n_shade = h[2]; out->n_shadow = h[3]; out->n_splat = s->n_splat;
     out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum;
     if (reset) { HIP_TRY(hipMemset(s->d_counters, 0, sizeof(h))); s->n_gen = s->n_splat = 0; s->ms_accum = 0.f; s->launches_accum = 0; }
+    return MI355_OK;
+}
+extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
+    if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
+    out[0] = (uint32_t) s->prims.size(); out[1] = (uint32_t) s->boxes.size(); out[2] = (uint32_t) s->bvh_shapes.size();
+    out[3] = (uint32_t) s->bvh.size(); out[4] = (uint32_t) s->tris.size(); out[5] = (uint32_t) s->grad_total; out[6] = out[7] = 0;
     return MI355_OK;
 }
 extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_params *p, uint32_t lane_begin, uint32_t count, float *d_out, void *stream) {

@@ -313,6 +313,12 @@ class Scene:
         self._handle, self._device = h, device
         return h
 
+    def info(self):
+        """Geometry organisation of the device replica (mi355_scene_info)."""
+        out = (C.c_uint32 * 8)()
+        abi.check(abi.lib().mi355_scene_info(self.handle(), out))
+        return {"flat_prims": out[0], "boxes": out[1], "bvh_meshes": out[2], "bvh_nodes": out[3], "triangles": out[4], "grad_floats": out[5]}
+
     def release(self):
         if self._handle is not None:
             abi.lib().mi355_scene_destroy(self._handle)

@@ -64,6 +64,40 @@ def test_ray_intersect_cornell(mi, orc, torch_cuda):
     assert np.isinf(got["t"][miss]).all()
 
 
+def test_box_and_quad_primitives(mi, orc, torch_cuda):
+    """Geometry organisation: Cornell = 6 rectangle records + 2 oriented boxes; a sheared cube is still a parallelepiped;
+    a cube with one displaced corner is not (falls back to parallelogram / triangle records) -- all three agree with the
+    oracle's per-triangle Moeller-Trumbore, including prim_index and barycentrics (through uv)."""
+    T = mi.ScalarTransform4f
+    scene = mi.load_dict(small_cbox(mi, 32))
+    assert scene.info() == {"flat_prims": 6, "boxes": 2, "bvh_meshes": 0, "bvh_nodes": 0, "triangles": 24, "grad_floats": 12}
+    shear = mi.Transform4f([[0.5, 0.2, 0.0, 0.1], [0.0, 0.4, 0.1, -0.2], [0.1, 0.0, 0.3, 0.2], [0, 0, 0, 1]])
+    v = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1]], dtype=np.float32)
+    f = np.array([[0, 1, 2], [3, 0, 2], [4, 5, 6], [7, 4, 6], [0, 4, 7], [1, 0, 7], [1, 7, 6], [2, 1, 6], [2, 6, 5], [3, 2, 5], [4, 0, 3], [5, 4, 3]], dtype=np.uint32)
+    bent = v.copy(); bent[7] += [0.3, 0.2, 0.1]
+    cases = [({"type": "cube", "to_world": shear}, {"boxes": 1, "flat_prims": 1}),
+             ({"type": "mesh", "vertex_positions": bent, "faces": f, "to_world": T.scale(0.5)}, {"boxes": 0}),
+             ({"type": "mesh", "vertex_positions": v, "faces": f[:10], "to_world": T.scale(0.5)}, {"boxes": 0, "flat_prims": 6})]
+    for shape, expect in cases:
+        d = {"type": "scene", "obj": shape, "floor": {"type": "rectangle", "to_world": T.translate([0, -1, 0]).rotate([1, 0, 0], -90)},
+             "sensor": {"type": "perspective", "fov": 60, "to_world": T.look_at([0.3, 0.4, 3], [0, 0, 0], [0, 1, 0]),
+                        "film": {"type": "hdrfilm", "width": 64, "height": 64, "pixel_format": "rgb"}}}
+        sc = mi.load_dict(d); info = sc.info()
+        for k, val in expect.items():
+            assert info[k] == val, (k, info)
+        o = orc.OracleScene(sc, mi.abi)
+        rays = _rays_for(sc, o, 8192, seed=11)
+        ref = orc.unpack_hits(o.ray_intersect(rays)); got = orc.unpack_hits(_gpu_intersect(mi, torch_cuda, sc, rays))
+        same_shape = (ref["shape"] == got["shape"]) & (ref["occluded"] == got["occluded"])
+        assert same_shape.mean() > 0.999
+        hit = same_shape & np.isfinite(ref["t"])
+        assert (ref["shape"][hit] == 0).sum() > 300
+        assert np.allclose(ref["t"][hit], got["t"][hit], rtol=3e-5, atol=3e-6)
+        same = hit & (ref["prim"] == got["prim"])
+        assert same.sum() > 0.99 * hit.sum()
+        assert np.allclose(ref["u"][same], got["u"][same], atol=5e-5) and np.allclose(ref["v"][same], got["v"][same], atol=5e-5)
+
+
 def _icosphere(sub=3):
     t = (1 + 5 ** 0.5) / 2
     v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
