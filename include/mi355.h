@@ -146,8 +146,9 @@ typedef struct mi355_scene_desc {
 #define MI355_FLAG_HIDE_EMITTERS  1u   /* MonteCarloIntegrator::m_hide_emitters */
 #define MI355_FLAG_TIMING         2u   /* bracket the path kernel with HIP events on `stream` */
 
-enum { MI355_MODE_FUSED = 0,           /* one launch per pass, path state lives in registers */
-       MI355_MODE_WAVEFRONT = 1 };     /* SoA ray/hit/state streams + ballot compaction per bounce */
+enum { MI355_MODE_FUSED = 0,           /* one launch per pass, a lane keeps its path in registers until it ends (default) */
+       MI355_MODE_WAVEFRONT = 1 };     /* after every bounce the workgroup re-packs surviving lanes (wave ballot + prefix sum,
+                                          SoA state exchanged through LDS) so that waves stay full; path integrator only */
 
 enum { MI355_INTEGRATOR_PATH = 0,      /* src/integrators/path.cpp */
        MI355_INTEGRATOR_PRB  = 1 };    /* src/python/python/ad/integrators/prb.py (primal estimator differs in RR timing) */

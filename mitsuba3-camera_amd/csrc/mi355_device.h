@@ -259,7 +259,7 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
     return tn <= tf * 1.00001f + 1e-6f;
 }
 
-#define MI_BVH_STACK 24
+#define MI_BVH_STACK 20
 #ifndef MI_PRIM_UNROLL
 #define MI_PRIM_UNROLL 1
 #endif
@@ -413,6 +413,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
 // Scene::ray_test (scene.cpp:201-210): any hit.
 MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32_t *stk) {
     bool occluded = false;
+    if (!__any(active)) return false;                                      // nobody in this wave asked
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     const uint32_t n = sc.n_prims;
     MI_UNROLL_PRIMS
@@ -614,59 +615,80 @@ struct Counters3 { uint32_t isect, shade, shadow; };
 // -------------------------------------------------------------------------------------------
 // PathIntegrator::sample, src/integrators/path.cpp:95-287
 // -------------------------------------------------------------------------------------------
-MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
-                        bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt) {
-    v3 throughput = V3(1.f, 1.f, 1.f), result = V3(0.f, 0.f, 0.f); float eta = 1.f; uint32_t depth = 0;
-    bool valid_ray = false;                                                // no environment emitter, path.cpp:115
-    v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
-    active = active && max_depth != 0;
-    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
-        Hit hit = scene_intersect(sc, ray, active, stk);
-        if (active) cnt.isect++;
-        bool si_valid = active && hit.t != MI_INF;
-        bool active_next = si_valid && (depth + 1 < max_depth);            // path.cpp:177
-        active = false;
-        if (si_valid) {
-            cnt.shade++;
-            SI si = compute_si(sc, ray, hit);
-            const DShape &sh = sc.shapes[hit.shape];
-            int32_t emitter = sh.emitter;
-            if (emitter >= 0) {                                            // path.cpp:158-174
-                v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);   // records.h:173-180
-                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
-                float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
-                v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
-                result = fma3(throughput, le * mis_bsdf, result);
-            }
+// Loop-carried state of PathIntegrator::sample (path.cpp:108-121).  For the lanes that are still alive the loop counter
+// IS the path depth (depth is only incremented on valid hits, path.cpp:266, and an invalid hit ends the path), and
+// prev_bsdf_delta is true exactly at the first vertex -- so neither needs a register.  eta stays 1 (no refraction yet).
+struct PathState { Ray ray; v3 throughput, result, prev_p; float prev_bsdf_pdf; Pcg32 rng; };
+
+MI_DEV void path_init(PathState &st, const Ray &ray, const Pcg32 &rng) {
+    st.ray = ray; st.throughput = V3(1.f, 1.f, 1.f); st.result = V3(0.f, 0.f, 0.f); st.prev_p = V3(0.f, 0.f, 0.f);
+    st.prev_bsdf_pdf = 1.f; st.rng = rng;
+}
+// One iteration of the loop of path.cpp:142-281 at depth `it`.  Returns whether the lane continues; `hit_any` reports
+// a valid surface hit (feeds valid_ray, path.cpp:256).
+MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
+                      bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
+    const float eta = 1.f;
+    Hit hit = scene_intersect(sc, st.ray, active, stk);
+    if (active) cnt.isect++;
+    bool si_valid = active && hit.t != MI_INF;
+    bool active_next = si_valid && (it + 1 < max_depth);                    // path.cpp:177
+    bool alive = false;
+    hit_any = si_valid;
+    if (si_valid) {
+        cnt.shade++;
+        SI si = compute_si(sc, st.ray, hit);
+        const DShape &sh = sc.shapes[hit.shape];
+        int32_t emitter = sh.emitter;
+        if (emitter >= 0) {                                                // path.cpp:158-174
+            v3 rel = si.p - st.prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);   // records.h:173-180
+            float em_pdf = it == 0 ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            float mis_bsdf = mis_weight(st.prev_bsdf_pdf, em_pdf);
+            v3 le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
+            st.result = fma3(st.throughput, le * mis_bsdf, st.result);
+        }
+        // At the last vertex (it + 1 == max_depth, uniform over the wave) nothing below can change the result:
+        // active_next is false for every lane, so no NEE contribution, no continuation (path.cpp:177-187).
+        if (it + 1 < max_depth) {
             const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
             v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
             // ---- emitter sampling (path.cpp:186-208)
-            float ex = next_1d(rng), ey = next_1d(rng);
+            float ex = next_1d(st.rng), ey = next_1d(st.rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
             bool need_shadow = sample_emitter_direction(sc, si, ex, ey, active_next, ds, em_weight, shadow);
             // ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33)
-            float s1 = next_1d(rng); (void) s1; float s2x = next_1d(rng), s2y = next_1d(rng);
+            float s1 = next_1d(st.rng); (void) s1; float s2x = next_1d(st.rng), s2y = next_1d(st.rng);
             v3 wo = si_to_local(si, ds.d);
             v3 bsdf_val; float bsdf_pdf; diffuse_eval_pdf(refl, si.wi, wo, true, bsdf_val, bsdf_pdf);
             v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2x, s2y, true, bs_wo, bs_pdf, bsdf_weight);
             v3 contrib = (bsdf_val * em_weight) * mis_weight(ds.pdf, bsdf_pdf);
             bool occluded = scene_ray_test(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
             if (need_shadow) cnt.shadow++;
-            if (need_shadow && !occluded) result = fma3(throughput, contrib, result);   // path.cpp:220-230
+            if (need_shadow && !occluded) st.result = fma3(st.throughput, contrib, st.result);   // path.cpp:220-230
             // ---- BSDF sampling + loop update (path.cpp:234-280)
-            ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
-            throughput = throughput * bsdf_weight;
-            valid_ray = true;
-            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
-            depth += 1;
-            float tmax = max3(throughput);
+            st.ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
+            st.throughput = st.throughput * bsdf_weight;
+            st.prev_p = si.p; st.prev_bsdf_pdf = bs_pdf;
+            float tmax = max3(st.throughput);
             float rr_prob = fminf(tmax * (eta * eta), .95f);
-            bool rr_active = depth >= rr_depth, rr_continue = next_1d(rng) < rr_prob;
-            if (rr_active) throughput = throughput * rcp_(rr_prob);
-            active = active_next && (!rr_active || rr_continue) && tmax != 0.f;
+            bool rr_active = it + 1 >= rr_depth, rr_continue = next_1d(st.rng) < rr_prob;
+            if (rr_active) st.throughput = st.throughput * rcp_(rr_prob);
+            alive = active_next && (!rr_active || rr_continue) && tmax != 0.f;
         }
     }
-    result_out = valid_ray ? result : V3(0.f, 0.f, 0.f); valid_out = valid_ray;
+    return alive;
+}
+MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
+                        bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt) {
+    PathState st; path_init(st, ray, rng);
+    bool valid_ray = false;                                                // no environment emitter, path.cpp:115
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        bool hit_any;
+        active = path_step(sc, st, it, max_depth, rr_depth, active, stk, hit_any, cnt);
+        valid_ray = valid_ray || hit_any;
+    }
+    rng = st.rng;
+    result_out = valid_ray ? st.result : V3(0.f, 0.f, 0.f); valid_out = valid_ray;
 }
 
 // -------------------------------------------------------------------------------------------

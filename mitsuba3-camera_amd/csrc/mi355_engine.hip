@@ -15,6 +15,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <algorithm>
 #include <numeric>
@@ -29,12 +30,14 @@
 #define MI_MIN_WAVES_BWD 4                  // k_prb_backward spills at 5 (measured slower)
 #endif
 #define ROW_STRIDE 68                       // 64 lanes + 4 pad floats: 16-B aligned rows, shifts banks by 4 per row
-#define SPLAT_ROWS 29                       // 25 tap weights + 4 channel values
+#define SPLAT_ROWS 14                       // 5 x-weights + 5 y-weights + 4 channel values (separable filter)
 #define WAVE_FLOATS (SPLAT_ROWS * ROW_STRIDE)
 #define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
+#define CSTATE_WORDS 21                     // per lane, k_render_compact
 #define MAX_SMALL_GRAD 1024
-
-static_assert(WAVE_FLOATS >= STACK_WORDS, "BVH stack aliases the splat staging area");
+// one LDS region per workgroup, reused in turn by: BVH traversal stacks | compaction state exchange | film splat staging
+#define CMAX(a, b) ((a) > (b) ? (a) : (b))
+#define REGION_FLOATS CMAX(CMAX(WAVES * WAVE_FLOATS, WAVES * STACK_WORDS), CSTATE_WORDS * BLOCK)
 
 struct RenderArgs {
     uint32_t seed, spp_total, max_depth, rr_depth, flags;
@@ -74,25 +77,28 @@ MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, 
     bool lds_path = a.seg != 0;
     if (lds_path) {
 #pragma unroll
-        for (int ty = 0; ty < 5; ++ty)
+        for (int k = 0; k < 5; ++k) {
+            smem_wave[k * ROW_STRIDE + lane_id] = nominal ? sp.wx[k] : 0.f;
+            smem_wave[(5 + k) * ROW_STRIDE + lane_id] = nominal ? sp.wy[k] : 0.f;
+        }
 #pragma unroll
-            for (int tx = 0; tx < 5; ++tx)
-                smem_wave[(ty * 5 + tx) * ROW_STRIDE + lane_id] = nominal ? sp.wy[ty] * sp.wx[tx] : 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) smem_wave[(25 + c) * ROW_STRIDE + lane_id] = nominal ? values[c] : 0.f;
+        for (int c = 0; c < CH; ++c) smem_wave[(10 + c) * ROW_STRIDE + lane_id] = nominal ? values[c] : 0.f;
     }
     __syncthreads();
     if (lds_path) {
         const uint32_t seg = a.seg, groups = 64u / seg, total = groups * 25u * CH;
         for (uint32_t o = lane_id; o < total; o += 64) {
             uint32_t g = o / (25u * CH), r = o - g * (25u * CH), t = r / CH, c = r - t * CH;
-            const float *wr = smem_wave + t * ROW_STRIDE + g * seg;
-            const float *vr = smem_wave + (25 + c) * ROW_STRIDE + g * seg;
+            const float *xr = smem_wave + (t % 5u) * ROW_STRIDE + g * seg;
+            const float *yr = smem_wave + (5u + t / 5u) * ROW_STRIDE + g * seg;
+            const float *vr = smem_wave + (10 + c) * ROW_STRIDE + g * seg;
             float sum = 0.f;
             for (uint32_t l = 0; l < seg; l += 4) {
-                float4 wv = *reinterpret_cast<const float4 *>(wr + l);
+                float4 xv = *reinterpret_cast<const float4 *>(xr + l);
+                float4 yv = *reinterpret_cast<const float4 *>(yr + l);
                 float4 vv = *reinterpret_cast<const float4 *>(vr + l);
-                sum = fmaf(wv.x, vv.x, sum); sum = fmaf(wv.y, vv.y, sum); sum = fmaf(wv.z, vv.z, sum); sum = fmaf(wv.w, vv.w, sum);
+                sum = fmaf(yv.x * xv.x, vv.x, sum); sum = fmaf(yv.y * xv.y, vv.y, sum);      // weight = wy*wx (imageblock.cpp:486)
+                sum = fmaf(yv.z * xv.z, vv.z, sum); sum = fmaf(yv.w * xv.w, vv.w, sum);
             }
             uint32_t ig = i_wave_first + g * seg;
             if (ig < a.n_local && sum != 0.f) {
@@ -127,12 +133,12 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
 template <int INTEGRATOR, int OUT>
 __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem_wave) + lane_id;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li;
     if (OUT == OUT_LANES) {   // lanes of the whole job, no sharding
@@ -163,9 +169,90 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, Rende
     flush_counters(s_cnt, cnt, g_counters);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_render_compact: same work as k_render<PATH, FILM>, but after every bounce the workgroup re-packs its surviving
+// lanes into the lowest thread slots (wave ballot + popcount prefix, state exchanged through LDS).  Waves whose slots
+// are all empty skip the bounce and just meet the others at the barriers, so the VALU time of a workgroup shrinks
+// from "6 bounces x 4 waves" to "sum over bounces of ceil(alive / 64)".  Final radiance returns to the lane's ORIGINAL
+// slot (`fin`) so that the per-pixel LDS film reduction still sees all samples of a pixel side by side.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];         // BVH stack | compaction state | splat staging
+    __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_wcnt[WAVES];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_id = tid & 63;
+    float *smem_wave = smem + wave * WAVE_FLOATS;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t i = blockIdx.x * BLOCK + tid;
+    LaneInfo li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);     // integrator.cpp:435
+    PathState st; path_init(st, sample_primary_ray(sc, pos_x, pos_y), rng);
+    Counters3 cnt = { 0, 0, 0 };
+    fin[tid] = 0.f; fin[BLOCK + tid] = 0.f; fin[2 * BLOCK + tid] = 0.f; fin[3 * BLOCK + tid] = 0.f;
+    uint32_t orig = tid;                       // which original slot the path in this thread belongs to
+    bool valid_ray = false;
+    uint32_t n_alive = min((uint32_t) BLOCK, a.n_local - min(a.n_local, blockIdx.x * BLOCK));   // slots [0, n_alive) hold live paths
+    for (uint32_t it = 0; it < a.max_depth && n_alive > 0; ++it) {
+        bool mine = tid < n_alive, alive = false;
+        if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
+            bool hit_any;
+            alive = path_step(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            valid_ray = valid_ray || hit_any;
+        }
+        if (mine && !alive) {                                               // path over: park its radiance in its original slot
+            bool v = valid_ray;
+            fin[orig] = v ? st.result.x : 0.f; fin[BLOCK + orig] = v ? st.result.y : 0.f; fin[2 * BLOCK + orig] = v ? st.result.z : 0.f;
+            fin[3 * BLOCK + orig] = v ? 1.f : 0.f;
+        }
+        unsigned long long m = __ballot(alive);
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+        if (lane_id == 0) s_wcnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();                                                    // everyone is done with the stack / previous state
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < WAVES; ++w) { uint32_t c = s_wcnt[w]; base += w < wave ? c : 0u; total += c; }
+        if (alive) {
+            uint32_t j = base + rank;
+            float *q = smem + j;
+            q[0 * BLOCK] = st.ray.o.x; q[1 * BLOCK] = st.ray.o.y; q[2 * BLOCK] = st.ray.o.z;
+            q[3 * BLOCK] = st.ray.d.x; q[4 * BLOCK] = st.ray.d.y; q[5 * BLOCK] = st.ray.d.z;
+            q[6 * BLOCK] = st.throughput.x; q[7 * BLOCK] = st.throughput.y; q[8 * BLOCK] = st.throughput.z;
+            q[9 * BLOCK] = st.result.x; q[10 * BLOCK] = st.result.y; q[11 * BLOCK] = st.result.z;
+            q[12 * BLOCK] = st.prev_p.x; q[13 * BLOCK] = st.prev_p.y; q[14 * BLOCK] = st.prev_p.z;
+            q[15 * BLOCK] = st.prev_bsdf_pdf;
+            q[16 * BLOCK] = __uint_as_float((uint32_t) st.rng.state); q[17 * BLOCK] = __uint_as_float((uint32_t) (st.rng.state >> 32));
+            q[18 * BLOCK] = __uint_as_float((uint32_t) st.rng.inc); q[19 * BLOCK] = __uint_as_float((uint32_t) (st.rng.inc >> 32));
+            q[20 * BLOCK] = __uint_as_float(orig);
+        }
+        __syncthreads();
+        n_alive = total;
+        if (tid < n_alive) {
+            const float *q = smem + tid;
+            st.ray.o = V3(q[0 * BLOCK], q[1 * BLOCK], q[2 * BLOCK]); st.ray.d = V3(q[3 * BLOCK], q[4 * BLOCK], q[5 * BLOCK]);
+            st.ray.maxt = MI_LARGEST;
+            st.throughput = V3(q[6 * BLOCK], q[7 * BLOCK], q[8 * BLOCK]); st.result = V3(q[9 * BLOCK], q[10 * BLOCK], q[11 * BLOCK]);
+            st.prev_p = V3(q[12 * BLOCK], q[13 * BLOCK], q[14 * BLOCK]); st.prev_bsdf_pdf = q[15 * BLOCK];
+            st.rng.state = (uint64_t) __float_as_uint(q[16 * BLOCK]) | ((uint64_t) __float_as_uint(q[17 * BLOCK]) << 32);
+            st.rng.inc = (uint64_t) __float_as_uint(q[18 * BLOCK]) | ((uint64_t) __float_as_uint(q[19 * BLOCK]) << 32);
+            orig = __float_as_uint(q[20 * BLOCK]);
+            valid_ray = true;                                               // a path that continues has hit a surface
+        }
+        if (sc.n_bvh_shapes) __syncthreads();                               // the BVH stack aliases the state just read
+    }
+    __syncthreads();
+    float values[4] = { fin[tid], fin[BLOCK + tid], fin[2 * BLOCK + tid], 1.f };          // integrator.cpp:477-486 (rgb film, no alpha)
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    __syncthreads();
+    film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
 // RBIntegrator.render_backward step 1a: common.py:741-758 with L = 1, weight = 1
 __global__ __launch_bounds__(BLOCK) void k_splat_weights(DScene sc, RenderArgs a, float *weight) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * WAVE_FLOATS];   // splat staging only
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li = lane_info(sc, a, i);
@@ -814,7 +901,9 @@ struct Timed {
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
-    if (p->mode != MI355_MODE_FUSED) return fail(MI355_ERR_UNSUPPORTED, "wavefront mode is not part of this build yet");
+    if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT) return fail(MI355_ERR_INVALID, "unknown mode");
+    if (p->mode == MI355_MODE_WAVEFRONT && p->integrator != MI355_INTEGRATOR_PATH)
+        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for the path integrator only");
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
@@ -822,6 +911,8 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     if ((rc = tm.begin())) return rc;
     if (p->integrator == MI355_INTEGRATOR_PRB)
         hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
+    else if (p->mode == MI355_MODE_WAVEFRONT)
+        hipLaunchKernelGGL(k_render_compact, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     else
         hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
     HIP_TRY(hipGetLastError());

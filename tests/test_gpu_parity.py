@@ -174,6 +174,30 @@ def test_render_matches_oracle(mi, orc, torch_cuda, cbox32, spp):
     assert np.allclose(raw[:, :, 3], raw_ref[:, :, 3], rtol=1e-4, atol=1e-4)          # W channel: pure filter weights
 
 
+@pytest.mark.parametrize("spp,max_depth,rr_depth", [(16, 6, 5), (64, -1, 2), (3, 4, 5), (128, 2, 5)])
+def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_depth, rr_depth):
+    """MI355_MODE_WAVEFRONT re-packs lanes between bounces; lanes are still pure functions of (seed, lane id), so the film
+    must equal the fused mode's (up to float-atomic order) and the oracle's."""
+    integ = mi.PathIntegrator({"max_depth": max_depth, "rr_depth": rr_depth})
+    fused = integ.render(cbox32, seed=8, spp=spp, develop=False)
+    integ.mode = mi.abi.MODE_WAVEFRONT
+    integ.counters(cbox32, reset=True)
+    wf = integ.render(cbox32, seed=8, spp=spp, develop=False)
+    c_wf = integ.counters(cbox32, reset=True)
+    assert torch_cuda.allclose(wf, fused, rtol=1e-4, atol=1e-4)
+    o = orc.OracleScene(cbox32, mi.abi)
+    o.counters(reset=True)
+    ref, _ = o.render(o.params(integ, 8, spp))
+    img = integ.render(cbox32, seed=8, spp=spp).cpu().numpy()
+    assert np.abs(img - ref).max() < 1e-3 * ref.max()
+    r = o.counters()
+    for k in ("n_isect", "n_shade", "n_shadow"):
+        assert abs(int(c_wf[k]) - r[k]) <= 2e-3 * r[k] + 2, (k, c_wf[k], r[k])
+    prb = mi.PRBIntegrator(); prb.mode = mi.abi.MODE_WAVEFRONT
+    with pytest.raises(mi.Mi355Error):
+        prb.render(cbox32, seed=1, spp=4)
+
+
 @pytest.mark.parametrize("rfilter", [{"type": "box"}, {"type": "tent"}, {"type": "gaussian", "stddev": 0.4}])
 def test_render_filters_and_crop(mi, orc, torch_cuda, rfilter):
     d = small_cbox(mi, 48, rfilter=rfilter, crop_width=24, crop_height=16, crop_offset_x=10, crop_offset_y=20)
