@@ -699,7 +699,12 @@ MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_dept
 // Gradient sinks: `s_grad` = per-workgroup LDS accumulators for the "small" parameters
 // (constant reflectances, emitter radiances), `g_grad` = the global gradient buffer (textures).
 // -------------------------------------------------------------------------------------------
-struct GradSink { float *s_grad; float *g_grad; };
+// `q` = per-workgroup LDS queue of texture-gradient records (float index of the texel's first channel, d/dr, d/dg, d/db),
+// flushed once at the end of the kernel: keeps ~3000-cycle float atomics out of the bounce loop, where every later
+// vector load would have to wait for them (vmcnt retires in order).
+// One record (8 dwords) per textured vertex: texture id, texel ids of the (0,0) and (1,1) taps, the two lerp weights and
+// dLoss/d(albedo rgb); the other two taps and the 12 (tap, channel) atomics are expanded at flush time.
+struct GradSink { float *s_grad; float *g_grad; float *q; uint32_t *qn; uint32_t qcap; };
 
 template <bool BACKWARD>
 MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
@@ -728,6 +733,17 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                 Le = (beta * le_mis) * e;
             }
             active_next = active_next && (depth + 1 < max_depth);          // prb.py:139
+            if (!(it + 1 < max_depth)) {
+                // last vertex (uniform over the wave): active_next is false for every lane, so Lr_dir = 0, the BSDF sample is
+                // unused and bsdf.eval(..., active_next) = 0 -- only Le and its emitter gradient remain (prb.py:134,173,230).
+                L = BACKWARD ? L - Le : L + Le;
+                if (BACKWARD && emitter >= 0 && le_front && sc.emitters[emitter].grad_slot >= 0) {
+                    float *gb = sink.s_grad + sc.emitters[emitter].grad_slot;
+                    atomicAdd(gb + 0, dL.x * beta.x * le_mis); atomicAdd(gb + 1, dL.y * beta.y * le_mis); atomicAdd(gb + 2, dL.z * beta.z * le_mis);
+                }
+                depth += 1;
+                continue;
+            }
             const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
             TexTaps taps; v3 refl;
             if (bsdf.texture >= 0) refl = texture_eval(sc, sc.textures[bsdf.texture], si.uv, BACKWARD ? &taps : nullptr);
@@ -771,17 +787,36 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                 float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
                 dLo = dLo + ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
                 v3 ga = dL * dLo;
-                if (bsdf.texture >= 0) {
-                    const DTexture &tx = sc.textures[bsdf.texture];
-                    if (tx.grad_slot >= 0 && sink.g_grad) {
-                        float *gb = sink.g_grad + tx.grad_offset;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) if (taps.idx[k] >= 0 && taps.w[k] != 0.f) {
-                            if (tx.c == 3) { atomicAdd(gb + taps.idx[k] * 3 + 0, taps.w[k] * ga.x); atomicAdd(gb + taps.idx[k] * 3 + 1, taps.w[k] * ga.y);
-                                             atomicAdd(gb + taps.idx[k] * 3 + 2, taps.w[k] * ga.z); }
-                            else atomicAdd(gb + taps.idx[k], taps.w[k] * (ga.x + ga.y + ga.z));
+                bool textured = bsdf.texture >= 0 && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0 && sink.g_grad != nullptr;
+                bool queued = textured && sc.textures[bsdf.texture].c == 3 && sink.q != nullptr;
+                {   // wave-aggregated slot allocation: one LDS atomic per wave, one record per textured lane
+                    unsigned long long m = __ballot(queued);
+                    if (m) {
+                        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                        uint32_t base = 0;
+                        if (rank == 0 && queued) base = atomicAdd(sink.qn, (uint32_t) __popcll(m));
+                        base = (uint32_t) __shfl((int) base, __ffsll((long long) m) - 1);
+                        uint32_t slot = base + rank;
+                        if (queued && slot < sink.qcap && taps.idx[3] >= 0) {
+                            float *r = sink.q + 8u * slot;
+                            float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];     // w = (w0y|w1y) * (w0x|w1x), sums to 1
+                            r[0] = __uint_as_float((uint32_t) bsdf.texture); r[1] = __uint_as_float((uint32_t) taps.idx[0]);
+                            r[2] = __uint_as_float((uint32_t) taps.idx[3]); r[3] = w1x; r[4] = w1y; r[5] = ga.x; r[6] = ga.y; r[7] = ga.z;
+                            textured = false;                              // handled
                         }
                     }
+                }
+                if (textured) {                                            // queue full, or a 1-channel texture: direct atomics
+                    const DTexture &tx = sc.textures[bsdf.texture];
+                    float *gb = sink.g_grad + tx.grad_offset;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (taps.idx[k] >= 0 && taps.w[k] != 0.f) {
+                        if (tx.c == 3) { atomicAdd(gb + taps.idx[k] * 3 + 0, taps.w[k] * ga.x); atomicAdd(gb + taps.idx[k] * 3 + 1, taps.w[k] * ga.y);
+                                         atomicAdd(gb + taps.idx[k] * 3 + 2, taps.w[k] * ga.z); }
+                        else atomicAdd(gb + taps.idx[k], taps.w[k] * (ga.x + ga.y + ga.z));
+                    }
+                }
+                if (bsdf.texture >= 0) {
                 } else if (bsdf.grad_slot >= 0) {
                     float *gb = sink.s_grad + bsdf.grad_slot;
                     atomicAdd(gb + 0, ga.x); atomicAdd(gb + 1, ga.y); atomicAdd(gb + 2, ga.z);

@@ -35,6 +35,7 @@
 #define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
 #define CSTATE_WORDS 21                     // per lane, k_render_compact
 #define MAX_SMALL_GRAD 1024
+#define GRAD_QUEUE 496                      // texture-gradient records per workgroup (16 KB, 2 per lane); overflow -> direct atomics
 // one LDS region per workgroup, reused in turn by: BVH traversal stacks | compaction state exchange | film splat staging
 #define CMAX(a, b) ((a) > (b) ? (a) : (b))
 #define REGION_FLOATS CMAX(CMAX(WAVES * WAVE_FLOATS, WAVES * STACK_WORDS), CSTATE_WORDS * BLOCK)
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, Rende
     if (INTEGRATOR == MI355_INTEGRATOR_PATH)
         path_sample(sc, rng, ray, a.max_depth, a.rr_depth, li.act, stk, rgb, valid, cnt);
     else {
-        GradSink none = { nullptr, nullptr };
+        GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 };
         prb_sample<false>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, li.act, stk,
                           V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, rgb, valid, cnt);
     }
@@ -264,13 +265,24 @@ __global__ __launch_bounds__(BLOCK) void k_splat_weights(DScene sc, RenderArgs a
 }
 
 // RBIntegrator.render_backward steps 1b-3: common.py:741-796
-__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float *grad_in, const float *weight,
+// grad_in / (W == 0 ? 1 : W), one float4 per pixel: the adjoint of HDRFilm::develop's division (hdrfilm.cpp:396-400)
+__global__ void k_prepare_grad(const float *grad_in, const float *weight, float4 *gw, uint32_t n_pixels) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float wv = weight[i]; float inv = 1.0f / (wv == 0.f ? 1.f : wv);
+    gw[i] = make_float4(grad_in[3 * i] * inv, grad_in[3 * i + 1] * inv, grad_in[3 * i + 2] * inv, 0.f);
+}
+
+__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
     __shared__ float s_grad[MAX_SMALL_GRAD];
+    __shared__ float s_q[GRAD_QUEUE * 8];
+    __shared__ uint32_t s_qn;
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_qn = 0;
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) s_grad[k] = 0.f;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
     float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);
     Ray ray = sample_primary_ray(sc, pos_x, pos_y);
-    // dL = adjoint of splat + develop: sum over taps of grad_in[p] * w(p) / W[p]   (hdrfilm.cpp:400)
+    // dL = adjoint of splat + develop: sum over taps of w(p) * grad_in[p] / W[p]   (hdrfilm.cpp:400); gw = grad_in / W
     Splat sp = splat_weights(sc, pos_x, pos_y);
     v3 dL = V3(0.f, 0.f, 0.f);
     const int W = (int) sc.crop_w, H = (int) sc.crop_h;
@@ -291,20 +303,36 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene
             for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
                 int32_t x = sp.x0 + tx, y = sp.y0 + ty;
                 if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
-                size_t p = (size_t) y * W + x; float wv = weight[p]; float dv = wv == 0.f ? 1.f : wv;
-                float w = sp.wy[ty] * sp.wx[tx] / dv;
-                dL.x += grad_in[3 * p] * w; dL.y += grad_in[3 * p + 1] * w; dL.z += grad_in[3 * p + 2] * w;
+                float4 g = gw[(size_t) y * W + x];
+                float w = sp.wy[ty] * sp.wx[tx];
+                dL.x = fmaf(g.x, w, dL.x); dL.y = fmaf(g.y, w, dL.y); dL.z = fmaf(g.z, w, dL.z);
             }
     }
     Counters3 cnt = { 0, 0, 0 };
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
-    GradSink none = { nullptr, nullptr }, sink = { s_grad, g_grad };
+    GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE };
     Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
     v3 L, L2; bool valid;
     prb_sample<false>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, li.act, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
     prb_sample<true>(sc, rng, ray, a.max_depth, a.rr_depth, hide, li.act, stk, dL, L, sink, L2, valid, cnt);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
+    // flush the texture-gradient queue: 12 consecutive lanes expand one record into its (tap, channel) atomics, so the
+    // three channels of a texel (12 contiguous bytes) leave in one wave-instruction and share a 64-B request
+    {
+        uint32_t n = min(s_qn, (uint32_t) GRAD_QUEUE) * 12u;
+        for (uint32_t e = threadIdx.x; e < n; e += BLOCK) {
+            uint32_t rec = e / 12u, k = e - rec * 12u, tap = k / 3u, ch = k - tap * 3u;
+            const float *r = s_q + 8u * rec;
+            const DTexture &tx = sc.textures[__float_as_uint(r[0])];
+            uint32_t i00 = __float_as_uint(r[1]), i11 = __float_as_uint(r[2]);
+            uint32_t x0 = i00 % tx.w, x1 = i11 % tx.w;
+            uint32_t idx = tap == 0 ? i00 : (tap == 3 ? i11 : (tap == 1 ? i00 - x0 + x1 : i11 - x1 + x0));
+            float wx = (tap & 1u) ? r[3] : 1.f - r[3], wy = (tap & 2u) ? r[4] : 1.f - r[4];
+            float v = (wy * wx) * r[5 + ch];
+            if (v != 0.f) atomicAdd(g_grad + tx.grad_offset + (size_t) idx * 3u + ch, v);
+        }
+    }
     flush_counters(s_cnt, cnt, g_counters);
 }
 
@@ -430,6 +458,7 @@ struct mi355_scene {
     DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
+    float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow
     uint64_t n_gen = 0, n_splat = 0;
     hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
@@ -782,6 +811,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_textures, s->textures))) return rc;
     if ((rc = upload(&s->d_texdata, s->texdata))) return rc;
     if ((rc = upload(&s->d_small_map, s->small_map))) return rc;
+    HIP_TRY(hipMalloc((void **) &s->d_gw, (size_t) se.crop_width * se.crop_height * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
@@ -808,7 +838,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -954,7 +984,9 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
     hipStream_t st = (hipStream_t) stream;
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
-    hipLaunchKernelGGL(k_prb_backward, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, d_grad_in, d_weight,
+    uint32_t npix = s->ds.crop_w * s->ds.crop_h;
+    hipLaunchKernelGGL(k_prepare_grad, dim3((npix + 255) / 256), dim3(256), 0, st, d_grad_in, d_weight, s->d_gw, npix);
+    hipLaunchKernelGGL(k_prb_backward, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
                        d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
