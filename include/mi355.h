@@ -91,6 +91,7 @@ typedef struct mi355_bsdf_desc {
     float    eta[3], k[3];              /* roughconductor complex IOR */
     float    int_ior, ext_ior;          /* dielectric */
     uint32_t sample_visible;
+    float    transmittance[3];          /* dielectric: specular_transmittance (reflectance[] = specular_reflectance) */
 } mi355_bsdf_desc;
 
 typedef struct mi355_emitter_desc {
@@ -247,7 +248,8 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 
 /* How the replica's geometry was organised (cf. the accel statistics Scene logs, scene.cpp:108-118):
    out[0] flat parallelogram records, out[1] oriented-box records, out[2] meshes traversed through a BVH,
-   out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6..7] reserved. */
+   out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6] analytic spheres,
+   out[7] feature bits (bit 0: glossy / specular BSDFs present -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
 
 /* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):

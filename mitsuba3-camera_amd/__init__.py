@@ -11,7 +11,7 @@ The directory name contains a hyphen, so the package is loaded under the module 
 from . import _abi as abi
 from ._abi import Mi355Error
 from .transforms import Transform4f, ScalarTransform4f
-from .scene import (Scene, Shape, BSDF, Emitter, Texture, Sensor, Film, PluginError, load_dict, cornell_box, parse_fov)
+from .scene import (Scene, Shape, BSDF, Emitter, Texture, Sensor, Film, PluginError, load_dict, cornell_box, veach_mis_scene, parse_fov)
 from .integrators import (Integrator, PathIntegrator, PRBIntegrator, make_integrator, SceneParameters, traverse, render,
                           sample_tea_32, shard_pixels, scene_param_layout)
 

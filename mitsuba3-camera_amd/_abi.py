@@ -39,7 +39,7 @@ class BsdfDesc(C.Structure):
     _fields_ = [("type", C.c_uint32), ("reflectance", C.c_float * 3), ("reflectance_texture", C.c_int32),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("distribution", C.c_uint32),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3), ("int_ior", C.c_float), ("ext_ior", C.c_float),
-                ("sample_visible", C.c_uint32)]
+                ("sample_visible", C.c_uint32), ("transmittance", C.c_float * 3)]
 
 
 class EmitterDesc(C.Structure):

@@ -73,7 +73,15 @@ struct DBvhNode {                                          // binary BVH over on
     float lo[3]; uint32_t left;                            // inner: children = left, left+1; leaf: first triangle
     float hi[3]; uint32_t count;                           // 0 = inner node, else number of triangles
 };
-struct DBsdf { uint32_t type; float reflectance[3]; int32_t texture; int32_t grad_slot; uint32_t pad[2]; };
+struct DBsdf {                       // 96 B
+    uint32_t type; float reflectance[3]; int32_t texture; int32_t grad_slot;
+    float alpha_u, alpha_v; uint32_t distribution, sample_visible;      // roughconductor.cpp:163-212
+    float eta[3], k[3];
+    float rel_eta;                                                      // dielectric: int_ior / ext_ior (dielectric.cpp:222)
+    float transmittance[3];
+    uint32_t pad[4];
+};
+struct DSphere { float center[3]; float radius; uint32_t shape; uint32_t pad[3]; };   // sphere.cpp:158-159
 struct DEmitter { uint32_t type; float radiance[3]; uint32_t shape; int32_t grad_slot; uint32_t pad[2]; };
 struct DTexture { uint32_t w, h, c, filter, wrap; int32_t grad_slot; uint64_t data_offset; uint64_t grad_offset; float to_uv[6]; };
 
@@ -90,6 +98,9 @@ struct DScene {
     const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
     const DPrimFin *fins;
     const DBox     *boxes;        // parallelepiped meshes
+    const DSphere  *spheres;
+    uint32_t n_spheres, features; // features: bit 0 = some BSDF is not `diffuse`, bit 1 = analytic spheres present;
+                                  // any bit set -> the kernels are instantiated with FULL = true
     const uint32_t *bvh_shapes;   // shapes traversed through their BVH
     uint32_t n_prims, n_bvh_shapes, n_boxes;
     const DBsdf    *bsdfs;
@@ -353,8 +364,40 @@ MI_DEV bool box_test(const DBox &bx, const Ray &ray, float tlim, float &t) {
     return (b.tnear <= b.tfar) & (t >= 0.f) & (t < tlim);
 }
 
+// math::solve_quadratic, include/mitsuba/core/math.h:360-402
+MI_DEV bool solve_quadratic(float a, float b, float c, float &x0, float &x1) {
+    bool linear_case = a == 0.f, valid_linear = linear_case && b != 0.f;
+    x0 = x1 = -c / b;
+    float discrim = fmaf(b, b, -(4.f * a * c));
+    bool valid_quadratic = !linear_case && discrim >= 0.f;
+    if (valid_quadratic) {
+        float sqrt_discrim = sqrt_(discrim);
+        float temp = -0.5f * (b + copysignf(sqrt_discrim, b));
+        float x0p = div_(temp, a), x1p = div_(c, temp);
+        x0 = fminf(x0p, x1p); x1 = fmaxf(x0p, x1p);
+    }
+    return valid_linear || valid_quadratic;
+}
+// Sphere::ray_intersect_preliminary_impl, src/shapes/sphere.cpp:491-563 (closest) and ray_test_impl :565-601 (any)
+MI_DEV bool sphere_intersect(const DSphere &sp, const Ray &ray, float tlim, float &t) {
+    v3 center = ld3(sp.center);
+    v3 l = ray.o - center, d = ray.d;
+    float plane_t = div_(dot3(-l, d), norm3(d));
+    bool no_hit = plane_t == 0.f && (ray.o.x != center.x && ray.o.y != center.y && ray.o.z != center.z);
+    v3 o = ray_at(ray, plane_t) - center;
+    no_hit = no_hit && (norm3(o) > sp.radius);
+    float A = sqnorm3(d), B = 2.f * dot3(o, d), C = sqnorm3(o) - sp.radius * sp.radius;
+    float near_t, far_t; bool found = solve_quadratic(A, B, C, near_t, far_t);
+    near_t += plane_t; far_t += plane_t;
+    bool out_bounds = !(near_t < tlim && far_t >= 0.f), in_bounds = near_t < 0.f && !(far_t < tlim);
+    t = near_t < 0.f ? far_t : near_t;
+    return found && !no_hit && !out_bounds && !in_bounds;
+}
+
 #define MI_BOX_FLAG 0x40000000u
+#define MI_SPHERE_FLAG 0x20000000u
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
+template <bool FULL>
 MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
     Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
@@ -371,10 +414,17 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
         bool h = box_test(sc.boxes[k], ray, tlim, t);
         tlim = h ? t : tlim; best = h ? (MI_BOX_FLAG | k) : best;
     }
+    if (FULL) for (uint32_t k = 0; k < sc.n_spheres; ++k) {
+        float t;
+        bool h = sphere_intersect(sc.spheres[k], ray, tlim, t) && t < tlim;
+        tlim = h ? t : tlim; best = h ? (MI_SPHERE_FLAG | k) : best;
+    }
     if (best != 0xffffffffu) {                                          // per-lane finalize (divergent gather, once per ray)
         hit.t = tlim; ray.maxt = tlim;
         uint32_t fin = 0xffffffffu; float s = hit.u, u = hit.v;
-        if (best & MI_BOX_FLAG) {
+        if (FULL && (best & MI_SPHERE_FLAG)) {
+            hit.shape = sc.spheres[best & ~MI_SPHERE_FLAG].shape; hit.prim = 0; hit.u = hit.v = 0.f;
+        } else if (best & MI_BOX_FLAG) {
             const DBox &bx = sc.boxes[best & ~MI_BOX_FLAG];
             BoxLocal b = box_local(bx, ray);                           // same arithmetic as in the loop -> same face decision
             bool inside = b.tnear < 0.f;
@@ -411,6 +461,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
     return hit;
 }
 // Scene::ray_test (scene.cpp:201-210): any hit.
+template <bool FULL>
 MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32_t *stk) {
     bool occluded = false;
     if (!__any(active)) return false;                                      // nobody in this wave asked
@@ -425,6 +476,10 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
         float t;
         if (box_test(sc.boxes[k], ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
+    if (FULL) for (uint32_t k = 0; k < sc.n_spheres; ++k) {
+        float t;
+        if (sphere_intersect(sc.spheres[k], ray, tlim, t)) { occluded = true; tlim = 0.f; }
+    }
     if (sc.n_bvh_shapes) {
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
         for (uint32_t i = 0; i < sc.n_bvh_shapes; ++i)
@@ -436,6 +491,7 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
 // PreliminaryIntersection::compute_surface_interaction (interaction.h:642-668) ->
 // Rectangle / Mesh::compute_surface_interaction (rectangle.cpp:497-567 IsDiff branch, mesh.cpp:1375-1548)
 // -> finalize_surface_interaction (interaction.h:464-484).  Caller guarantees hit.t != inf.
+template <bool FULL>
 MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
     SI si; si.t = hit.t; si.shape = (int32_t) hit.shape; si.prim = hit.prim;
     const DShape &sh = sc.shapes[hit.shape];                               // per-lane gather (divergent index)
@@ -444,6 +500,24 @@ MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
         si.p = ray_at(ray, hit.t);
         si.n = ld3(sh.frame_n); si.sh_n = si.n; dp_du = ld3(sh.frame_s); dp_dv = ld3(sh.frame_t);
         si.uv.x = fmaf(hit.u, .5f, .5f); si.uv.y = fmaf(hit.v, .5f, .5f);
+    } else if (FULL && sh.type == MI355_SHAPE_SPHERE) {                   // sphere.cpp:609-712, IsDiff && !FollowShape
+        v3 center = ld3(sh.frame_s);
+        si.p = ray_at(ray, hit.t);
+        si.sh_n = normalize3(si.p - center);
+        v3 local = xf_point(sh.to_object, si.p);
+        float rd_2 = local.x * local.x + local.y * local.y;
+        v3 dz = V3(local.x, local.y, local.z - mulsign(1.f, local.z));      // dr::unit_angle_z: robust acos(z)
+        float temp = 2.f * asinf(.5f * norm3(dz));
+        float theta = local.z >= 0.f ? temp : MI_PI - temp;
+        float phi = atan2f(local.y, local.x); if (phi < 0.f) phi += 2.f * MI_PI;
+        si.uv.x = phi * (0.5f * MI_INV_PI); si.uv.y = theta * MI_INV_PI;
+        dp_du = V3(-local.y, local.x, 0.f);
+        float rd = sqrt_(rd_2), inv_rd = rcp_(rd);
+        dp_dv = V3(local.z * (local.x * inv_rd), local.z * (local.y * inv_rd), -rd);
+        if (rd == 0.f) dp_dv = V3(1.f, 0.f, 0.f);
+        dp_du = xf_vector(sh.to_world, dp_du) * (2.f * MI_PI); dp_dv = xf_vector(sh.to_world, dp_dv) * MI_PI;
+        if (sh.flags & DSHAPE_FLIP) si.sh_n = -si.sh_n;
+        si.n = si.sh_n;
     } else {
         const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + hit.prim);
         uint32_t i0 = sh.vtx_offset + fi[0], i1 = sh.vtx_offset + fi[1], i2 = sh.vtx_offset + fi[2];
@@ -546,11 +620,189 @@ MI_DEV void diffuse_sample(v3 refl, v3 wi, float s2x, float s2y, bool active, v3
     weight = (active && pdf > 0.f) ? refl : V3(0.f, 0.f, 0.f);
 }
 
+// -------------------------------------------------------------------------------------------
+// microfacet distribution (include/mitsuba/render/microfacet.h), Fresnel (fresnel.h), rough conductor, smooth dielectric
+// -------------------------------------------------------------------------------------------
+MI_DEV float erfinv_(float x) {                                            // Giles 2010, single precision
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f); p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f); p = fmaf(p, w, -0.00417768164f); p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f); p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f); p = fmaf(p, w, 0.00943887047f); p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+struct MF { uint32_t type; float au, av; bool sample_visible; };
+MI_DEV MF mf_make(const DBsdf &b) { MF m; m.type = b.distribution; m.au = fmaxf(b.alpha_u, 1e-4f); m.av = fmaxf(b.alpha_v, 1e-4f); m.sample_visible = b.sample_visible != 0; return m; }
+MI_DEV float sqr_(float x) { return x * x; }
+MI_DEV float safe_sqrt_(float x) { return sqrtf(fmaxf(x, 0.f)); }
+MI_DEV float mf_eval(const MF &d, v3 m) {                                  // microfacet.h:185-207
+    float alpha_uv = d.au * d.av, ct = m.z, ct2 = ct * ct, result;
+    if (d.type == 0) result = expf(-(sqr_(m.x / d.au) + sqr_(m.y / d.av)) / ct2) / (MI_PI * alpha_uv * sqr_(ct2));
+    else result = 1.0f / (MI_PI * alpha_uv * sqr_(sqr_(m.x / d.au) + sqr_(m.y / d.av) + sqr_(m.z)));
+    return result * ct > 1e-20f ? result : 0.f;
+}
+MI_DEV float mf_smith_g1(const MF &d, v3 v, v3 m) {                        // microfacet.h:341-365
+    float xy_alpha_2 = sqr_(d.au * v.x) + sqr_(d.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr_(v.z), result;
+    if (d.type == 0) {
+        float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = a * a;
+        result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot3(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+MI_DEV float mf_pdf(const MF &d, v3 wi, v3 m) {                            // microfacet.h:219-228
+    float result = mf_eval(d, m);
+    if (d.sample_visible) result *= mf_smith_g1(d, wi, m) * fabsf(dot3(wi, m)) / wi.z; else result *= m.z;
+    return result;
+}
+MI_DEV void disk_concentric(float sx, float sy, float &px, float &py) {     // warp.h:54-90
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    bool is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * MI_PI * rp / r;
+    if (q13) phi = 0.5f * MI_PI - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; sincosf(phi, &sn, &cs); px = r * cs; py = r * sn;
+}
+MI_DEV void mf_sample_visible_11(const MF &d, float cos_theta_i, float sx, float sy, float &ox, float &oy) {   // microfacet.h:368-421
+    if (d.type == 0) {
+        float tan_theta_i = safe_sqrt_(fmaf(-cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = 1.0f / tan_theta_i;
+        float maxval = erff(cot_theta_i);
+        sx = fmaxf(fminf(sx, 1.f - 1e-6f), 1e-6f); sy = fmaxf(fminf(sy, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * erff(sqrtf(-logf(sx)));
+        const float inv_sqrt_pi = 0.56418958354775628695f;
+        sx *= 1.f + maxval + inv_sqrt_pi * tan_theta_i * expf(-sqr_(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {
+            float slope = erfinv_(x), value = 1.f + x + inv_sqrt_pi * tan_theta_i * expf(-sqr_(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        ox = erfinv_(x); oy = erfinv_(fmaf(2.f, sy, -1.f));
+    } else {
+        float px, py; disk_concentric(sx, sy, px, py);
+        float sfac = 0.5f * (1.f + cos_theta_i), a = safe_sqrt_(1.f - sqr_(px));
+        py = fmaf(py - a, sfac, a);
+        float z = safe_sqrt_(1.f - fmaf(py, py, px * px));
+        float sin_theta_i = safe_sqrt_(1.f - sqr_(cos_theta_i));
+        float norm = 1.0f / fmaf(sin_theta_i, py, cos_theta_i * z);
+        ox = fmaf(cos_theta_i, py, -(sin_theta_i * z)) * norm; oy = px * norm;
+    }
+}
+MI_DEV v3 mf_sample(const MF &d, v3 wi, float sx, float sy, float &pdf) {   // microfacet.h:244-326
+    if (!d.sample_visible) {
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+        if (d.au == d.av) { sincosf((2.f * MI_PI) * sy, &sin_phi, &cos_phi); alpha_2 = d.au * d.au; }
+        else {
+            float ratio = d.av / d.au, tmp = ratio * tanf((2.f * MI_PI) * sy);
+            cos_phi = 1.0f / sqrtf(fmaf(tmp, tmp, 1.f)); cos_phi = mulsign(cos_phi, fabsf(sy - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = 1.0f / (sqr_(cos_phi / d.au) + sqr_(sin_phi / d.av));
+        }
+        if (d.type == 0) {
+            cos_theta = 1.0f / sqrtf(fmaf(-alpha_2, logf(1.f - sx), 1.f)); cos_theta_2 = cos_theta * cos_theta;
+            float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.f - sx) / (MI_PI * d.au * d.av * cos_theta_3);
+        } else {
+            float tan_theta_m_2 = alpha_2 * sx / (1.f - sx);
+            cos_theta = 1.0f / sqrtf(1.f + tan_theta_m_2); cos_theta_2 = cos_theta * cos_theta;
+            float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = 1.0f / (MI_PI * d.au * d.av * cos_theta_3 * sqr_(temp));
+        }
+        float sin_theta = sqrtf(1.f - cos_theta_2);
+        return V3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    }
+    v3 wi_p = normalize3(V3(d.au * wi.x, d.av * wi.y, wi.z));
+    float st2 = fmaf(wi_p.x, wi_p.x, wi_p.y * wi_p.y), ist = 1.0f / sqrtf(st2);   // Frame3f::sincos_phi, frame.h:111-122
+    float cos_phi = fminf(fmaxf(wi_p.x * ist, -1.f), 1.f), sin_phi = fminf(fmaxf(wi_p.y * ist, -1.f), 1.f);
+    if (fabsf(st2) <= 4.f * MI_EPS) { cos_phi = 1.f; sin_phi = 0.f; }
+    float slx, sly; mf_sample_visible_11(d, wi_p.z, sx, sy, slx, sly);
+    float ax = fmaf(cos_phi, slx, -(sin_phi * sly)) * d.au, ay = fmaf(sin_phi, slx, cos_phi * sly) * d.av;
+    v3 m = normalize3(V3(-ax, -ay, 1.f));
+    pdf = mf_eval(d, m) * mf_smith_g1(d, wi, m) * fabsf(dot3(wi, m)) / wi.z;
+    return m;
+}
+MI_DEV void fresnel_(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {   // fresnel.h:34-72
+    bool outside = cos_theta_i >= 0.f;
+    float rcp_eta = 1.0f / eta; eta_it = outside ? eta : rcp_eta; eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    float cia = fabsf(cos_theta_i), cta = safe_sqrt_(cos_theta_t_sqr);
+    bool index_matched = eta == 1.f, special = index_matched || cia == 0.f;
+    float a_s = fmaf(-eta_it, cta, cia) / fmaf(eta_it, cta, cia), a_p = fmaf(-eta_it, cia, cta) / fmaf(eta_it, cia, cta);
+    r = 0.5f * (a_s * a_s + a_p * a_p);
+    if (special) r = index_matched ? 0.f : 1.f;
+    cos_theta_t = mulsign(-cta, cos_theta_i);
+}
+MI_DEV float fresnel_conductor_(float cos_theta_i, float eta_r, float eta_i) {   // fresnel.h:92-118
+    float ci2 = cos_theta_i * cos_theta_i, si2 = 1.f - ci2, si4 = si2 * si2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - si2, a_2_pb_2 = safe_sqrt_(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a = safe_sqrt_(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + ci2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * ci2 + si4, term_4 = term_2 * si2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+struct BSample { v3 wo; float pdf, eta; bool delta; };
+MI_DEV void roughconductor_eval_pdf(const DBsdf &b, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {   // roughconductor.cpp:428-517
+    val = V3(0.f, 0.f, 0.f); pdf = 0.f;
+    v3 H = normalize3(wo + wi);
+    active = active && wi.z > 0.f && wo.z > 0.f && dot3(wi, H) > 0.f && dot3(wo, H) > 0.f;
+    if (!active) return;
+    MF d = mf_make(b);
+    float D = mf_eval(d, H);
+    if (D == 0.f) return;
+    float g1_wi = mf_smith_g1(d, wi, H), G = g1_wi * mf_smith_g1(d, wo, H);
+    float value = D * G / (4.f * wi.z), ct = dot3(wi, H);
+    v3 F = V3(fresnel_conductor_(ct, b.eta[0], b.k[0]), fresnel_conductor_(ct, b.eta[1], b.k[1]), fresnel_conductor_(ct, b.eta[2], b.k[2]));
+    val = F * (ld3(b.reflectance) * value);
+    pdf = d.sample_visible ? D * g1_wi / (4.f * wi.z) : mf_pdf(d, wi, H) / (4.f * dot3(wo, H));
+}
+MI_DEV void roughconductor_sample(const DBsdf &b, v3 wi, float sx, float sy, bool active, BSample &bs, v3 &weight) {   // roughconductor.cpp:226-312
+    weight = V3(0.f, 0.f, 0.f);
+    active = active && wi.z > 0.f;
+    MF d = mf_make(b);
+    float pdf; v3 m = mf_sample(d, wi, sx, sy, pdf);
+    bs.wo = m * (2.f * dot3(wi, m)) - wi; bs.eta = 1.f; bs.delta = false;
+    active = active && pdf != 0.f && bs.wo.z > 0.f;
+    float w = d.sample_visible ? mf_smith_g1(d, bs.wo, m) : mf_smith_g1(d, wi, m) * mf_smith_g1(d, bs.wo, m) * dot3(wi, m) / (wi.z * m.z);
+    bs.pdf = pdf / (4.f * dot3(bs.wo, m));
+    float ct = dot3(wi, m);
+    v3 F = V3(fresnel_conductor_(ct, b.eta[0], b.k[0]), fresnel_conductor_(ct, b.eta[1], b.k[1]), fresnel_conductor_(ct, b.eta[2], b.k[2]));
+    if (active) weight = F * (ld3(b.reflectance) * w);
+}
+MI_DEV void dielectric_sample(const DBsdf &b, v3 wi, float s1, bool active, BSample &bs, v3 &weight) {   // dielectric.cpp:246-371
+    float r_i, cos_theta_t, eta_it, eta_ti; fresnel_(wi.z, b.rel_eta, r_i, cos_theta_t, eta_it, eta_ti);
+    bool selected_r = s1 <= r_i && active;
+    bs.pdf = selected_r ? r_i : 1.f - r_i;
+    bs.wo = selected_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);
+    bs.eta = selected_r ? 1.f : eta_it; bs.delta = true;
+    v3 w = selected_r ? ld3(b.reflectance) : ld3(b.transmittance) * (eta_ti * eta_ti);
+    weight = active ? w : V3(0.f, 0.f, 0.f);
+}
+template <bool FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
+    if (!FULL || b.type == MI355_BSDF_DIFFUSE) diffuse_eval_pdf(refl, wi, wo, active, val, pdf);
+    else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
+    else { val = V3(0.f, 0.f, 0.f); pdf = 0.f; }
+}
+template <bool FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, float s1, float s2x, float s2y, bool active, BSample &bs, v3 &weight) {
+    if (!FULL || b.type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2x, s2y, active, bs.wo, bs.pdf, weight); bs.eta = 1.f; bs.delta = false; }
+    else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2x, s2y, active, bs, weight);
+    else dielectric_sample(b, wi, s1, active, bs, weight);
+}
+
 struct DS { v3 p, n; float pdf; v3 d; float dist; int32_t emitter; };     // DirectionSample, records.h:93-195
 
 // Scene::sample_emitter_direction (scene.cpp:299-353) -> AreaLight::sample_direction (area.cpp:117-168)
 // -> Shape::sample_direction (shape.cpp:358-375) -> Rectangle::sample_position (rectangle.cpp:166-180).
 // The shadow ray is returned to the caller so that fused and wavefront modes can trace it their own way.
+template <bool FULL>
 MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, float sy, bool active, DS &ds, v3 &spec, Ray &shadow) {
     ds.p = ds.n = ds.d = V3(0.f, 0.f, 0.f); ds.pdf = 0.f; ds.dist = 0.f; ds.emitter = -1; spec = V3(0.f, 0.f, 0.f);
     if (sc.n_emitters == 0) return false;
@@ -563,15 +815,44 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     const DEmitter &em = sc.emitters[index];
     const DShape &sh = sc.shapes[em.shape];
     ds.emitter = (int32_t) index;
-    if (sh.type != MI355_SHAPE_RECTANGLE) return false;
-    ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
-    ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
-    ds.d = ds.p - si.p;
-    float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2);
-    ds.d = ds.d * rcp_(ds.dist);
-    float dp = fabsf(dot3(ds.d, ds.n));
-    float x = div_(dist2, dp);
-    ds.pdf *= isfinite(x) ? x : 0.f;
+    if (sh.type == MI355_SHAPE_RECTANGLE) {
+        ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
+        ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
+        ds.d = ds.p - si.p;
+        float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2);
+        ds.d = ds.d * rcp_(ds.dist);
+        float dp = fabsf(dot3(ds.d, ds.n));
+        float x = div_(dist2, dp);
+        ds.pdf *= isfinite(x) ? x : 0.f;
+    } else if (FULL && sh.type == MI355_SHAPE_SPHERE) {                   // Sphere::sample_direction, sphere.cpp:236-311
+        v3 center = ld3(sh.frame_s); float radius = sh.frame_t[0];
+        v3 dc_v = center - si.p; float dc_2 = sqnorm3(dc_v);
+        float radius_adj = radius * ((sh.flags & DSHAPE_FLIP) ? (1.f + MI_RAY_EPS) : (1.f - MI_RAY_EPS));
+        v3 dn;
+        if (dc_2 > radius_adj * radius_adj) {
+            float inv_dc = rsqrt_(dc_2), sin_theta_max = radius * inv_dc, sin_theta_max_2 = sin_theta_max * sin_theta_max,
+                  inv_sin_theta_max = rcp_(sin_theta_max), cos_theta_max = sqrt_(fmaxf(1.f - sin_theta_max_2, 0.f));
+            float t1 = fmaf(cos_theta_max - 1.f, sx, 1.f);
+            float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - t1 * t1 : sin_theta_max_2 * sx,
+                  cos_theta = sqrt_(fmaxf(1.f - sin_theta_2, 0.f));
+            float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * sqrt_(fmaxf(fmaf(-sin_theta_2, inv_sin_theta_max * inv_sin_theta_max, 1.f), 0.f)),
+                  sin_alpha = sqrt_(fmaxf(fmaf(-cos_alpha, cos_alpha, 1.f), 0.f));
+            float sin_phi, cos_phi; sincos_(sy * (2.f * MI_PI), sin_phi, cos_phi);
+            v3 fn = dc_v * (-inv_dc), fs, ft; coordinate_system(fn, fs, ft);
+            dn = fma3s(fn, cos_alpha, fma3s(ft, sin_phi * sin_alpha, fs * (cos_phi * sin_alpha)));
+            ds.p = fma3s(dn, radius, center); ds.n = dn; ds.d = ds.p - si.p;
+            float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2); ds.d = ds.d * rcp_(ds.dist);
+            ds.pdf = div_(0.5f * MI_INV_PI, 1.f - cos_theta_max);
+            if (ds.dist == 0.f) ds.pdf = 0.f;
+        } else {
+            float z = fmaf(-2.f, sy, 1.f), r = sqrt_(fmaxf(fmaf(-z, z, 1.f), 0.f)), sn, cs; sincos_(2.f * MI_PI * sx, sn, cs);
+            dn = V3(r * cs, r * sn, z);
+            ds.p = fma3s(dn, radius, center); ds.n = dn; ds.d = ds.p - si.p;
+            float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2); ds.d = ds.d * rcp_(ds.dist);
+            ds.pdf = div_(sh.inv_area * dist2, fabsf(dot3(ds.d, ds.n)));
+        }
+        if (sh.flags & DSHAPE_FLIP) ds.n = -ds.n;
+    } else return false;
     active = active && dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;            // area.cpp:136
     spec = active ? ld3(em.radiance) * rcp_(ds.pdf) : V3(0.f, 0.f, 0.f);
     if (sc.n_emitters > 1) { ds.pdf *= sc.inv_emitter_count; spec = spec * emitter_weight; }
@@ -580,12 +861,16 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     return active;                                                         // true: a shadow ray must be tested
 }
 // Scene::pdf_emitter_direction (scene.cpp:355-366) -> area.cpp:170-197 -> shape.cpp:377-388
-MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 d, v3 n, float dist) {
+template <bool FULL>
+MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 ref_p, v3 d, v3 n, float dist) {
     const DShape &sh = sc.shapes[sc.emitters[emitter].shape];
     float dp = dot3(d, n);
     if (!(dp < 0.f)) return 0.f;
-    float adp = fabsf(dp);
-    float pdf = sh.inv_area * (adp != 0.f ? div_(dist * dist, adp) : 0.f);
+    float adp = fabsf(dp), pdf;
+    if (FULL && sh.type == MI355_SHAPE_SPHERE) {                           // Sphere::pdf_direction, sphere.cpp:313-325
+        float sin_alpha = sh.frame_t[0] * rcp_(norm3(ld3(sh.frame_s) - ref_p)), cos_alpha = sqrt_(fmaxf(1.f - sin_alpha * sin_alpha, 0.f));
+        pdf = sin_alpha < 0.99999994f ? div_(0.5f * MI_INV_PI, 1.f - cos_alpha) : div_(sh.inv_area * (dist * dist), adp);
+    } else pdf = sh.inv_area * (adp != 0.f ? div_(dist * dist, adp) : 0.f);
     return pdf * sc.inv_emitter_count;
 }
 
@@ -618,18 +903,19 @@ struct Counters3 { uint32_t isect, shade, shadow; };
 // Loop-carried state of PathIntegrator::sample (path.cpp:108-121).  For the lanes that are still alive the loop counter
 // IS the path depth (depth is only incremented on valid hits, path.cpp:266, and an invalid hit ends the path), and
 // prev_bsdf_delta is true exactly at the first vertex -- so neither needs a register.  eta stays 1 (no refraction yet).
-struct PathState { Ray ray; v3 throughput, result, prev_p; float prev_bsdf_pdf; Pcg32 rng; };
+// With FULL = true (scenes with glossy / specular BSDFs) eta and prev_bsdf_delta become real state.
+struct PathState { Ray ray; v3 throughput, result, prev_p; float prev_bsdf_pdf; Pcg32 rng; float eta; bool prev_delta; };
 
 MI_DEV void path_init(PathState &st, const Ray &ray, const Pcg32 &rng) {
     st.ray = ray; st.throughput = V3(1.f, 1.f, 1.f); st.result = V3(0.f, 0.f, 0.f); st.prev_p = V3(0.f, 0.f, 0.f);
-    st.prev_bsdf_pdf = 1.f; st.rng = rng;
+    st.prev_bsdf_pdf = 1.f; st.rng = rng; st.eta = 1.f; st.prev_delta = true;
 }
 // One iteration of the loop of path.cpp:142-281 at depth `it`.  Returns whether the lane continues; `hit_any` reports
 // a valid surface hit (feeds valid_ray, path.cpp:256).
+template <bool FULL>
 MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
                       bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
-    const float eta = 1.f;
-    Hit hit = scene_intersect(sc, st.ray, active, stk);
+    Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
     if (active) cnt.isect++;
     bool si_valid = active && hit.t != MI_INF;
     bool active_next = si_valid && (it + 1 < max_depth);                    // path.cpp:177
@@ -637,12 +923,13 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     hit_any = si_valid;
     if (si_valid) {
         cnt.shade++;
-        SI si = compute_si(sc, st.ray, hit);
+        SI si = compute_si<FULL>(sc, st.ray, hit);
         const DShape &sh = sc.shapes[hit.shape];
         int32_t emitter = sh.emitter;
         if (emitter >= 0) {                                                // path.cpp:158-174
             v3 rel = si.p - st.prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);   // records.h:173-180
-            float em_pdf = it == 0 ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            bool prev_delta = FULL ? st.prev_delta : (it == 0);
+            float em_pdf = prev_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, st.prev_p, d, si.sh_n, dist);
             float mis_bsdf = mis_weight(st.prev_bsdf_pdf, em_pdf);
             v3 le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
             st.result = fma3(st.throughput, le * mis_bsdf, st.result);
@@ -655,20 +942,24 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             // ---- emitter sampling (path.cpp:186-208)
             float ex = next_1d(st.rng), ey = next_1d(st.rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool need_shadow = sample_emitter_direction(sc, si, ex, ey, active_next, ds, em_weight, shadow);
+            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;        // BSDFFlags::Smooth, path.cpp:187
+            bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             // ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33)
-            float s1 = next_1d(st.rng); (void) s1; float s2x = next_1d(st.rng), s2y = next_1d(st.rng);
+            float s1 = next_1d(st.rng), s2x = next_1d(st.rng), s2y = next_1d(st.rng);
             v3 wo = si_to_local(si, ds.d);
-            v3 bsdf_val; float bsdf_pdf; diffuse_eval_pdf(refl, si.wi, wo, true, bsdf_val, bsdf_pdf);
-            v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2x, s2y, true, bs_wo, bs_pdf, bsdf_weight);
+            v3 bsdf_val; float bsdf_pdf; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, true, bsdf_val, bsdf_pdf);
+            BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bsm, bsdf_weight);
+            v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
             v3 contrib = (bsdf_val * em_weight) * mis_weight(ds.pdf, bsdf_pdf);
-            bool occluded = scene_ray_test(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
+            bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
             if (need_shadow) cnt.shadow++;
             if (need_shadow && !occluded) st.result = fma3(st.throughput, contrib, st.result);   // path.cpp:220-230
             // ---- BSDF sampling + loop update (path.cpp:234-280)
             st.ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
             st.throughput = st.throughput * bsdf_weight;
             st.prev_p = si.p; st.prev_bsdf_pdf = bs_pdf;
+            if (FULL) { st.eta *= bsm.eta; st.prev_delta = bsm.delta; }
+            const float eta = FULL ? st.eta : 1.f;
             float tmax = max3(st.throughput);
             float rr_prob = fminf(tmax * (eta * eta), .95f);
             bool rr_active = it + 1 >= rr_depth, rr_continue = next_1d(st.rng) < rr_prob;
@@ -678,13 +969,14 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     }
     return alive;
 }
+template <bool FULL>
 MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
                         bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt) {
     PathState st; path_init(st, ray, rng);
     bool valid_ray = false;                                                // no environment emitter, path.cpp:115
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
         bool hit_any;
-        active = path_step(sc, st, it, max_depth, rr_depth, active, stk, hit_any, cnt);
+        active = path_step<FULL>(sc, st, it, max_depth, rr_depth, active, stk, hit_any, cnt);
         valid_ray = valid_ray || hit_any;
     }
     rng = st.rng;
@@ -706,27 +998,27 @@ MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_dept
 // dLoss/d(albedo rgb); the other two taps and the 12 (tap, channel) atomics are expanded at flush time.
 struct GradSink { float *s_grad; float *g_grad; float *q; uint32_t *qn; uint32_t qcap; };
 
-template <bool BACKWARD>
+template <bool BACKWARD, bool FULL>
 MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                        bool active, uint32_t *stk, v3 dL, v3 state_in, GradSink sink,
                        v3 &L_out, bool &valid_out, Counters3 &cnt) {
     uint32_t depth = 0; v3 L = BACKWARD ? state_in : V3(0.f, 0.f, 0.f); v3 beta = V3(1.f, 1.f, 1.f); float eta = 1.f;
     v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
-        Hit hit = scene_intersect(sc, ray, active, stk);
+        Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
         if (active) cnt.isect++;
         bool si_valid = active && hit.t != MI_INF;
         bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
         active = false;
         if (si_valid) {
             cnt.shade++;
-            SI si = compute_si(sc, ray, hit);
+            SI si = compute_si<FULL>(sc, ray, hit);
             const DShape &sh = sc.shapes[hit.shape];
             int32_t emitter = sh.emitter;
             v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
             if (emitter >= 0) {                                            // prb.py:126-134
                 v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
-                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, prev_p, d, si.sh_n, dist);
                 le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
                 le_front = si.wi.z > 0.f;
                 v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
@@ -751,24 +1043,28 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             // ---- emitter sampling (prb.py:142-162)
             float ex = next_1d(rng), ey = next_1d(rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool need_shadow = sample_emitter_direction(sc, si, ex, ey, active_next, ds, em_weight, shadow);
-            bool occluded = scene_ray_test(sc, shadow, need_shadow, stk);
+            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+            bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
+            bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
             if (need_shadow) cnt.shadow++;
             bool active_em = need_shadow && !occluded;
             if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
             v3 wo = si_to_local(si, ds.d);
-            v3 bsdf_value_em; float bsdf_pdf_em; diffuse_eval_pdf(refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+            v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+            const bool is_diffuse = !FULL || bsdf.type == MI355_BSDF_DIFFUSE;
             float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
             v3 Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
             // ---- detached BSDF sampling (prb.py:166-169)
-            float s1 = next_1d(rng); (void) s1; float s2x = next_1d(rng), s2y = next_1d(rng);
-            v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2x, s2y, active_next, bs_wo, bs_pdf, bsdf_weight);
+            float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
+            BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, active_next, bsm, bsdf_weight);
+            v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
             // ---- update (prb.py:173-182)
             v3 beta_pre = beta;
             L = BACKWARD ? (L - Le) - Lr_dir : (L + Le) + Lr_dir;
             ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
             beta = beta * bsdf_weight;
-            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
+            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = FULL ? bsm.delta : false;
+            if (FULL) eta *= bsm.eta;
             // ---- stopping criterion (prb.py:186-198)
             float bmax = max3(beta);
             active_next = active_next && bmax != 0.f;
@@ -778,16 +1074,16 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             bool rr_continue = next_1d(rng) < rr_prob;
             active_next = active_next && (!rr_active || rr_continue);
             if (BACKWARD) {                                                // prb.py:202-247
-                float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f;
+                float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f && is_diffuse;
                 v3 det = bsdf_weight * bs_pdf;
                 v3 inv = V3(det.x != 0.f ? rcp_(det.x) : 0.f, det.y != 0.f ? rcp_(det.y) : 0.f, det.z != 0.f ? rcp_(det.z) : 0.f);
                 float dval = ev_active ? MI_INV_PI * co : 0.f;
                 v3 dLo = (L * inv) * dval;                                 // d Lr_ind / d albedo
-                bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f;
+                bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f && is_diffuse;
                 float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
                 dLo = dLo + ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
                 v3 ga = dL * dLo;
-                bool textured = bsdf.texture >= 0 && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0 && sink.g_grad != nullptr;
+                bool textured = is_diffuse && bsdf.texture >= 0 && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0 && sink.g_grad != nullptr;
                 bool queued = textured && sc.textures[bsdf.texture].c == 3 && sink.q != nullptr;
                 {   // wave-aggregated slot allocation: one LDS atomic per wave, one record per textured lane
                     unsigned long long m = __ballot(queued);
@@ -816,7 +1112,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                         else atomicAdd(gb + taps.idx[k], taps.w[k] * (ga.x + ga.y + ga.z));
                     }
                 }
-                if (bsdf.texture >= 0) {
+                if (bsdf.texture >= 0 || !is_diffuse) {
                 } else if (bsdf.grad_slot >= 0) {
                     float *gb = sink.s_grad + bsdf.grad_slot;
                     atomicAdd(gb + 0, ga.x); atomicAdd(gb + 1, ga.y); atomicAdd(gb + 2, ga.z);

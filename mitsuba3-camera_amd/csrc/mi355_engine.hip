@@ -131,8 +131,8 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
     if (threadIdx.x < 3 && g_counters) atomicAdd(&g_counters[1 + threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
 }
 
-template <int INTEGRATOR, int OUT>
-__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
+template <int INTEGRATOR, int OUT, bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];
     __shared__ uint32_t s_cnt[4];
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render(DScene sc, Rende
     Counters3 cnt = { 0, 0, 0 };
     v3 rgb; bool valid;
     if (INTEGRATOR == MI355_INTEGRATOR_PATH)
-        path_sample(sc, rng, ray, a.max_depth, a.rr_depth, li.act, stk, rgb, valid, cnt);
+        path_sample<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, li.act, stk, rgb, valid, cnt);
     else {
         GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 };
-        prb_sample<false>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, li.act, stk,
+        prb_sample<false, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, li.act, stk,
                           V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, rgb, valid, cnt);
     }
     __syncthreads();                                                        // traversal stack region is reused below
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
         bool mine = tid < n_alive, alive = false;
         if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
             bool hit_any;
-            alive = path_step(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            alive = path_step<false>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
             valid_ray = valid_ray || hit_any;
         }
         if (mine && !alive) {                                               // path over: park its radiance in its original slot
@@ -273,7 +273,8 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
     gw[i] = make_float4(grad_in[3 * i] * inv, grad_in[3 * i + 1] * inv, grad_in[3 * i + 2] * inv, 0.f);
 }
 
-__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES_BWD) void k_prb_backward(DScene
     GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE };
     Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
     v3 L, L2; bool valid;
-    prb_sample<false>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, li.act, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
-    prb_sample<true>(sc, rng, ray, a.max_depth, a.rr_depth, hide, li.act, stk, dL, L, sink, L2, valid, cnt);
+    prb_sample<false, FULL>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, li.act, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
+    prb_sample<true, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, li.act, stk, dL, L, sink, L2, valid, cnt);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
     // flush the texture-gradient queue: 12 consecutive lanes expand one record into its (tap, channel) atomics, so the
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(BLOCK) void k_debug_intersect(DScene sc, const floa
     uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x; bool act = i < n; uint32_t ii = act ? i : 0;
     Ray r; r.o = ld3(rays + 8 * (size_t) ii); r.d = ld3(rays + 8 * (size_t) ii + 3); r.maxt = rays[8 * (size_t) ii + 6];
-    Hit h = scene_intersect(sc, r, act, stk);
-    bool occ = scene_ray_test(sc, r, act, stk);
+    Hit h = scene_intersect<true>(sc, r, act, stk);
+    bool occ = scene_ray_test<true>(sc, r, act, stk);
     if (act) {
         float *o = hits + 8 * (size_t) i;
         o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = __uint_as_float(h.prim); o[4] = __uint_as_float(h.shape);
@@ -448,14 +449,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
@@ -664,6 +665,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if (se.type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build");
     if (!se.crop_width || !se.crop_height || !se.film_width || !se.film_height) return fail(MI355_ERR_INVALID, "empty film");
     DScene &ds = s->ds; memset(&ds, 0, sizeof(ds));
+    s->spheres.clear();
     // textures
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const mi355_texture_desc &t = d->textures[i];
@@ -676,16 +678,23 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     }
     for (uint32_t i = 0; i < d->n_bsdfs; ++i) {
         const mi355_bsdf_desc &b = d->bsdfs[i];
-        if (b.type != MI355_BSDF_DIFFUSE) return fail(MI355_ERR_UNSUPPORTED, "bsdf type not supported by this build (diffuse only)");
+        if (b.type != MI355_BSDF_DIFFUSE && b.type != MI355_BSDF_ROUGHCONDUCTOR && b.type != MI355_BSDF_DIELECTRIC)
+            return fail(MI355_ERR_UNSUPPORTED, "bsdf type not supported by this build (diffuse, roughconductor, dielectric)");
         if (b.reflectance_texture >= (int32_t) d->n_textures) return fail(MI355_ERR_INVALID, "bsdf references a missing texture");
+        if (b.type != MI355_BSDF_DIFFUSE && b.reflectance_texture >= 0) return fail(MI355_ERR_UNSUPPORTED, "textured specular reflectance is not supported");
+        if (b.type == MI355_BSDF_DIELECTRIC && !(b.int_ior > 0.f && b.ext_ior > 0.f)) return fail(MI355_ERR_INVALID, "indices of refraction must be positive");
         DBsdf o; memset(&o, 0, sizeof(o)); o.type = b.type; memcpy(o.reflectance, b.reflectance, 12); o.texture = b.reflectance_texture; o.grad_slot = -1;
+        o.alpha_u = b.alpha_u; o.alpha_v = b.alpha_v; o.distribution = b.distribution; o.sample_visible = b.sample_visible;
+        memcpy(o.eta, b.eta, 12); memcpy(o.k, b.k, 12); memcpy(o.transmittance, b.transmittance, 12);
+        o.rel_eta = b.type == MI355_BSDF_DIELECTRIC ? b.int_ior / b.ext_ior : 1.f;
+        if (b.type != MI355_BSDF_DIFFUSE) ds.features |= 1u;
         s->bsdfs.push_back(o);
     }
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         const mi355_emitter_desc &e = d->emitters[i];
         if (e.type != MI355_EMITTER_AREA) return fail(MI355_ERR_UNSUPPORTED, "emitter type not supported (area only)");
         if (e.shape >= d->n_shapes) return fail(MI355_ERR_INVALID, "emitter references a missing shape");
-        if (d->shapes[e.shape].type != MI355_SHAPE_RECTANGLE) return fail(MI355_ERR_UNSUPPORTED, "area emitters must sit on rectangles in this build");
+        if (d->shapes[e.shape].type == MI355_SHAPE_MESH) return fail(MI355_ERR_UNSUPPORTED, "area emitters must sit on rectangles or spheres in this build");
         DEmitter o; memset(&o, 0, sizeof(o)); o.type = e.type; memcpy(o.radiance, e.radiance, 12); o.shape = e.shape; o.grad_slot = -1;
         s->emitters.push_back(o);
     }
@@ -749,12 +758,20 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
                 DTri t; for (int q = 0; q < 3; ++q) { t.p0[q] = a[q]; t.e1[q] = b[q] - a[q]; t.e2[q] = c[q] - a[q]; }
                 s->tris.push_back(t); s->tri_face.push_back(f);
             }
-        } else return fail(MI355_ERR_UNSUPPORTED, "shape type not supported by this build (rectangle, mesh)");
+        } else if (sd.type == MI355_SHAPE_SPHERE) {                         // Sphere::update, sphere.cpp:150-172
+            h3 c = H3(o.to_world[3], o.to_world[7], o.to_world[11]);
+            h3 ex = hxf_vector(o.to_world, H3(1.f, 0.f, 0.f)); float radius = sqrtf(hdot(ex, ex));
+            if (!(radius > 0.f)) return fail(MI355_ERR_INVALID, "sphere radius must be positive");
+            o.frame_s[0] = c.x; o.frame_s[1] = c.y; o.frame_s[2] = c.z; o.frame_t[0] = radius;   // DShape: frame_s = centre, frame_t[0] = radius
+            o.inv_area = 1.0f / (4.f * MI_PI * (radius * radius));
+            DSphere sp; memset(&sp, 0, sizeof(sp)); sp.center[0] = c.x; sp.center[1] = c.y; sp.center[2] = c.z; sp.radius = radius; sp.shape = i;
+            s->spheres.push_back(sp); ds.features |= 2u;
+        } else return fail(MI355_ERR_UNSUPPORTED, "shape type not supported by this build (rectangle, mesh, sphere)");
         s->shapes.push_back(o);
     }
     // gradient layout: constant reflectances, textures, emitter radiances (mi355_scene_param_layout)
     uint64_t off = 0;
-    for (uint32_t i = 0; i < s->bsdfs.size(); ++i) if (s->bsdfs[i].texture < 0) {
+    for (uint32_t i = 0; i < s->bsdfs.size(); ++i) if (s->bsdfs[i].texture < 0 && s->bsdfs[i].type == MI355_BSDF_DIFFUSE) {
         mi355_param_info pi = { MI355_PARAM_BSDF_REFLECTANCE, i, off, 3 }; s->layout.push_back(pi);
         s->bsdfs[i].grad_slot = (int32_t) s->small_map.size();
         for (int k = 0; k < 3; ++k) s->small_map.push_back((uint32_t) (off + k));
@@ -805,6 +822,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_prims, s->prims))) return rc;
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
+    if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
@@ -816,6 +834,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
     ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes; ds.boxes = s->d_boxes; ds.n_boxes = (uint32_t) s->boxes.size();
+    ds.spheres = s->d_spheres; ds.n_spheres = (uint32_t) s->spheres.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
     return MI355_OK;
@@ -838,7 +857,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -939,12 +958,17 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
-    if (p->integrator == MI355_INTEGRATOR_PRB)
-        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
-    else if (p->mode == MI355_MODE_WAVEFRONT)
+    const bool full = (s->ds.features != 0u) != 0;
+    if (p->mode == MI355_MODE_WAVEFRONT && full)
+        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for all-diffuse scenes only");
+    float *nof = nullptr;
+    if (p->integrator == MI355_INTEGRATOR_PRB) {
+        if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+        else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+    } else if (p->mode == MI355_MODE_WAVEFRONT)
         hipLaunchKernelGGL(k_render_compact, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
-    else
-        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM>), grid, block, 0, st, s->ds, a, d_film_rgbw, (float *) nullptr, s->d_counters);
+    else if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+    else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
     s->n_gen += a.n_local; s->n_splat += a.n_local;
@@ -986,8 +1010,12 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
     if ((rc = tm.begin())) return rc;
     uint32_t npix = s->ds.crop_w * s->ds.crop_h;
     hipLaunchKernelGGL(k_prepare_grad, dim3((npix + 255) / 256), dim3(256), 0, st, d_grad_in, d_weight, s->d_gw, npix);
-    hipLaunchKernelGGL(k_prb_backward, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
-                       d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
+    if (s->ds.features != 0u)
+        hipLaunchKernelGGL(k_prb_backward<true>, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
+                           d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
+    else
+        hipLaunchKernelGGL(k_prb_backward<false>, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
+                           d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
     s->n_gen += a.n_local;
@@ -1007,7 +1035,8 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
 extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
     if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
     out[0] = (uint32_t) s->prims.size(); out[1] = (uint32_t) s->boxes.size(); out[2] = (uint32_t) s->bvh_shapes.size();
-    out[3] = (uint32_t) s->bvh.size(); out[4] = (uint32_t) s->tris.size(); out[5] = (uint32_t) s->grad_total; out[6] = out[7] = 0;
+    out[3] = (uint32_t) s->bvh.size(); out[4] = (uint32_t) s->tris.size(); out[5] = (uint32_t) s->grad_total;
+    out[6] = (uint32_t) s->spheres.size(); out[7] = s->ds.features;
     return MI355_OK;
 }
 extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_params *p, uint32_t lane_begin, uint32_t count, float *d_out, void *stream) {
@@ -1019,10 +1048,14 @@ extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_para
     if (!count) return MI355_OK;
     a.n_local = count; a.lane_begin = lane_begin; a.seg = 0;
     dim3 grid((count + BLOCK - 1) / BLOCK), block(BLOCK); hipStream_t st = (hipStream_t) stream;
-    if (p->integrator == MI355_INTEGRATOR_PRB)
-        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_LANES>), grid, block, 0, st, s->ds, a, (float *) nullptr, d_out, (unsigned long long *) nullptr);
-    else
-        hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_LANES>), grid, block, 0, st, s->ds, a, (float *) nullptr, d_out, (unsigned long long *) nullptr);
+    float *nof = nullptr; unsigned long long *noc = nullptr; const bool full = (s->ds.features != 0u) != 0;
+    if (p->integrator == MI355_INTEGRATOR_PRB) {
+        if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_LANES, true>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
+        else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_LANES, false>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
+    } else {
+        if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_LANES, true>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
+        else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_LANES, false>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
+    }
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

@@ -88,12 +88,38 @@ class Texture:
         self.id = id
 
 
+_IOR = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
+        "acetone": 1.36, "ethanol": 1.361, "carbon tetrachloride": 1.461, "glycerol": 1.4729, "benzene": 1.501,
+        "silicone oil": 1.52045, "bromine": 1.661, "water ice": 1.31, "fused quartz": 1.458, "pyrex": 1.470,
+        "acrylic glass": 1.49, "polypropylene": 1.49, "bk7": 1.5046, "sodium chloride": 1.544, "amber": 1.55, "pet": 1.5750,
+        "diamond": 2.419}      # include/mitsuba/render/ior.h:21-47
+
+
+def lookup_ior(props, name, default):
+    v = props.get(name, default)
+    if isinstance(v, str):
+        if v.lower() not in _IOR:
+            raise PluginError('Unable to find an IOR value for "%s"!' % v.lower())
+        return float(_IOR[v.lower()])
+    return float(v)
+
+
 class BSDF:
-    def __init__(self, id, reflectance=(0.5, 0.5, 0.5), texture=None):
+    def __init__(self, id, reflectance=(0.5, 0.5, 0.5), texture=None, type=abi.BSDF_DIFFUSE):
         self.id = id
-        self.type = abi.BSDF_DIFFUSE
+        self.type = type
         self.reflectance = np.asarray(reflectance, dtype=np.float32).reshape(3).copy()
         self.texture = texture      # Texture or None
+        # roughconductor (roughconductor.cpp:163-212) / dielectric (dielectric.cpp:208-236)
+        self.alpha_u = self.alpha_v = 0.1
+        self.distribution = 0       # 0 beckmann, 1 ggx
+        self.sample_visible = True
+        self.eta = np.zeros(3, dtype=np.float32); self.k = np.ones(3, dtype=np.float32)
+        self.int_ior, self.ext_ior = 1.5046, 1.000277
+        self.transmittance = np.ones(3, dtype=np.float32)
+
+    def flags_smooth(self):
+        return self.type != abi.BSDF_DIELECTRIC
 
 
 class Emitter:
@@ -114,18 +140,23 @@ class Shape:
         self.vertex_positions = self.vertex_normals = self.vertex_texcoords = self.faces = None
 
     def primitive_count(self):
-        return 1 if self.type == abi.SHAPE_RECTANGLE else int(self.faces.shape[0])
+        return 1 if self.type != abi.SHAPE_MESH else int(self.faces.shape[0])
 
     def surface_area(self):
         if self.type == abi.SHAPE_RECTANGLE:      # rectangle.cpp:158-160
             s = self.to_world.transform_vector([2, 0, 0]); t = self.to_world.transform_vector([0, 2, 0])
             return float(np.linalg.norm(np.cross(s, t)))
+        if self.type == abi.SHAPE_SPHERE:         # sphere.cpp:197-199
+            return float(4 * math.pi * np.linalg.norm(self.to_world.transform_vector([1, 0, 0])) ** 2)
         p = self.vertex_positions; f = self.faces
         return float(0.5 * np.linalg.norm(np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]]), axis=1).sum())
 
     def bbox(self):
         if self.type == abi.SHAPE_RECTANGLE:      # rectangle.cpp:128-138
             c = np.array([self.to_world.transform_affine(q) for q in ([-1, -1, 0], [-1, 1, 0], [1, -1, 0], [1, 1, 0])])
+        elif self.type == abi.SHAPE_SPHERE:       # sphere.cpp:190-195
+            ce = self.to_world.transform_affine([0, 0, 0]); r = np.linalg.norm(self.to_world.transform_vector([1, 0, 0]))
+            return ce - r, ce + r
         else:
             c = self.vertex_positions
         return c.min(axis=0), c.max(axis=0)
@@ -263,6 +294,11 @@ class Scene:
         for i, b in enumerate(self.bsdfs):
             bs[i].type = b.type; bs[i].reflectance[:] = b.reflectance.tolist()
             bs[i].reflectance_texture = self.textures.index(b.texture) if b.texture is not None else -1
+            bs[i].alpha_u, bs[i].alpha_v, bs[i].distribution = b.alpha_u, b.alpha_v, b.distribution
+            bs[i].sample_visible = 1 if b.sample_visible else 0
+            bs[i].eta[:] = b.eta.tolist(); bs[i].k[:] = b.k.tolist()
+            bs[i].int_ior, bs[i].ext_ior = b.int_ior, b.ext_ior
+            bs[i].transmittance[:] = b.transmittance.tolist()
         em = (abi.EmitterDesc * max(len(self.emitters), 1))()
         for i, e in enumerate(self.emitters):
             em[i].type = e.type; em[i].radiance[:] = e.radiance.tolist(); em[i].shape = self.shapes.index(e.shape)
@@ -317,7 +353,8 @@ class Scene:
         """Geometry organisation of the device replica (mi355_scene_info)."""
         out = (C.c_uint32 * 8)()
         abi.check(abi.lib().mi355_scene_info(self.handle(), out))
-        return {"flat_prims": out[0], "boxes": out[1], "bvh_meshes": out[2], "bvh_nodes": out[3], "triangles": out[4], "grad_floats": out[5]}
+        return {"flat_prims": out[0], "boxes": out[1], "bvh_meshes": out[2], "bvh_nodes": out[3], "triangles": out[4], "grad_floats": out[5],
+                "spheres": out[6], "features": out[7]}
 
     def release(self):
         if self._handle is not None:
@@ -356,8 +393,36 @@ def _rgb(v, what, bounded):
 
 def _make_bsdf(scene, props, id):
     t = props.get("type")
+    if t == "roughconductor":
+        if props.get("material", "none") != "none":
+            raise PluginError("roughconductor: named materials need the reference's IOR data files (absent); give eta / k")
+        b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "roughconductor.specular_reflectance", True), type=abi.BSDF_ROUGHCONDUCTOR)
+        d = str(props.get("distribution", "beckmann")).lower()
+        if d not in ("beckmann", "ggx"):
+            raise PluginError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % d)
+        b.distribution = 0 if d == "beckmann" else 1
+        if "alpha_u" in props or "alpha_v" in props:
+            if not ("alpha_u" in props and "alpha_v" in props):
+                raise PluginError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+            if "alpha" in props:
+                raise PluginError("Microfacet model: please specify either 'alpha' or 'alpha_u'/'alpha_v'.")
+            b.alpha_u, b.alpha_v = float(props["alpha_u"]), float(props["alpha_v"])
+        else:
+            b.alpha_u = b.alpha_v = float(props.get("alpha", 0.1))
+        b.sample_visible = bool(props.get("sample_visible", True))
+        b.eta = _rgb(props.get("eta", 0.0), "roughconductor.eta", False); b.k = _rgb(props.get("k", 1.0), "roughconductor.k", False)
+        scene.bsdfs.append(b)
+        return b
+    if t == "dielectric":
+        b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "dielectric.specular_reflectance", True), type=abi.BSDF_DIELECTRIC)
+        b.transmittance = _rgb(props.get("specular_transmittance", 1.0), "dielectric.specular_transmittance", True)
+        b.int_ior = lookup_ior(props, "int_ior", "bk7"); b.ext_ior = lookup_ior(props, "ext_ior", "air")
+        if b.int_ior < 0 or b.ext_ior < 0:
+            raise PluginError("The interior and exterior indices of refraction must be positive!")
+        scene.bsdfs.append(b)
+        return b
     if t != "diffuse":
-        raise PluginError('bsdf plugin "%s" is outside the path in this build (diffuse)' % t)
+        raise PluginError('bsdf plugin "%s" is outside the path in this build (diffuse, roughconductor, dielectric)' % t)
     refl = props.get("reflectance", 0.5)
     if isinstance(refl, dict) and refl.get("type") == "bitmap":
         if "data" not in refl:
@@ -395,13 +460,13 @@ def load_dict(d):
             scene.integrator_props = dict(v)
         elif vt in ("perspective",):
             scene.sensor = Sensor(v)
-        elif vt in ("diffuse",):
+        elif vt in ("diffuse", "roughconductor", "dielectric"):
             named[key] = _make_bsdf(scene, v, key)
-        elif vt in ("rectangle", "cube", "obj", "mesh"):
+        elif vt in ("rectangle", "cube", "obj", "mesh", "sphere"):
             pending_shapes.append((key, v))
         elif vt in ("thinlens", "orthographic", "realisticlens", "radialwarp", "volpath", "direct", "ptracer", "aov",
-                    "sphere", "disk", "cylinder", "ply", "serialized", "constant", "point", "envmap", "directional",
-                    "roughconductor", "dielectric", "conductor", "plastic", "twosided"):
+                    "disk", "cylinder", "ply", "serialized", "constant", "point", "envmap", "directional",
+                    "conductor", "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)
         else:
             raise PluginError('Plugin "%s" not found!' % vt)
@@ -422,7 +487,9 @@ def load_dict(d):
             bsdf = named[bp["id"]]
         else:
             bsdf = _make_bsdf(scene, bp, key + ".bsdf")
-        kind = abi.SHAPE_RECTANGLE if vt == "rectangle" else abi.SHAPE_MESH
+        kind = abi.SHAPE_RECTANGLE if vt == "rectangle" else (abi.SHAPE_SPHERE if vt == "sphere" else abi.SHAPE_MESH)
+        if vt == "sphere":      # sphere.cpp:131-146: to_world * translate(center) * scale(radius)
+            tw = tw @ ScalarTransform4f.translate(v.get("center", [0, 0, 0])) @ ScalarTransform4f.scale(float(v.get("radius", 1.0)))
         shape = Shape(key, kind, tw, bsdf, flip_normals=bool(v.get("flip_normals", False)))
         if vt == "cube":
             _make_cube(shape)
@@ -449,8 +516,8 @@ def load_dict(d):
         if ep is not None:
             if ep.get("type") != "area":
                 raise PluginError('emitter plugin "%s" is outside the path (area)' % ep.get("type"))
-            if kind != abi.SHAPE_RECTANGLE:
-                raise PluginError("area emitters on meshes are outside this build's path (rectangle emitters only)")
+            if kind == abi.SHAPE_MESH:
+                raise PluginError("area emitters on meshes are outside this build's path (rectangle and sphere emitters)")
             e = Emitter(_rgb(ep.get("radiance", 1.0), "area.radiance", False))
             e.shape = shape; shape.emitter = e
             scene.emitters.append(e)
@@ -497,3 +564,41 @@ def cornell_box():
         'large-box': {'type': 'cube', 'to_world': T.translate([-0.33, -0.4, -0.28]).rotate([0, 1, 0], 18.25).scale([0.3, 0.61, 0.3]),
                       'bsdf': {'type': 'ref', 'id': 'white'}},
     }
+
+
+def veach_mis_scene(res=256):
+    """Build-authored analogue of the Veach MIS test scene (BASELINE config 4; the reference's scene file is not in its
+    tree): four `roughconductor` plates of roughness 0.005 / 0.02 / 0.05 / 0.1 tilted towards the camera, four
+    sphere `area` emitters of radius 0.03 / 0.1 / 0.3 / 0.9 (x0.25) with equal power and different colours, one `dielectric`
+    sphere, diffuse floor and back wall, one dim rectangular fill light."""
+    T = ScalarTransform4f
+    d = {
+        'type': 'scene',
+        'integrator': {'type': 'path', 'max_depth': 8},
+        'sensor': {'type': 'perspective', 'fov': 38, 'near_clip': 0.01, 'far_clip': 100.0,
+                   'to_world': T.look_at(origin=[0, 2.0, 7.5], target=[0, 0.2, 0], up=[0, 1, 0]),
+                   'sampler': {'type': 'independent', 'sample_count': 64},
+                   'film': {'type': 'hdrfilm', 'width': res, 'height': res, 'rfilter': {'type': 'gaussian'}, 'pixel_format': 'rgb'}},
+        'grey': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.4, 0.4, 0.4]}},
+        'floor': {'type': 'rectangle', 'to_world': T.translate([0, -1.2, 0]).rotate([1, 0, 0], -90).scale(6.0), 'bsdf': {'type': 'ref', 'id': 'grey'}},
+        'back': {'type': 'rectangle', 'to_world': T.translate([0, 2.0, -3.5]).scale([6.0, 4.0, 1.0]), 'bsdf': {'type': 'ref', 'id': 'grey'}},
+        'fill': {'type': 'rectangle', 'to_world': T.translate([0, 6.0, 2.0]).rotate([1, 0, 0], 90).scale(1.5), 'bsdf': {'type': 'ref', 'id': 'grey'},
+                 'emitter': {'type': 'area', 'radiance': {'type': 'rgb', 'value': [1.0, 1.0, 1.0]}}},
+        'glass': {'type': 'sphere', 'center': [1.75, -0.75, 2.6], 'radius': 0.45, 'bsdf': {'type': 'dielectric', 'int_ior': 'bk7', 'ext_ior': 'air'}},
+    }
+    alphas = [0.005, 0.02, 0.05, 0.1]
+    for i, a in enumerate(alphas):
+        tilt = -38.0 + 9.0 * i
+        d['plate%d' % i] = {'type': 'rectangle',
+                            'to_world': T.translate([0, -0.9 + 0.42 * i, 1.6 - 0.95 * i]).rotate([1, 0, 0], -90 - tilt).scale([2.2, 0.38, 1.0]),
+                            'bsdf': {'type': 'roughconductor', 'alpha': a, 'distribution': 'ggx' if i % 2 else 'beckmann',
+                                     'eta': [0.2, 0.92, 1.1], 'k': [3.9, 2.45, 2.14]}}
+    radii = [0.03, 0.1, 0.3, 0.9]
+    colors = [[1.0, 0.35, 0.3], [0.35, 1.0, 0.4], [0.35, 0.45, 1.0], [1.0, 0.9, 0.5]]
+    for i, r in enumerate(radii):
+        rr = 0.25 * r
+        power = 40.0
+        rad = [power * c / (4 * math.pi * rr * rr * math.pi) for c in colors[i]]
+        d['lamp%d' % i] = {'type': 'sphere', 'center': [-1.65 + 1.1 * i, 1.55, -1.9], 'radius': rr, 'bsdf': {'type': 'ref', 'id': 'grey'},
+                           'emitter': {'type': 'area', 'radiance': {'type': 'rgb', 'value': rad}}}
+    return d

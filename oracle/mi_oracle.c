@@ -272,6 +272,7 @@ typedef struct {
     uint32_t type, bsdf; int32_t emitter; uint32_t flip_normals;
     float to_world[12], to_object[12];
     v3 frame_s, frame_t, frame_n; float inv_area;        /* rectangle.cpp:115-126 */
+    v3 center; float radius;                              /* sphere.cpp:158-159 */
     uint32_t vertex_count, face_count;
     float *pos, *nrm, *uv; uint32_t *faces;
 } OShape;
@@ -327,6 +328,11 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
                 area += 0.5 * (double) norm3(cross3(sub3(p1, p0), sub3(p2, p0)));
             }
             o->inv_area = (float) (1.0 / area);
+        } else if (sd->type == MI355_SHAPE_SPHERE) {
+            /* Sphere::update, sphere.cpp:150-172 (uniform positive scale assumed) */
+            o->center = xf_point(o->to_world, V3(0.f, 0.f, 0.f));
+            o->radius = norm3(xf_vector(o->to_world, V3(1.f, 0.f, 0.f)));
+            o->inv_area = rcpf_(4.f * ORC_PI * (o->radius * o->radius));
         } else { free(s); return NULL; }
     }
     s->sensor = d->sensor;
@@ -401,6 +407,47 @@ static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t
     return active;
 }
 
+/* math::solve_quadratic: include/mitsuba/core/math.h:360-402 */
+static int solve_quadratic(float a, float b, float c, float *x0, float *x1) {
+    int linear_case = a == 0.f, valid_linear = linear_case && b != 0.f;
+    *x0 = *x1 = -c / b;
+    float discrim = fmaf(b, b, -(4.f * a * c));
+    int valid_quadratic = !linear_case && discrim >= 0.f;
+    if (valid_quadratic) {
+        float sqrt_discrim = sqrtf(discrim);
+        float temp = -0.5f * (b + copysignf(sqrt_discrim, b));
+        float x0p = temp / a, x1p = c / temp;
+        *x0 = fminf(x0p, x1p); *x1 = fmaxf(x0p, x1p);
+    }
+    return valid_linear || valid_quadratic;
+}
+/* Sphere::ray_intersect_preliminary_impl: src/shapes/sphere.cpp:491-563 (float32 branch of the AD variants) */
+static int sphere_intersect(const OShape *sh, const Ray *ray, float *t_out) {
+    v3 l = sub3(ray->o, sh->center), d = ray->d;
+    float plane_t = dot3(neg3(l), d) / norm3(d);
+    int no_hit = plane_t == 0.f && (ray->o.x != sh->center.x && ray->o.y != sh->center.y && ray->o.z != sh->center.z);
+    v3 plane_p = ray_at(ray, plane_t);
+    no_hit = no_hit && (norm3(sub3(plane_p, sh->center)) > sh->radius);
+    v3 o = sub3(plane_p, sh->center);
+    float A = sqnorm3(d), B = 2.f * dot3(o, d), C = sqnorm3(o) - sh->radius * sh->radius;
+    float near_t, far_t; int found = solve_quadratic(A, B, C, &near_t, &far_t);
+    near_t += plane_t; far_t += plane_t;
+    int out_bounds = !(near_t <= ray->maxt && far_t >= 0.f);
+    int in_bounds = near_t < 0.f && far_t > ray->maxt;
+    int active = found && !no_hit && !out_bounds && !in_bounds;
+    *t_out = near_t < 0.f ? far_t : near_t;
+    return active;
+}
+/* Sphere::ray_test_impl: sphere.cpp:565-601 */
+static int sphere_test(const OShape *sh, const Ray *ray) {
+    v3 o = sub3(ray->o, sh->center), d = ray->d;
+    float A = sqnorm3(d), B = 2.f * dot3(o, d), C = sqnorm3(o) - sh->radius * sh->radius;
+    float near_t, far_t; int found = solve_quadratic(A, B, C, &near_t, &far_t);
+    int out_bounds = !(near_t <= ray->maxt && far_t >= 0.f);
+    int in_bounds = near_t < 0.f && far_t > ray->maxt;
+    return found && !out_bounds && !in_bounds;
+}
+
 /* Scene::ray_intersect_preliminary (closest hit): scene.cpp:192-199; traversal semantics of
    kdtree.h:2197-2293 (maxt shrinks to the closest hit so far) restated as a linear scan. */
 static PI scene_intersect(OScene *sc, const Ray *ray_in) {
@@ -410,6 +457,9 @@ static PI scene_intersect(OScene *sc, const Ray *ray_in) {
         if (sh->type == MI355_SHAPE_RECTANGLE) {
             float t; v2 uv;
             if (rect_intersect(sh, &ray, &t, &uv) && t < pi.t) { pi.t = t; pi.prim_uv = uv; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
+        } else if (sh->type == MI355_SHAPE_SPHERE) {
+            float t;
+            if (sphere_intersect(sh, &ray, &t) && t < pi.t) { pi.t = t; pi.prim_uv.x = pi.prim_uv.y = 0.f; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
         } else {
             for (uint32_t f = 0; f < sh->face_count; ++f) {
                 const uint32_t *fi = sh->faces + 3 * f; float t; v2 uv;
@@ -426,6 +476,7 @@ static int scene_ray_test(OScene *sc, const Ray *ray) {
     for (uint32_t i = 0; i < sc->n_shapes; ++i) {
         const OShape *sh = &sc->shapes[i]; float t; v2 uv;
         if (sh->type == MI355_SHAPE_RECTANGLE) { if (rect_intersect(sh, ray, &t, &uv)) return 1; }
+        else if (sh->type == MI355_SHAPE_SPHERE) { if (sphere_test(sh, ray)) return 1; }
         else for (uint32_t f = 0; f < sh->face_count; ++f) {
             const uint32_t *fi = sh->faces + 3 * f;
             if (moeller_trumbore(ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv)) return 1;
@@ -447,6 +498,26 @@ static SI compute_si(const OScene *sc, const Ray *ray, const PI *pi) {
         si.p = ray_at(ray, pi->t);
         si.n = sh->frame_n; si.sh_n = sh->frame_n; si.dp_du = sh->frame_s; si.dp_dv = sh->frame_t;
         si.uv.x = fmaf(pi->prim_uv.x, .5f, .5f); si.uv.y = fmaf(pi->prim_uv.y, .5f, .5f);
+    } else if (sh->type == MI355_SHAPE_SPHERE) {
+        /* Sphere::compute_surface_interaction, sphere.cpp:609-712, IsDiff && !FollowShape branch */
+        si.p = ray_at(ray, pi->t);
+        si.sh_n = normalize3(sub3(si.p, sh->center));
+        v3 local = xf_point(sh->to_object, si.p);
+        float rd_2 = local.x * local.x + local.y * local.y;
+        /* dr::unit_angle_z [Dr.Jit, recalled]: robust acos(z) */
+        v3 dz = V3(local.x, local.y, local.z - mulsign(1.f, local.z));
+        float temp = 2.f * asinf(.5f * norm3(dz));
+        float theta = local.z >= 0.f ? temp : ORC_PI - temp;
+        float phi = atan2f(local.y, local.x); if (phi < 0.f) phi += 2.f * ORC_PI;
+        si.uv.x = phi * (0.5f * ORC_INV_PI); si.uv.y = theta * ORC_INV_PI;
+        si.dp_du = V3(-local.y, local.x, 0.f);
+        float rd = sqrtf(rd_2), inv_rd = rcpf_(rd), cos_phi = local.x * inv_rd, sin_phi = local.y * inv_rd;
+        si.dp_dv = V3(local.z * cos_phi, local.z * sin_phi, -rd);
+        if (rd == 0.f) si.dp_dv = V3(1.f, 0.f, 0.f);
+        si.dp_du = scale3(xf_vector(sh->to_world, si.dp_du), 2.f * ORC_PI);
+        si.dp_dv = scale3(xf_vector(sh->to_world, si.dp_dv), ORC_PI);
+        if (sh->flip_normals) si.sh_n = neg3(si.sh_n);
+        si.n = si.sh_n;
     } else {
         const uint32_t *fi = sh->faces + 3 * pi->prim_index;
         v3 p0 = mesh_vertex(sh, fi[0]), p1 = mesh_vertex(sh, fi[1]), p2 = mesh_vertex(sh, fi[2]);
@@ -568,6 +639,228 @@ ORC_API void orc_diffuse_sample(const float *refl, const float *wi, const float 
     wo3[0] = wo.x; wo3[1] = wo.y; wo3[2] = wo.z; w3[0] = w.x; w3[1] = w.y; w3[2] = w.z;
 }
 
+/* ----------------------------------------------------------------------------------------
+ * microfacet distribution (include/mitsuba/render/microfacet.h) and Fresnel (fresnel.h)
+ * erf / erfinv: Dr.Jit polynomial approximations are absent from the tree -> libm erff and Giles' single-precision
+ * erfinv ("Approximating the erfinv function", 2010) [parity unpinned]
+ * ---------------------------------------------------------------------------------------- */
+static float erfinv_(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f); p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f); p = fmaf(p, w, -0.00417768164f); p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f); p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f); p = fmaf(p, w, 0.00943887047f); p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+typedef struct { uint32_t type; float au, av; int sample_visible; } MF;      /* microfacet.h:63-180 */
+static MF mf_make(uint32_t type, float au, float av, int sv) { MF m = { type, fmaxf(au, 1e-4f), fmaxf(av, 1e-4f), sv }; return m; }  /* configure(), :424-427 */
+static inline float sqr_(float x) { return x * x; }
+static inline float safe_sqrt_(float x) { return sqrtf(fmaxf(x, 0.f)); }
+/* MicrofacetDistribution::eval, microfacet.h:185-207 */
+static float mf_eval(const MF *d, v3 m) {
+    float alpha_uv = d->au * d->av, ct = m.z, ct2 = ct * ct, result;
+    if (d->type == 0)
+        result = expf(-(sqr_(m.x / d->au) + sqr_(m.y / d->av)) / ct2) / (ORC_PI * alpha_uv * sqr_(ct2));
+    else
+        result = rcpf_(ORC_PI * alpha_uv * sqr_(sqr_(m.x / d->au) + sqr_(m.y / d->av) + sqr_(m.z)));
+    return result * ct > 1e-20f ? result : 0.f;
+}
+/* smith_g1, microfacet.h:341-365 */
+static float mf_smith_g1(const MF *d, v3 v, v3 m) {
+    float xy_alpha_2 = sqr_(d->au * v.x) + sqr_(d->av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr_(v.z), result;
+    if (d->type == 0) {
+        float a = rsqrtf_(tan_theta_alpha_2), a_sqr = a * a;
+        result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot3(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+/* pdf, microfacet.h:219-228 */
+static float mf_pdf(const MF *d, v3 wi, v3 m) {
+    float result = mf_eval(d, m);
+    if (d->sample_visible) result *= mf_smith_g1(d, wi, m) * fabsf(dot3(wi, m)) / wi.z;
+    else result *= m.z;
+    return result;
+}
+/* sample_visible_11, microfacet.h:368-421 */
+static v2 mf_sample_visible_11(const MF *d, float cos_theta_i, v2 sample) {
+    v2 r;
+    if (d->type == 0) {
+        float tan_theta_i = safe_sqrt_(fmaf(-cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = rcpf_(tan_theta_i);
+        float maxval = erff(cot_theta_i);
+        sample.x = fmaxf(fminf(sample.x, 1.f - 1e-6f), 1e-6f); sample.y = fmaxf(fminf(sample.y, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * erff(sqrtf(-logf(sample.x)));
+        const float inv_sqrt_pi = 0.56418958354775628695f;
+        sample.x *= 1.f + maxval + inv_sqrt_pi * tan_theta_i * expf(-sqr_(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {
+            float slope = erfinv_(x), value = 1.f + x + inv_sqrt_pi * tan_theta_i * expf(-sqr_(slope)) - sample.x,
+                  derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        r.x = erfinv_(x); r.y = erfinv_(fmaf(2.f, sample.y, -1.f));
+    } else {
+        v2 p = square_to_uniform_disk_concentric(sample);
+        float sfac = 0.5f * (1.f + cos_theta_i);
+        float a = safe_sqrt_(1.f - sqr_(p.x));
+        p.y = fmaf(p.y - a, sfac, a);                                   /* dr::lerp(a, b, t) = fmadd(b - a, t, a) [recalled] */
+        float x = p.x, y = p.y, z = safe_sqrt_(1.f - fmaf(p.y, p.y, p.x * p.x));
+        float sin_theta_i = safe_sqrt_(1.f - sqr_(cos_theta_i));
+        float norm = rcpf_(fmaf(sin_theta_i, y, cos_theta_i * z));
+        r.x = fmaf(cos_theta_i, y, -(sin_theta_i * z)) * norm; r.y = x * norm;
+    }
+    return r;
+}
+/* sample, microfacet.h:244-326 */
+static v3 mf_sample(const MF *d, v3 wi, v2 sample, float *pdf) {
+    if (!d->sample_visible) {
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+        if (d->au == d->av) { float ph = (2.f * ORC_PI) * sample.y; sin_phi = sinf(ph); cos_phi = cosf(ph); alpha_2 = d->au * d->au; }
+        else {
+            float ratio = d->av / d->au, tmp = ratio * tanf((2.f * ORC_PI) * sample.y);
+            cos_phi = rsqrtf_(fmaf(tmp, tmp, 1.f)); cos_phi = mulsign(cos_phi, fabsf(sample.y - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = rcpf_(sqr_(cos_phi / d->au) + sqr_(sin_phi / d->av));
+        }
+        if (d->type == 0) {
+            cos_theta = rsqrtf_(fmaf(-alpha_2, logf(1.f - sample.x), 1.f)); cos_theta_2 = cos_theta * cos_theta;
+            float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            *pdf = (1.f - sample.x) / (ORC_PI * d->au * d->av * cos_theta_3);
+        } else {
+            float tan_theta_m_2 = alpha_2 * sample.x / (1.f - sample.x);
+            cos_theta = rsqrtf_(1.f + tan_theta_m_2); cos_theta_2 = cos_theta * cos_theta;
+            float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            *pdf = rcpf_(ORC_PI * d->au * d->av * cos_theta_3 * sqr_(temp));
+        }
+        float sin_theta = sqrtf(1.f - cos_theta_2);
+        return V3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    }
+    v3 wi_p = normalize3(V3(d->au * wi.x, d->av * wi.y, wi.z));
+    /* Frame3f::sincos_phi, frame.h:111-122 */
+    float st2 = fmaf(wi_p.x, wi_p.x, wi_p.y * wi_p.y), ist = rsqrtf_(st2);
+    float cos_phi = fminf(fmaxf(wi_p.x * ist, -1.f), 1.f), sin_phi = fminf(fmaxf(wi_p.y * ist, -1.f), 1.f);
+    if (fabsf(st2) <= 4.f * ORC_EPS) { cos_phi = 1.f; sin_phi = 0.f; }
+    v2 slope = mf_sample_visible_11(d, wi_p.z, sample);
+    float sx = fmaf(cos_phi, slope.x, -(sin_phi * slope.y)) * d->au, sy = fmaf(sin_phi, slope.x, cos_phi * slope.y) * d->av;
+    v3 m = normalize3(V3(-sx, -sy, 1.f));
+    *pdf = mf_eval(d, m) * mf_smith_g1(d, wi, m) * fabsf(dot3(wi, m)) / wi.z;
+    return m;
+}
+/* fresnel(), include/mitsuba/render/fresnel.h:34-72 */
+static void fresnel_(float cos_theta_i, float eta, float *r_out, float *cos_theta_t_out, float *eta_it_out, float *eta_ti_out) {
+    int outside = cos_theta_i >= 0.f;
+    float rcp_eta = rcpf_(eta), eta_it = outside ? eta : rcp_eta, eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    float cia = fabsf(cos_theta_i), cta = safe_sqrt_(cos_theta_t_sqr);
+    int index_matched = eta == 1.f, special = index_matched || cia == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fmaf(-eta_it, cta, cia) / fmaf(eta_it, cta, cia);
+    float a_p = fmaf(-eta_it, cia, cta) / fmaf(eta_it, cia, cta);
+    float r = 0.5f * (a_s * a_s + a_p * a_p);
+    if (special) r = r_sc;
+    *r_out = r; *cos_theta_t_out = mulsign(-cta, cos_theta_i); *eta_it_out = eta_it; *eta_ti_out = eta_ti;
+}
+/* fresnel_conductor(), fresnel.h:92-118 */
+static float fresnel_conductor_(float cos_theta_i, float eta_r, float eta_i) {
+    float ci2 = cos_theta_i * cos_theta_i, si2 = 1.f - ci2, si4 = si2 * si2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - si2, a_2_pb_2 = safe_sqrt_(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a = safe_sqrt_(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + ci2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * ci2 + si4, term_4 = term_2 * si2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+ORC_API void orc_fresnel(float cos_theta_i, float eta, float *out4) { fresnel_(cos_theta_i, eta, &out4[0], &out4[1], &out4[2], &out4[3]); }
+ORC_API float orc_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) { return fresnel_conductor_(cos_theta_i, eta_r, eta_i); }
+ORC_API void orc_microfacet(uint32_t type, float au, float av, int sample_visible, const float *wi3, const float *v3s, const float *samples2, int n,
+                            float *eval_out, float *pdf_out, float *g1_out, float *sample_m3, float *sample_pdf) {
+    MF d = mf_make(type, au, av, sample_visible); v3 wi = V3(wi3[0], wi3[1], wi3[2]);
+    for (int i = 0; i < n; ++i) {
+        if (v3s) { v3 v = V3(v3s[3*i], v3s[3*i+1], v3s[3*i+2]);
+            if (eval_out) eval_out[i] = mf_eval(&d, v); if (pdf_out) pdf_out[i] = mf_pdf(&d, wi, v); if (g1_out) g1_out[i] = mf_smith_g1(&d, v, wi); }
+        if (samples2) { v2 sm = { samples2[2*i], samples2[2*i+1] }; float pdf; v3 m = mf_sample(&d, wi, sm, &pdf);
+            sample_m3[3*i] = m.x; sample_m3[3*i+1] = m.y; sample_m3[3*i+2] = m.z; sample_pdf[i] = pdf; }
+    }
+}
+
+/* ---- generic BSDF interface: BSDF::eval_pdf / sample (bsdf.h:371-470) dispatched on the plugin type ---- */
+typedef struct { v3 wo; float pdf, eta; int delta; } BSample;
+static int bsdf_is_smooth(const mi355_bsdf_desc *b) { return b->type != MI355_BSDF_DIELECTRIC; }   /* BSDFFlags::Smooth, bsdf.h:96 */
+/* RoughConductor::eval_pdf, roughconductor.cpp:428-517 */
+static void roughconductor_eval_pdf(const mi355_bsdf_desc *b, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
+    *val = V3(0, 0, 0); *pdf = 0.f;
+    v3 H = normalize3(add3(wo, wi));
+    active = active && wi.z > 0.f && wo.z > 0.f && dot3(wi, H) > 0.f && dot3(wo, H) > 0.f;
+    if (!active) return;
+    MF d = mf_make(b->distribution, b->alpha_u, b->alpha_v, (int) b->sample_visible);
+    float D = mf_eval(&d, H);
+    if (D == 0.f) return;
+    float g1_wi = mf_smith_g1(&d, wi, H), G = g1_wi * mf_smith_g1(&d, wo, H);
+    float value = D * G / (4.f * wi.z);
+    float ct = dot3(wi, H);
+    v3 F = V3(fresnel_conductor_(ct, b->eta[0], b->k[0]), fresnel_conductor_(ct, b->eta[1], b->k[1]), fresnel_conductor_(ct, b->eta[2], b->k[2]));
+    v3 sr = V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+    *val = mul3(F, scale3(sr, value));
+    *pdf = d.sample_visible ? D * g1_wi / (4.f * wi.z) : mf_pdf(&d, wi, H) / (4.f * dot3(wo, H));
+}
+/* RoughConductor::sample, roughconductor.cpp:226-312 */
+static void roughconductor_sample(const mi355_bsdf_desc *b, v3 wi, v2 s2, int active, BSample *bs, v3 *weight) {
+    memset(bs, 0, sizeof(*bs)); *weight = V3(0, 0, 0);
+    active = active && wi.z > 0.f;
+    MF d = mf_make(b->distribution, b->alpha_u, b->alpha_v, (int) b->sample_visible);
+    float pdf; v3 m = mf_sample(&d, wi, s2, &pdf);
+    bs->wo = sub3(scale3(m, 2.f * dot3(wi, m)), wi);                     /* reflect(wi, m), fresnel.h:281-284 */
+    bs->eta = 1.f; bs->delta = 0;
+    active = active && pdf != 0.f && bs->wo.z > 0.f;
+    float w = d.sample_visible ? mf_smith_g1(&d, bs->wo, m) : mf_smith_g1(&d, wi, m) * mf_smith_g1(&d, bs->wo, m) * dot3(wi, m) / (wi.z * m.z);
+    bs->pdf = pdf / (4.f * dot3(bs->wo, m));
+    float ct = dot3(wi, m);
+    v3 F = V3(fresnel_conductor_(ct, b->eta[0], b->k[0]), fresnel_conductor_(ct, b->eta[1], b->k[1]), fresnel_conductor_(ct, b->eta[2], b->k[2]));
+    v3 sr = V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+    if (active) *weight = mul3(F, scale3(sr, w));
+}
+/* SmoothDielectric::sample, dielectric.cpp:246-371 (unpolarized, radiance transport); eval/pdf are zero (delta lobes) */
+static void dielectric_sample(const mi355_bsdf_desc *b, v3 wi, float s1, int active, BSample *bs, v3 *weight) {
+    float eta = b->int_ior / b->ext_ior;
+    float r_i, cos_theta_t, eta_it, eta_ti; fresnel_(wi.z, eta, &r_i, &cos_theta_t, &eta_it, &eta_ti);
+    float t_i = 1.f - r_i;
+    int selected_r = s1 <= r_i && active;
+    bs->pdf = selected_r ? r_i : t_i;
+    bs->wo = selected_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);
+    bs->eta = selected_r ? 1.f : eta_it; bs->delta = 1;
+    v3 w = selected_r ? V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]) : V3(b->transmittance[0], b->transmittance[1], b->transmittance[2]);
+    if (!selected_r) w = scale3(w, eta_ti * eta_ti);                    /* radiance scaling, dielectric.cpp:361-366 */
+    *weight = active ? w : V3(0, 0, 0);
+}
+static void bsdf_eval_pdf(const mi355_bsdf_desc *b, v3 refl, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
+    if (b->type == MI355_BSDF_DIFFUSE) diffuse_eval_pdf(refl, wi, wo, active, val, pdf);
+    else if (b->type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
+    else { *val = V3(0, 0, 0); *pdf = 0.f; }
+}
+static void bsdf_sample(const mi355_bsdf_desc *b, v3 refl, v3 wi, float s1, v2 s2, int active, BSample *bs, v3 *weight) {
+    if (b->type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2, active, &bs->wo, &bs->pdf, weight); bs->eta = 1.f; bs->delta = 0; }
+    else if (b->type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2, active, bs, weight);
+    else dielectric_sample(b, wi, s1, active, bs, weight);
+}
+ORC_API void orc_bsdf_eval_pdf(const mi355_bsdf_desc *b, const float *wi, const float *wo, float *val3, float *pdf) {
+    v3 v; v3 refl = V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+    bsdf_eval_pdf(b, refl, V3(wi[0], wi[1], wi[2]), V3(wo[0], wo[1], wo[2]), 1, &v, pdf); val3[0] = v.x; val3[1] = v.y; val3[2] = v.z;
+}
+ORC_API void orc_bsdf_sample(const mi355_bsdf_desc *b, const float *wi, float s1, const float *s2, float *wo3, float *pdf_eta_delta3, float *w3) {
+    BSample bs; v3 w; v2 q = { s2[0], s2[1] }; v3 refl = V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+    bsdf_sample(b, refl, V3(wi[0], wi[1], wi[2]), s1, q, 1, &bs, &w);
+    wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; pdf_eta_delta3[0] = bs.pdf; pdf_eta_delta3[1] = bs.eta; pdf_eta_delta3[2] = (float) bs.delta;
+    w3[0] = w.x; w3[1] = w.y; w3[2] = w.z;
+}
+
 /* PathIntegrator::mis_weight: src/integrators/path.cpp:300-305 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -591,13 +884,44 @@ static void sample_emitter_direction(OScene *sc, const SI *si, v2 sample, int ac
     if (sh->type == MI355_SHAPE_RECTANGLE) {
         ds->p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
         ds->n = sh->frame_n; ds->pdf = sh->inv_area; ds->uv = sample;
+        ds->d = sub3(ds->p, si->p);
+        float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2);
+        ds->d = scale3(ds->d, rcpf_(ds->dist));
+        float dp = fabsf(dot3(ds->d, ds->n));
+        float x = dist2 / dp;
+        ds->pdf *= isfinite(x) ? x : 0.f;
+    } else if (sh->type == MI355_SHAPE_SPHERE) {
+        /* Sphere::sample_direction, sphere.cpp:236-311 */
+        v3 dc_v = sub3(sh->center, si->p); float dc_2 = sqnorm3(dc_v);
+        float radius_adj = sh->radius * (sh->flip_normals ? (1.f + RAY_EPS) : (1.f - RAY_EPS));
+        v3 dn;
+        if (dc_2 > radius_adj * radius_adj) {
+            float inv_dc = rsqrtf_(dc_2), sin_theta_max = sh->radius * inv_dc, sin_theta_max_2 = sin_theta_max * sin_theta_max,
+                  inv_sin_theta_max = rcpf_(sin_theta_max), cos_theta_max = safe_sqrt_(1.f - sin_theta_max_2);
+            float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - sqr_(fmaf(cos_theta_max - 1.f, sample.x, 1.f)) : sin_theta_max_2 * sample.x,
+                  cos_theta = safe_sqrt_(1.f - sin_theta_2);
+            float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * safe_sqrt_(fmaf(-sin_theta_2, sqr_(inv_sin_theta_max), 1.f)),
+                  sin_alpha = safe_sqrt_(fmaf(-cos_alpha, cos_alpha, 1.f));
+            float ph = sample.y * (2.f * ORC_PI), sin_phi = sinf(ph), cos_phi = cosf(ph);
+            v3 fn = scale3(dc_v, -inv_dc), fs, ft; coordinate_system(fn, &fs, &ft);
+            v3 loc = V3(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha);
+            dn = fma3s(fn, loc.z, fma3s(ft, loc.y, scale3(fs, loc.x)));
+            ds->p = fma3s(dn, sh->radius, sh->center); ds->n = dn;
+            ds->d = sub3(ds->p, si->p);
+            float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2); ds->d = scale3(ds->d, rcpf_(ds->dist));
+            ds->pdf = (0.5f * ORC_INV_PI) / (1.f - cos_theta_max);
+            if (ds->dist == 0.f) ds->pdf = 0.f;
+        } else {
+            float z = fmaf(-2.f, sample.y, 1.f), r = safe_sqrt_(fmaf(-z, z, 1.f)), ph = 2.f * ORC_PI * sample.x;   /* warp.h:250-255 */
+            dn = V3(r * cosf(ph), r * sinf(ph), z);
+            ds->p = fma3s(dn, sh->radius, sh->center); ds->n = dn;
+            ds->d = sub3(ds->p, si->p);
+            float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2); ds->d = scale3(ds->d, rcpf_(ds->dist));
+            ds->pdf = sh->inv_area * dist2 / fabsf(dot3(ds->d, ds->n));
+        }
+        if (sh->flip_normals) ds->n = neg3(ds->n);
+        ds->uv = sample;
     } else { ds->pdf = 0.f; return; }                                   /* mesh emitters: outside the path's configs */
-    ds->d = sub3(ds->p, si->p);
-    float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2);
-    ds->d = scale3(ds->d, rcpf_(ds->dist));
-    float dp = fabsf(dot3(ds->d, ds->n));
-    float x = dist2 / dp;
-    ds->pdf *= isfinite(x) ? x : 0.f;
     active = active && dot3(ds->d, ds->n) < 0.f && ds->pdf != 0.f;      /* area.cpp:136 */
     v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
     *spec = active ? scale3(rad, rcpf_(ds->pdf)) : V3(0, 0, 0);          /* area.cpp:165-167 */
@@ -611,12 +935,15 @@ static void sample_emitter_direction(OScene *sc, const SI *si, v2 sample, int ac
 }
 /* Scene::pdf_emitter_direction (scene.cpp:355-366) -> AreaLight::pdf_direction (area.cpp:170-197)
    -> Shape::pdf_direction (shape.cpp:377-388) */
-static float pdf_emitter_direction(const OScene *sc, int32_t emitter, v3 d, v3 n, float dist) {
+static float pdf_emitter_direction(const OScene *sc, int32_t emitter, v3 ref_p, v3 d, v3 n, float dist) {
     const OShape *sh = &sc->shapes[sc->emitters[emitter].shape];
     float dp = dot3(d, n);
     if (!(dp < 0.f)) return 0.f;
-    float adp = fabsf(dp);
-    float pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    float adp = fabsf(dp), pdf;
+    if (sh->type == MI355_SHAPE_SPHERE) {                               /* Sphere::pdf_direction, sphere.cpp:313-325 */
+        float sin_alpha = sh->radius * rcpf_(norm3(sub3(sh->center, ref_p))), cos_alpha = safe_sqrt_(1.f - sin_alpha * sin_alpha);
+        pdf = sin_alpha < 0.99999994f ? (0.5f * ORC_INV_PI) / (1.f - cos_alpha) : sh->inv_area * (dist * dist) / adp;
+    } else pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
     return pdf * (1.f / (float) sc->n_emitters);
 }
 
@@ -670,7 +997,7 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
             v3 rel = sub3(si.p, prev_p); float dist = norm3(rel);
             v3 d = scale3(rel, rcpf_(dist));                            /* records.h:173-180 */
             float em_pdf = 0.f;
-            if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(sc, emitter, prev_p, d, si.sh_n, dist);
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
             const float *r = sc->emitters[emitter].radiance;
             v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);   /* area.cpp:83-90 */
@@ -682,15 +1009,16 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
         const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
         v3 refl = bsdf_reflectance(sc, bsdf, &si);
         /* ---- emitter sampling (path.cpp:186-208) */
-        int active_em = active_next;                                    /* diffuse has BSDFFlags::Smooth */
+        int active_em = active_next && bsdf_is_smooth(bsdf);             /* path.cpp:187 */
         DS ds; v3 em_weight; v2 s_em; s_em.x = pcg32_float(rng); s_em.y = pcg32_float(rng);
         sample_emitter_direction(sc, &si, s_em, active_em, &ds, &em_weight, &cnt->shadow);
         active_em = active_em && ds.pdf != 0.f;
         v3 wo = si_to_local(&si, ds.d);
         /* ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33) */
-        float s1 = pcg32_float(rng); (void) s1; v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
-        v3 bsdf_val; float bsdf_pdf; diffuse_eval_pdf(refl, si.wi, wo, 1, &bsdf_val, &bsdf_pdf);
-        v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2, 1, &bs_wo, &bs_pdf, &bsdf_weight);
+        float s1 = pcg32_float(rng); v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
+        v3 bsdf_val; float bsdf_pdf; bsdf_eval_pdf(bsdf, refl, si.wi, wo, 1, &bsdf_val, &bsdf_pdf);
+        BSample bsm; v3 bsdf_weight; bsdf_sample(bsdf, refl, si.wi, s1, s2, 1, &bsm, &bsdf_weight);
+        v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
         if (active_em) {                                                /* path.cpp:220-230 */
             float mis_em = mis_weight(ds.pdf, bsdf_pdf);
             result = fma3(throughput, scale3(mul3(bsdf_val, em_weight), mis_em), result);
@@ -698,9 +1026,9 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
         /* ---- BSDF sampling (path.cpp:234-262) */
         ray = spawn_ray(si.p, si.n, si_to_world(&si, bs_wo));
         throughput = mul3(throughput, bsdf_weight);
-        eta *= 1.f;
+        eta *= bsm.eta;
         valid_ray = valid_ray || si_valid;
-        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = 0;
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = bsm.delta;
         /* ---- stopping criterion (path.cpp:266-280) */
         depth += 1;
         float tmax = max3(throughput);
@@ -735,7 +1063,7 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
         v3 Le = V3(0, 0, 0); float le_mis = 0.f; int le_front = 0;
         if (emitter >= 0) {
             v3 rel = sub3(si.p, prev_p); float dist = norm3(rel); v3 d = scale3(rel, rcpf_(dist));
-            float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, d, si.sh_n, dist);
+            float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, prev_p, d, si.sh_n, dist);
             le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
             const float *r = sc->emitters[emitter].radiance;
             le_front = si.wi.z > 0.f && active_next;
@@ -750,23 +1078,24 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
         if (bsdf->reflectance_texture >= 0) refl = texture_eval(&sc->textures[bsdf->reflectance_texture], si.uv, tidx, twgt);
         else refl = V3(bsdf->reflectance[0], bsdf->reflectance[1], bsdf->reflectance[2]);
         /* ---- emitter sampling (prb.py:142-162) */
-        int active_em = active_next;
+        int active_em = active_next && bsdf_is_smooth(bsdf);
         DS ds; v3 em_weight; v2 s_em; s_em.x = pcg32_float(rng); s_em.y = pcg32_float(rng);
         sample_emitter_direction(sc, &si, s_em, active_em, &ds, &em_weight, &cnt->shadow);
         active_em = active_em && ds.pdf != 0.f;
         v3 wo = si_to_local(&si, ds.d);
-        v3 bsdf_value_em; float bsdf_pdf_em; diffuse_eval_pdf(refl, si.wi, wo, active_em, &bsdf_value_em, &bsdf_pdf_em);
+        v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf(bsdf, refl, si.wi, wo, active_em, &bsdf_value_em, &bsdf_pdf_em);
         float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
         v3 Lr_dir = mul3(mul3(scale3(beta, mis_em), bsdf_value_em), em_weight);
         /* ---- detached BSDF sampling (prb.py:166-169) */
-        float s1 = pcg32_float(rng); (void) s1; v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
-        v3 bs_wo, bsdf_weight; float bs_pdf; diffuse_sample(refl, si.wi, s2, active_next, &bs_wo, &bs_pdf, &bsdf_weight);
+        float s1 = pcg32_float(rng); v2 s2; s2.x = pcg32_float(rng); s2.y = pcg32_float(rng);
+        BSample bsm; v3 bsdf_weight; bsdf_sample(bsdf, refl, si.wi, s1, s2, active_next, &bsm, &bsdf_weight);
+        v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
         /* ---- update (prb.py:173-182) */
         v3 beta_pre = beta;
         L = backward ? sub3(sub3(L, Le), Lr_dir) : add3(add3(L, Le), Lr_dir);
         ray = spawn_ray(si.p, si.n, si_to_world(&si, bs_wo));
-        eta *= 1.f; beta = mul3(beta, bsdf_weight);
-        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = 0;
+        eta *= bsm.eta; beta = mul3(beta, bsdf_weight);
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = bsm.delta;
         /* ---- stopping criterion (prb.py:186-198) */
         float bmax = max3(beta);
         active_next = active_next && bmax != 0.f;
@@ -778,13 +1107,13 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
         /* ---- differential phase (prb.py:202-247), closed form */
         if (backward && g) {
             /* bsdf.eval(si, wo_sampled, active_next) and its detached twin (prb.py:213-227) */
-            float co = bs_wo.z; int ev_active = active_next && si.wi.z > 0.f && co > 0.f;
+            float co = bs_wo.z; int ev_active = active_next && si.wi.z > 0.f && co > 0.f && bsdf->type == MI355_BSDF_DIFFUSE;
             v3 det = scale3(bsdf_weight, bs_pdf);
             v3 inv = V3(det.x != 0.f ? rcpf_(det.x) : 0.f, det.y != 0.f ? rcpf_(det.y) : 0.f, det.z != 0.f ? rcpf_(det.z) : 0.f);
             float dval_dalb = ev_active ? ORC_INV_PI * co : 0.f;                         /* d bsdf_val / d albedo */
             v3 dLo_dalb = scale3(mul3(L, inv), dval_dalb);                               /* Lr_ind term */
             /* Lr_dir term: beta_pre * mis_em * (InvPi cos_o_em) * em_weight */
-            int em_active = active_em && si.wi.z > 0.f && wo.z > 0.f;
+            int em_active = active_em && si.wi.z > 0.f && wo.z > 0.f && bsdf->type == MI355_BSDF_DIFFUSE;
             float dval_em = em_active ? ORC_INV_PI * wo.z : 0.f;
             dLo_dalb = add3(dLo_dalb, mul3(scale3(scale3(beta_pre, mis_em), dval_em), em_weight));
             v3 ga = mul3(dL, dLo_dalb);
@@ -799,7 +1128,7 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
                         else gb[tidx[k]] += twgt[k] * (ga.x + ga.y + ga.z);
                     }
                 }
-            } else {
+            } else if (bsdf->type == MI355_BSDF_DIFFUSE) {
                 int32_t slot = g->bsdf_slot[bidx];
                 if (slot >= 0) { float *gb = g->grad + g->layout[slot].offset; gb[0] += ga.x; gb[1] += ga.y; gb[2] += ga.z; }
             }

@@ -70,7 +70,8 @@ def test_box_and_quad_primitives(mi, orc, torch_cuda):
     oracle's per-triangle Moeller-Trumbore, including prim_index and barycentrics (through uv)."""
     T = mi.ScalarTransform4f
     scene = mi.load_dict(small_cbox(mi, 32))
-    assert scene.info() == {"flat_prims": 6, "boxes": 2, "bvh_meshes": 0, "bvh_nodes": 0, "triangles": 24, "grad_floats": 12}
+    assert scene.info() == {"flat_prims": 6, "boxes": 2, "bvh_meshes": 0, "bvh_nodes": 0, "triangles": 24, "grad_floats": 12,
+                            "spheres": 0, "features": 0}
     shear = mi.Transform4f([[0.5, 0.2, 0.0, 0.1], [0.0, 0.4, 0.1, -0.2], [0.1, 0.0, 0.3, 0.2], [0, 0, 0, 1]])
     v = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1]], dtype=np.float32)
     f = np.array([[0, 1, 2], [3, 0, 2], [4, 5, 6], [7, 4, 6], [0, 4, 7], [1, 0, 7], [1, 7, 6], [2, 1, 6], [2, 6, 5], [3, 2, 5], [4, 0, 3], [5, 4, 3]], dtype=np.uint32)
@@ -239,6 +240,64 @@ def test_sharded_render_equals_whole(mi, orc, torch_cuda, cbox32):
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), None))
         torch.cuda.synchronize()
         assert torch.allclose(film, whole, rtol=1e-4, atol=1e-4), split
+
+
+# ---- scope row a19: sphere / roughconductor / dielectric (BASELINE config 4 scene) ------------------------
+@pytest.fixture(scope="module")
+def veach64(mi):
+    return mi.load_dict(mi.veach_mis_scene(64))
+
+
+def test_veach_scene_intersect(mi, orc, torch_cuda, veach64):
+    assert veach64.info()["spheres"] == 5 and veach64.info()["features"] == 3
+    o = orc.OracleScene(veach64, mi.abi)
+    rays = _rays_for(veach64, o, 8192, seed=5)
+    rays[4096:, 0:3] *= 3.0                                    # random origins spread over the whole scene
+    ref = orc.unpack_hits(o.ray_intersect(rays)); got = orc.unpack_hits(_gpu_intersect(mi, torch_cuda, veach64, rays))
+    same = (ref["shape"] == got["shape"]) & (ref["occluded"] == got["occluded"])
+    assert same.mean() > 0.999
+    hit = same & np.isfinite(ref["t"])
+    sphere_ids = [i for i, sh in enumerate(veach64.shapes) if sh.type == mi.abi.SHAPE_SPHERE]
+    assert np.isin(ref["shape"][hit], sphere_ids).sum() > 100
+    assert np.allclose(ref["t"][hit], got["t"][hit], rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("integrator_name,max_depth,rr_depth", [("path", 8, 5), ("path", 3, 5), ("prb", 6, 2)])
+def test_veach_lane_radiance(mi, orc, torch_cuda, veach64, integrator_name, max_depth, rr_depth):
+    integ = mi.make_integrator({"type": integrator_name, "max_depth": max_depth, "rr_depth": rr_depth})
+    o = orc.OracleScene(veach64, mi.abi)
+    spp, seed = 4, 3
+    n = 64 * 64 * spp
+    ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
+    got = integ.lane_radiance(veach64, seed, spp, 0, n).cpu().numpy()
+    assert np.isfinite(got).all()
+    # glossy lobes amplify ulp-level differences (expf / erff / sincos of gfx950 vs glibc): looser per-lane tolerance, tight means
+    close = np.isclose(got[:, :3], ref[:, :3], rtol=2e-3, atol=1e-4).all(axis=1) & (got[:, 3] == ref[:, 3])
+    assert close.mean() > 0.995, "diverged lanes: %g" % (1 - close.mean())
+    assert np.allclose(got[:, :3].mean(0), ref[:, :3].mean(0), rtol=2e-2)
+
+
+def test_veach_render_and_backward(mi, orc, torch_cuda, veach64):
+    torch = torch_cuda
+    integ = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5})
+    o = orc.OracleScene(veach64, mi.abi)
+    img = integ.render(veach64, seed=2, spp=16).cpu().numpy()
+    ref, _ = o.render(o.params(integ, 2, 16))
+    # fireflies from the tiny lamp make max() a poor scale; compare robustly
+    err = np.abs(img - ref)
+    assert np.percentile(err, 99.5) < 2e-3 * np.percentile(ref, 99.5) + 1e-4
+    assert abs(img.mean() - ref.mean()) < 5e-3 * ref.mean()
+    params = mi.traverse(veach64)
+    gin = np.ones((64, 64, 3), dtype=np.float32)
+    g = integ.render_backward(veach64, params, torch.tensor(gin), seed=6, spp=16).cpu().numpy()
+    g_ref = o.render_backward(o.params(integ, 6, 16), gin)
+    lay, total = mi.scene_param_layout(veach64)
+    assert (lay, total) == o.param_layout() and total == 3 + 5 * 3           # grey albedo + 5 emitters; conductors/dielectric carry none
+    assert np.allclose(g, g_ref, rtol=2e-2, atol=2e-3 * np.abs(g_ref).max())
+    # linearity identity for every emitter: d<1, image>/d rad_c = sum(image_c contribution of that emitter) -> sum over emitters = image sum / 1
+    tot = sum((g[off:off + 3] * veach64.emitters[i].radiance).sum() for k, i, off, sz in lay if k == mi.abi.PARAM_EMITTER_RADIANCE)
+    img6 = integ.render(veach64, seed=6, spp=16).cpu().numpy()
+    assert abs(tot - img6.sum()) < 2e-3 * img6.sum()
 
 
 # ---- PRB adjoint --------------------------------------------------------------------------------------

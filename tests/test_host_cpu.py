@@ -66,7 +66,7 @@ def test_load_dict_errors_and_scope(mi):
     assert abs(sc.sensor.x_fov - 39.3077) < 1e-4
     assert sc.integrator().max_depth == 8 and sc.integrator().rr_depth == 5
     assert mi.PRBIntegrator().max_depth == 6                        # common.py:31
-    for bad in ({"type": "sphere"}, {"type": "frobnicator"}):
+    for bad in ({"type": "cylinder"}, {"type": "frobnicator"}):
         with pytest.raises(mi.PluginError):
             mi.load_dict({"type": "scene", "x": bad})
     with pytest.raises(mi.PluginError):                             # reflectance outside [0,1] (srgb.cpp:52-66)

@@ -305,3 +305,190 @@ def test_area_emitter_identities(orc, mi):
         integ = mi.PathIntegrator({"max_depth": 1})
         img, _ = o.render(o.params(integ, 0, 4))
         assert np.allclose(img, np.array([2.0, 3.0, 4.0]) * expect)
+
+
+# ---- scope row a19: microfacet / Fresnel / dielectric / sphere -----------------------------------------------
+def _mf(orc, mi, type_, au, av, sv, wi, v=None, samples=None):
+    l = orc.lib(mi.abi)
+    n = len(v) if v is not None else len(samples)
+    wi = np.asarray(wi, dtype=np.float32)
+    ev = np.zeros(n, dtype=np.float32); pdf = np.zeros(n, dtype=np.float32); g1 = np.zeros(n, dtype=np.float32)
+    sm = np.zeros((n, 3), dtype=np.float32); sp = np.zeros(n, dtype=np.float32)
+    va = np.ascontiguousarray(v, dtype=np.float32) if v is not None else None
+    sa = np.ascontiguousarray(samples, dtype=np.float32) if samples is not None else None
+    l.orc_microfacet.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5
+    l.orc_microfacet(type_, au, av, sv, _p(wi), _p(va) if va is not None else None, _p(sa) if sa is not None else None, n,
+                     _p(ev), _p(pdf), _p(g1), _p(sm), _p(sp))
+    return ev, pdf, g1, sm, sp
+
+
+def _dirs(theta, phi):
+    theta = np.asarray(theta, dtype=np.float32); phi = np.asarray(phi, dtype=np.float32)
+    return np.stack([np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,type_", [("microfacet_beckmann", 0), ("microfacet_ggx", 1)])
+def test_microfacet_tables(orc, mi, kats, name, type_):
+    k = kats[name]; wi = [0, 0, 1]; steps = 20
+    if type_ == 0:
+        v = _dirs(np.linspace(0, np.pi, steps), np.full(steps, np.pi / 2))
+        ev, pdf, _, _, _ = _mf(orc, mi, 0, 0.1, 0.3, 0, wi, v)
+        assert np.allclose(ev, k["eval_theta_sweep"], rtol=1e-4, atol=1e-6) and np.allclose(pdf, k["pdf_theta_sweep"], rtol=1e-4, atol=1e-6)
+        ev, pdf, _, _, _ = _mf(orc, mi, 0, 0.1, 0.1, 0, wi, v)
+        assert np.allclose(ev, k["eval_i_theta_sweep"], rtol=1e-4, atol=1e-6) and np.allclose(pdf, k["pdf_i_theta_sweep"], rtol=1e-4, atol=1e-6)
+        v = _dirs(np.full(steps, 0.1), np.linspace(0, 2 * np.pi, steps))
+        ev, pdf, _, _, _ = _mf(orc, mi, 0, 0.1, 0.3, 0, wi, v)
+        assert np.allclose(ev, k["eval_phi_sweep"], rtol=1e-4) and np.allclose(pdf, np.array(k["eval_phi_sweep"]) * np.cos(0.1), rtol=1e-4)
+        ev, pdf, _, _, _ = _mf(orc, mi, 0, 0.1, 0.1, 0, wi, v)
+        assert np.allclose(ev, k["eval_i_phi_sweep"], rtol=1e-4) and np.allclose(pdf, k["eval_i_phi_sweep"] * np.cos(0.1), rtol=1e-4)
+    v = _dirs(np.linspace(np.pi / 3, np.pi / 2, steps), np.full(steps, np.pi / 2))
+    assert np.allclose(_mf(orc, mi, type_, 0.1, 0.3, 0, wi, v)[2], k["g1_theta_sweep"], atol=2e-5)
+    assert np.allclose(_mf(orc, mi, type_, 0.1, 0.1, 0, wi, v)[2], k["g1_i_theta_sweep"], atol=2e-5)
+    v = _dirs(np.full(steps, np.pi / 2 * 0.98), np.linspace(0, 2 * np.pi, steps))
+    assert np.allclose(_mf(orc, mi, type_, 0.1, 0.3, 0, wi, v)[2], k["g1_phi_sweep"], rtol=1e-4)
+    assert np.allclose(_mf(orc, mi, type_, 0.1, 0.1, 0, wi, v)[2], k["g1_i_phi_sweep"], rtol=1e-4)
+    u = np.linspace(0, 1, 6, endpoint=False)
+    u1, u2 = np.meshgrid(u, u)
+    samples = np.stack([u1.ravel(), u2.ravel()], 1)
+    _, _, _, m, pdf = _mf(orc, mi, type_, 0.1, 0.3, 0, wi, samples=samples)
+    assert np.allclose(pdf, k["sample_pdf"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(m[:12], k["sample_m_first_rows"], atol=5e-4)
+    assert np.allclose((m ** 2).sum(1), 1, atol=1e-5)
+
+
+@pytest.mark.parametrize("type_,alpha,sv,angle", [(0, 0.125, 1, 15), (0, 0.5, 1, 80), (1, 0.125, 1, 30), (1, 0.5, 1, 80), (0, 0.5, 0, 30), (1, 0.125, 0, 15)])
+def test_microfacet_sample_matches_pdf(orc, mi, type_, alpha, sv, angle):
+    """test_microfacet.py:303-324 (chi^2) in histogram form: sample() is distributed according to pdf()."""
+    rng = np.random.default_rng(3)
+    n = 400000
+    th = np.radians(angle); wi = [np.sin(th), 0, np.cos(th)]
+    s = rng.random((n, 2), dtype=np.float32)
+    _, _, _, m, _ = _mf(orc, mi, type_, alpha, alpha, sv, wi, samples=s)
+    nb = 24
+    ct = np.clip(m[:, 2], -1, 1); ph = np.arctan2(m[:, 1], m[:, 0])
+    hist, ce, pe = np.histogram2d(ct, ph, bins=[nb, nb], range=[[0, 1], [-np.pi, np.pi]])
+    # integrate pdf over each (cos theta, phi) cell with a 20x20 midpoint rule
+    sub = 20
+    cc = (ce[:-1, None] + (np.arange(sub) + 0.5)[None, :] * (ce[1] - ce[0]) / sub).ravel()
+    pp = (pe[:-1, None] + (np.arange(sub) + 0.5)[None, :] * (pe[1] - pe[0]) / sub).ravel()
+    C_, P_ = np.meshgrid(cc, pp, indexing="ij")
+    st = np.sqrt(np.maximum(0, 1 - C_ ** 2))
+    v = np.stack([st * np.cos(P_), st * np.sin(P_), C_], -1).reshape(-1, 3)
+    pdf = _mf(orc, mi, type_, alpha, alpha, sv, wi, v)[1].reshape(nb, sub, nb, sub)
+    expect = pdf.mean(axis=(1, 3)) * (ce[1] - ce[0]) * (pe[1] - pe[0]) * n
+    assert abs(expect.sum() / n - 1) < 0.02                      # pdf integrates to ~1 over the hemisphere
+    big = expect > 50
+    z = (hist[big] - expect[big]) / np.sqrt(expect[big])
+    assert np.abs(z).max() < 6 and abs(z.mean()) < 0.5 and z.std() < 1.6
+
+
+def test_fresnel(orc, mi, kats):
+    l = orc.lib(mi.abi)
+    l.orc_fresnel.argtypes = [C.c_float, C.c_float, C.c_void_p]
+    l.orc_fresnel_conductor.restype = C.c_float; l.orc_fresnel_conductor.argtypes = [C.c_float] * 3
+
+    def fr(c, eta):
+        out = np.zeros(4, dtype=np.float32); l.orc_fresnel(c, eta, _p(out)); return out
+    k = kats["fresnel"]
+    for c, eta, expected in k["cases"]:
+        assert np.allclose(fr(c, eta), expected, atol=1e-6)
+    F, ctt, _, scale = fr(np.cos(np.radians(45)), 1.5)
+    a = k["deg45_to_1p5"]
+    assert np.isclose(ctt, -np.cos(np.radians(a["cos_theta_t_deg"])), atol=1e-6) and np.isclose(F, 0.5 * (a["a_s"] ** 2 + a["a_p"] ** 2), atol=1e-6)
+    assert np.isclose((scale * np.sqrt(1 - np.cos(np.radians(45)) ** 2)) ** 2 + ctt ** 2, 1, atol=1e-6)
+    F, ctt, _, _ = fr(np.cos(np.radians(45)), 1 / 1.5)
+    assert np.isclose(F, 1) and np.isclose(ctt, 0)                          # total internal reflection
+    a = k["deg10_from_1p5"]
+    F, ctt, _, _ = fr(np.cos(np.radians(10)), 1 / 1.5)
+    assert np.isclose(ctt, -np.cos(np.radians(a["cos_theta_t_deg"])), atol=1e-6) and np.isclose(F, 0.5 * (a["a_s"] ** 2 + a["a_p"] ** 2), atol=1e-6)
+    # test_fresnel.py:56-66: conductor with a real IOR == dielectric; Snell's law (:69-75); index matched (:48-53)
+    for c in np.cos(np.linspace(0, np.pi / 2, 20)):
+        for eta in (1.5, 1 / 1.5):
+            assert np.isclose(fr(c, eta)[0], l.orc_fresnel_conductor(c, eta, 0.0), atol=2e-6)
+    for th in np.linspace(0, np.pi / 2, 20):
+        _, ctt, _, _ = fr(np.cos(th), 1.5)
+        assert abs(np.sin(th) - 1.5 * np.sin(np.arccos(-ctt))) < 1e-5
+    for c in np.linspace(-1, 1, 20):
+        F, ctt, _, _ = fr(c, 1.0)
+        assert F == 0 and abs(ctt + c) < 5e-7
+
+
+def _bsdf_desc(mi, props):
+    sc = mi.load_dict({"type": "scene", "r": {"type": "rectangle", "bsdf": props}})
+    d = sc.desc()
+    return sc, d.bsdfs[0]
+
+
+def test_dielectric_spot_check(orc, mi, kats):
+    k = kats["dielectric_spot_check"]
+    l = orc.lib(mi.abi)
+    l.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    sc, b = _bsdf_desc(mi, {"type": "dielectric", "specular_reflectance": 0.3, "specular_transmittance": 0.6, "int_ior": 1.5, "ext_ior": 1.0})
+    ang = np.radians(k["angle_deg"]); wi = np.array([np.sin(ang), 0, np.cos(ang)], dtype=np.float32)
+
+    def sample(wi, s1):
+        wo = np.zeros(3, dtype=np.float32); ped = np.zeros(3, dtype=np.float32); w = np.zeros(3, dtype=np.float32); s2 = np.zeros(2, dtype=np.float32)
+        l.orc_bsdf_sample(C.byref(b), _p(wi), s1, _p(s2), _p(wo), _p(ped), _p(w)); return wo, ped, w
+    wo, ped, w = sample(wi, 0.0)
+    assert np.isclose(ped[0], k["reflect_pdf"], atol=1e-6) and np.allclose(wo, [-np.sin(ang), 0, np.cos(ang)], atol=1e-6) and ped[2] == 1
+    assert np.allclose(w, 0.3)
+    wo, ped, w = sample(wi, 1.0)
+    a2 = np.radians(k["refract_angle_deg"])
+    assert np.isclose(ped[0], 1 - k["reflect_pdf"], atol=1e-6) and np.allclose(wo, [-np.sin(a2), 0, -np.cos(a2)], atol=1e-6)
+    assert np.isclose(ped[1], 1.5) and np.allclose(w, 0.6 / 1.5 ** 2, rtol=1e-5)     # radiance scaling eta_ti^2
+    wo2, ped2, _ = sample(wo.copy(), 1.0)
+    assert np.isclose(ped2[0], 1 - k["reflect_pdf"], atol=1e-5) and np.allclose(wo2, wi, atol=1e-5)
+
+
+def test_roughconductor_eval_pdf_sample_consistency(orc, mi):
+    """test_rough_conductor.py:98-117 + sampling identity: weight * pdf == eval at the sampled direction."""
+    l = orc.lib(mi.abi)
+    l.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.orc_bsdf_eval_pdf.argtypes = [C.c_void_p] * 5
+    rng = np.random.default_rng(1)
+    for props in ({"type": "roughconductor"}, {"type": "roughconductor", "distribution": "ggx", "alpha_u": 0.05, "alpha_v": 0.3, "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.2]},
+                  {"type": "roughconductor", "alpha": 0.3, "sample_visible": False, "eta": 1.5, "k": 0.5}):
+        sc, b = _bsdf_desc(mi, props)
+        for _ in range(50):
+            th = rng.uniform(0.05, 1.4); ph = rng.uniform(0, 2 * np.pi)
+            wi = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], dtype=np.float32)
+            s2 = rng.random(2).astype(np.float32)
+            wo = np.zeros(3, dtype=np.float32); ped = np.zeros(3, dtype=np.float32); w = np.zeros(3, dtype=np.float32)
+            l.orc_bsdf_sample(C.byref(b), _p(wi), 0.5, _p(s2), _p(wo), _p(ped), _p(w))
+            val = np.zeros(3, dtype=np.float32); pdf = np.zeros(1, dtype=np.float32)
+            l.orc_bsdf_eval_pdf(C.byref(b), _p(wi), _p(wo), _p(val), _p(pdf))
+            if w.max() > 0:
+                assert np.isclose(pdf[0], ped[0], rtol=2e-3, atol=1e-6)
+                assert np.allclose(w * ped[0], val, rtol=3e-3, atol=1e-6)
+            assert ped[1] == 1 and ped[2] == 0
+
+
+def test_sphere_shape(orc, mi):
+    T = mi.ScalarTransform4f
+    rot = T.rotate([1, 0, 0], 35)
+    s1 = mi.load_dict({"type": "sphere", "radius": 2.0, "center": [1, 0, 0], "to_world": rot})
+    s2 = mi.load_dict({"type": "sphere", "to_world": rot @ T.translate([1, 0, 0]) @ T.scale(2)})
+    assert np.allclose(s1.to_world.matrix, s2.to_world.matrix, atol=1e-6) and s1.primitive_count() == 1
+    assert np.isclose(mi.load_dict({"type": "sphere"}).surface_area(), 4 * np.pi)
+    for r in (1, 2, 4):
+        lo, hi = mi.load_dict({"type": "sphere", "radius": r}).bbox()
+        assert np.allclose(lo, -r) and np.allclose(hi, r)
+    # ray casting against the analytic answer (test_sphere.py:50-85): grid of parallel rays, hit iff x^2+y^2 <= r^2
+    for r in (1, 3):
+        sc = mi.load_dict({"type": "scene", "s": {"type": "sphere", "radius": r, "to_world": T.translate([0, 1, 0]) @ T.rotate([0, 1, 0], 30.0)}})
+        o = orc.OracleScene(sc, mi.abi)
+        n = 21
+        xs = (np.arange(n) + 0.5) / n * 2 * r - r
+        X, Y = np.meshgrid(xs, xs)
+        rays = np.zeros((n * n, 8), dtype=np.float32)
+        rays[:, 0] = X.ravel(); rays[:, 1] = Y.ravel() + 1; rays[:, 2] = -8; rays[:, 5] = 1; rays[:, 6] = np.finfo(np.float32).max
+        hits, si = o.ray_intersect(rays, with_si=True)
+        h = orc.unpack_hits(hits)
+        inside = (X.ravel() ** 2 + Y.ravel() ** 2) <= r * r
+        edge = np.abs(np.sqrt(X.ravel() ** 2 + Y.ravel() ** 2) - r) < 1e-3
+        assert np.array_equal(np.isfinite(h["t"])[~edge], inside[~edge])
+        ok = inside & ~edge
+        assert np.allclose(h["t"][ok], 8 - np.sqrt(r * r - X.ravel()[ok] ** 2 - Y.ravel()[ok] ** 2), atol=1e-4)
+        nrm = si[ok, 3:6]; p = si[ok, 0:3]
+        assert np.allclose(nrm, (p - [0, 1, 0]) / r, atol=1e-4) and np.allclose(np.linalg.norm(p - [0, 1, 0], axis=1), r, atol=1e-4)
+        assert (si[ok, 6] >= 0).all() and (si[ok, 6] <= 1).all() and (si[ok, 7] >= 0).all() and (si[ok, 7] <= 1).all()
