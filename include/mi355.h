@@ -125,11 +125,14 @@ typedef struct mi355_sensor_desc {
     uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height; /* Film::crop_* */
     uint32_t rfilter;                   /* MI355_RFILTER_* */
     float    rfilter_param;             /* gaussian: stddev (default 0.5); tent: radius */
-    /* realistic lens (src/sensors/realisticlens.cpp): sequential interface table */
+    /* realistic lens (src/sensors/realisticlens.cpp): interface table ordered from the film towards the world,
+       AFTER the constructor's fine focus (:899-905).  lens_count x 8 floats, metres:
+       type (0 sphere :345-424, 1 plane :427-493, 2 aperture stop :495-550), signed curvature radius, element radius,
+       z intercept, IOR on the film side, IOR on the world side (both at 589.3 nm, :169-179), 0, 0 */
     uint32_t lens_count;
-    const float *lens_data;             /* lens_count x 8: curvature_radius, thickness(z offset), eta_d, abbe_V, aperture_radius, conic K, type, reserved */
-    float    film_diagonal;             /* physical film diagonal [m] */
-    float    focus_distance;
+    const float *lens_data;
+    float    film_diagonal;             /* physical film diagonal [m] (film.cpp:46-48, film.h:193-198) */
+    float    focus_distance;            /* unused by the engine (focus is already baked into the table) */
 } mi355_sensor_desc;
 
 typedef struct mi355_scene_desc {
@@ -249,7 +252,7 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 /* How the replica's geometry was organised (cf. the accel statistics Scene logs, scene.cpp:108-118):
    out[0] flat parallelogram records, out[1] oriented-box records, out[2] meshes traversed through a BVH,
    out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6] analytic spheres,
-   out[7] feature bits (bit 0: glossy / specular BSDFs present -> general kernels). */
+   out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres, 4: realisticlens sensor; any bit -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
 
 /* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):

@@ -99,8 +99,8 @@ struct DScene {
     const DPrimFin *fins;
     const DBox     *boxes;        // parallelepiped meshes
     const DSphere  *spheres;
-    uint32_t n_spheres, features; // features: bit 0 = some BSDF is not `diffuse`, bit 1 = analytic spheres present;
-                                  // any bit set -> the kernels are instantiated with FULL = true
+    uint32_t n_spheres, features; // features: bit 0 = some BSDF is not `diffuse`, bit 1 = analytic spheres present,
+                                  // bit 2 = realisticlens sensor; any bit set -> kernels instantiated with FULL = true
     const uint32_t *bvh_shapes;   // shapes traversed through their BVH
     uint32_t n_prims, n_bvh_shapes, n_boxes;
     const DBsdf    *bsdfs;
@@ -114,6 +114,9 @@ struct DScene {
     uint32_t crop_w, crop_h, crop_x, crop_y;
     uint32_t rfilter; float filter_radius; float filter_coeff[10];
     float inv_emitter_count;
+    // realisticlens sensor: interface table (8 floats per interface, film -> world), physical half extents of the film
+    uint32_t sensor_type, lens_count; const float *lens; float film_px, film_py;
+    uint32_t film_w, film_h;
 };
 
 // -------------------------------------------------------------------------------------------
@@ -893,6 +896,77 @@ MI_DEV Ray sample_primary_ray(const DScene &sc, float pos_x, float pos_y) {
     ray.o = V3(tw[3], tw[7], tw[11]) + ray.d * near_t;
     ray.maxt = far_t - near_t;
     return ray;
+}
+
+// -------------------------------------------------------------------------------------------
+// RealisticLensCamera::sample_ray -- src/sensors/realisticlens.cpp:2209-2292 (rear-element sampling :1870-1878),
+// trace_ray_from_film :1654-1683, LensInterface::compute_interaction :269-297, SpheroidLens::intersect :359-397,
+// PlanoLens::intersect :444-468, ApertureStop::compute_interaction :505-517.
+// The interface table is indexed by a wave-uniform loop counter (scalar loads); every lane refracts its own ray.
+// -------------------------------------------------------------------------------------------
+MI_DEV bool lens_interact(const float *L, v3 &o, v3 &d) {
+    uint32_t kind = (uint32_t) L[0]; float R = L[1], er = L[2], z = L[3], n_left = L[4], n_right = L[5];
+    v3 p, n; float t;
+    if (kind == 0) {
+        v3 center = V3(0.f, 0.f, z + R);
+        v3 pc = center - o;
+        float center_proj = dot3(pc, d);
+        float perp = norm3(pc - d * center_proj);
+        float disc = R * R - perp * perp;
+        if (!(disc >= 0.f)) return false;
+        float sq = sqrtf(disc), near_t = center_proj - sq, far_t = center_proj + sq;
+        if (!(far_t >= 0.f)) return false;
+        bool convex = R > 0.f;
+        t = (convex != (d.z < 0.f)) ? (near_t >= 0.f ? near_t : MI_INF) : far_t;
+        if (!(t != MI_INF)) return false;
+        p = fma3s(d, t, o);
+        n = normalize3(p - center); if (!convex) n = -n;
+    } else {
+        n = V3(0.f, 0.f, -1.f);
+        float n_dot_d = dot3(n, d);
+        if (!(fabsf(n_dot_d) >= MI_EPS)) return false;
+        t = (n.z * z - dot3(n, o)) / n_dot_d;
+        if (!(t >= 0.f)) return false;
+        p = fma3s(d, t, o);
+    }
+    if (!((p.x * p.x + p.y * p.y) < er * er)) return false;
+    if (kind == 2) { o = p; return true; }
+    v3 wi = -d;
+    float cos_theta_i = dot3(wi, n), r, cos_theta_t, eta_it, eta_ti;
+    fresnel_(cos_theta_i, n_right / n_left, r, cos_theta_t, eta_it, eta_ti);
+    if (!(r <= 0.99999994f)) return false;
+    float k = fmaf(dot3(wi, n), eta_ti, cos_theta_t);                       // refract(wi, m, cos_theta_t, eta_ti), fresnel.h:309-313
+    d = V3(fmaf(n.x, k, -(wi.x * eta_ti)), fmaf(n.y, k, -(wi.y * eta_ti)), fmaf(n.z, k, -(wi.z * eta_ti)));
+    o = p;
+    return true;
+}
+MI_DEV float sample_lens_ray(const DScene &sc, float pos_x, float pos_y, float ap_x, float ap_y, Ray &ray) {
+    float sx = 1.f / (float) sc.crop_w, sy = 1.f / (float) sc.crop_h;
+    float ax = fmaf(pos_x, sx, -(float) sc.crop_x * sx), ay = fmaf(pos_y, sy, -(float) sc.crop_y * sy);
+    float rsx = (float) sc.crop_w / (float) sc.film_w, rsy = (float) sc.crop_h / (float) sc.film_h;
+    float rox = (float) sc.crop_x / (float) sc.film_w, roy = (float) sc.crop_y / (float) sc.film_h;
+    v3 film_p = V3(sc.film_px * (2.f * fmaf(ax, rsx, rox) - 1.f), sc.film_py * (2.f * fmaf(ay, rsy, roy) - 1.f), 0.f);
+    float dkx, dky; disk_concentric(ap_x, ap_y, dkx, dky);
+    v3 aperture_p = V3(sc.lens[2] * dkx, sc.lens[2] * dky, sc.lens[3]);
+    v3 o = film_p, d = normalize3(aperture_p - film_p);
+    bool active = true;
+    for (uint32_t i = 0; i < sc.lens_count; ++i) { v3 o2 = o, d2 = d; bool ok = lens_interact(sc.lens + 8 * i, o2, d2); if (active && ok) { o = o2; d = d2; } active = active && ok; }
+    const float *tw = sc.cam_to_world;
+    ray.o = xf_point(tw, o); ray.d = xf_vector(tw, d);
+    float inv_z = rcp_(d.z), near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;
+    ray.o = ray.o + ray.d * near_t; ray.maxt = far_t - near_t;
+    float c2 = d.z * d.z;
+    return active ? c2 * c2 : 0.f;
+}
+// render_sample head (integrator.cpp:433-455): pixel jitter, aperture sample when the sensor needs one, ray + ray weight
+template <bool FULL>
+MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, float &pos_x, float &pos_y, Ray &ray) {
+    pos_x = (float) px + next_1d(rng); pos_y = (float) py + next_1d(rng);                  // integrator.cpp:435
+    if (FULL && sc.sensor_type == MI355_SENSOR_REALISTICLENS) {
+        float ap_x = next_1d(rng), ap_y = next_1d(rng);                                    // needs_aperture_sample, :438-440
+        return sample_lens_ray(sc, pos_x, pos_y, ap_x, ap_y, ray);
+    }
+    ray = sample_primary_ray(sc, pos_x, pos_y); return 1.f;
 }
 
 struct Counters3 { uint32_t isect, shade, shadow; };

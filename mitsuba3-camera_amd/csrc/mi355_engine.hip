@@ -148,17 +148,19 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
         uint32_t y = li.pixel / sc.crop_w; li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
     } else li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
-    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);     // integrator.cpp:435
-    Ray ray = sample_primary_ray(sc, pos_x, pos_y);
+    float pos_x, pos_y; Ray ray;
+    float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
+    bool trace = li.act && cam_w > 0.f;                                    // rays blocked inside the lens carry weight 0
     Counters3 cnt = { 0, 0, 0 };
     v3 rgb; bool valid;
     if (INTEGRATOR == MI355_INTEGRATOR_PATH)
-        path_sample<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, li.act, stk, rgb, valid, cnt);
+        path_sample<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, trace, stk, rgb, valid, cnt);
     else {
         GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 };
-        prb_sample<false, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, li.act, stk,
+        prb_sample<false, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, trace, stk,
                           V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, rgb, valid, cnt);
     }
+    rgb = rgb * cam_w;                                                      // spec_u = ray_weight * spec, integrator.cpp:461
     __syncthreads();                                                        // traversal stack region is reused below
     if (OUT == OUT_LANES) {
         if (li.act) { float4 o = make_float4(rgb.x, rgb.y, rgb.z, valid ? 1.f : 0.f); reinterpret_cast<float4 *>(lanes_out)[i] = o; }
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
     uint32_t i = blockIdx.x * BLOCK + tid;
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
-    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);     // integrator.cpp:435
-    PathState st; path_init(st, sample_primary_ray(sc, pos_x, pos_y), rng);
+    float pos_x, pos_y; Ray ray0;
+    (void) camera_ray<false>(sc, rng, li.px, li.py, pos_x, pos_y, ray0);   // perspective sensors only (checked by the host)
+    PathState st; path_init(st, ray0, rng);
     Counters3 cnt = { 0, 0, 0 };
     fin[tid] = 0.f; fin[BLOCK + tid] = 0.f; fin[2 * BLOCK + tid] = 0.f; fin[3 * BLOCK + tid] = 0.f;
     uint32_t orig = tid;                       // which original slot the path in this thread belongs to
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
-    float pos_x = (float) li.px + next_1d(rng), pos_y = (float) li.py + next_1d(rng);
-    Ray ray = sample_primary_ray(sc, pos_x, pos_y);
+    float pos_x, pos_y; Ray ray;
+    float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
+    bool trace = li.act && cam_w > 0.f;
     // dL = adjoint of splat + develop: sum over taps of w(p) * grad_in[p] / W[p]   (hdrfilm.cpp:400); gw = grad_in / W
     Splat sp = splat_weights(sc, pos_x, pos_y);
     v3 dL = V3(0.f, 0.f, 0.f);
@@ -309,13 +313,14 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
                 dL.x = fmaf(g.x, w, dL.x); dL.y = fmaf(g.y, w, dL.y); dL.z = fmaf(g.z, w, dL.z);
             }
     }
+    dL = dL * cam_w;                                                        // value = L * weight, common.py:752
     Counters3 cnt = { 0, 0, 0 };
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
     GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE };
     Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
     v3 L, L2; bool valid;
-    prb_sample<false, FULL>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, li.act, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
-    prb_sample<true, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, li.act, stk, dL, L, sink, L2, valid, cnt);
+    prb_sample<false, FULL>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, trace, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
+    prb_sample<true, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, dL, L, sink, L2, valid, cnt);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
     // flush the texture-gradient queue: 12 consecutive lanes expand one record into its (tap, channel) atomics, so the
@@ -449,14 +454,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
@@ -662,7 +667,17 @@ static bool try_make_box(mi355_scene *s, uint32_t shape_index, const mi355_shape
 
 static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     const mi355_sensor_desc &se = d->sensor;
-    if (se.type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build");
+    if (se.type != MI355_SENSOR_PERSPECTIVE && se.type != MI355_SENSOR_REALISTICLENS)
+        return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build (perspective, realisticlens)");
+    if (se.type == MI355_SENSOR_REALISTICLENS) {
+        if (!se.lens_count || !se.lens_data || se.lens_count > 64) return fail(MI355_ERR_INVALID, "realisticlens needs 1..64 interfaces");
+        if (!(se.film_diagonal > 0.f)) return fail(MI355_ERR_INVALID, "realisticlens needs the physical film diagonal");
+        for (uint32_t i = 0; i < se.lens_count; ++i) {
+            const float *L = se.lens_data + 8 * i;
+            if (!(L[0] == 0.f || L[0] == 1.f || L[0] == 2.f) || !(L[2] > 0.f) || !(L[4] > 0.f) || !(L[5] > 0.f) || (L[0] == 0.f && L[1] == 0.f))
+                return fail(MI355_ERR_INVALID, "malformed lens interface row");
+        }
+    }
     if (!se.crop_width || !se.crop_height || !se.film_width || !se.film_height) return fail(MI355_ERR_INVALID, "empty film");
     DScene &ds = s->ds; memset(&ds, 0, sizeof(ds));
     s->spheres.clear();
@@ -795,7 +810,16 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
             coff[2] = { (int32_t) se.crop_offset_x, (int32_t) se.crop_offset_y };
     float c2s[16];
-    host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
+    if (se.type == MI355_SENSOR_PERSPECTIVE)
+        host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
+    else {
+        s->lens.assign(se.lens_data, se.lens_data + 8 * (size_t) se.lens_count);
+        float aspect = (float) se.film_height / (float) se.film_width;       // Film::get_physical_size, film.h:193-198
+        float x = sqrtf(se.film_diagonal * se.film_diagonal / (1.f + aspect * aspect));
+        ds.film_px = x / 2; ds.film_py = aspect * x / 2; ds.lens_count = se.lens_count;
+    }
+    ds.sensor_type = se.type; ds.film_w = se.film_width; ds.film_h = se.film_height;
+    if (se.type == MI355_SENSOR_REALISTICLENS) ds.features |= 4u;
     memcpy(ds.cam_to_world, se.to_world, 48);
     ds.near_clip = se.near_clip; ds.far_clip = se.far_clip;
     ds.crop_w = se.crop_width; ds.crop_h = se.crop_height; ds.crop_x = se.crop_offset_x; ds.crop_y = se.crop_offset_y;
@@ -823,6 +847,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
+    if ((rc = upload(&s->d_lens, s->lens))) return rc;
+    ds.lens = s->d_lens;
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
@@ -857,7 +883,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -959,8 +985,8 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
-    if (p->mode == MI355_MODE_WAVEFRONT && full)
-        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for all-diffuse scenes only");
+    if (p->mode == MI355_MODE_WAVEFRONT && (full || s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE))
+        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for all-diffuse scenes with a perspective sensor only");
     float *nof = nullptr;
     if (p->integrator == MI355_INTEGRATOR_PRB) {
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);

@@ -1,0 +1,233 @@
+"""Host side of the `realisticlens` sensor (src/sensors/realisticlens.cpp, fork-specific): lens prescriptions,
+dispersive glass models, and the thick-lens autofocus the reference runs in its constructor.  The per-sample work
+(film point -> rear element -> sequential refraction through the interfaces) runs on the device; this module only
+produces the flat interface table handed over through the C ABI (mi355_sensor_desc.lens_data).
+
+Interface table row (8 floats, metres): type (0 sphere, 1 plane, 2 aperture stop), curvature radius (signed, sphere only),
+element radius, z intercept on the optical axis, IOR on the film side ("left"), IOR on the world side ("right"), 0, 0.
+In RGB variants every glass is evaluated at the nominal wavelength 589.3 nm (realisticlens.cpp:169-179).
+"""
+import math
+
+import numpy as np
+
+SPHERE, PLANE, APERTURE = 0, 1, 2
+NOMINAL_WAVELENGTH_UM = 0.5893
+
+
+class DispersiveMaterial:
+    """realisticlens.cpp:147-241: Cauchy n = A + B / lambda^2, or 3-term Sellmeier; wavelengths in micrometres."""
+
+    def __init__(self, name, cauchy=None, sellmeier=None):
+        self.name = name
+        self.cauchy = None if cauchy is None else (np.float32(cauchy[0]), np.float32(cauchy[1]))
+        self.sellmeier = None if sellmeier is None else [(np.float32(b), np.float32(c)) for b, c in sellmeier]
+
+    def compute_ior(self, wavelength_um=NOMINAL_WAVELENGTH_UM):
+        w = np.float32(wavelength_um)
+        if self.cauchy is not None:
+            return np.float32(self.cauchy[0] + self.cauchy[1] / (w * w))
+        w2 = w * w
+        n = np.float32(1.0)
+        for b, c in self.sellmeier:
+            n = np.float32(n + b * w2 / (w2 - c))
+        return np.float32(np.sqrt(n))
+
+    def abbe_number(self):
+        return float((self.compute_ior(0.58756) - 1.0) / (self.compute_ior(0.4861) - self.compute_ior(0.6563)))
+
+
+AIR = DispersiveMaterial("Air", cauchy=(1.000277, 0.0))
+
+
+class Interface:
+    def __init__(self, kind, element_radius, z, left, right, curvature_radius=0.0):
+        self.kind = kind
+        self.curvature_radius = float(curvature_radius)
+        self.element_radius = float(element_radius)
+        self.z = float(z)
+        self.left, self.right = left, right      # materials on the film side / world side
+
+    def row(self):
+        return [float(self.kind), self.curvature_radius, self.element_radius, self.z,
+                float(self.left.compute_ior()), float(self.right.compute_ior()), 0.0, 0.0]
+
+
+# ---- scalar double-precision trace used only by the constructor-time autofocus ---------------------------------
+def _fresnel(cos_theta_i, eta):
+    outside = cos_theta_i >= 0
+    eta_it, eta_ti = (eta, 1 / eta) if outside else (1 / eta, eta)
+    ctt2 = 1 - (1 - cos_theta_i * cos_theta_i) * eta_ti * eta_ti
+    cia, cta = abs(cos_theta_i), math.sqrt(max(ctt2, 0.0))
+    if eta == 1:
+        r = 0.0
+    elif cia == 0:
+        r = 1.0
+    else:
+        a_s = (cia - eta_it * cta) / (cia + eta_it * cta); a_p = (cta - eta_it * cia) / (cta + eta_it * cia)
+        r = 0.5 * (a_s * a_s + a_p * a_p)
+    return r, (-cta if cos_theta_i >= 0 else cta), eta_ti
+
+
+def _interact(itf, o, d):
+    """LensInterface::compute_interaction (realisticlens.cpp:269-297) in float64.  Returns (o, d) or None."""
+    if itf.kind == SPHERE:
+        R = itf.curvature_radius
+        c = np.array([0.0, 0.0, itf.z + R])
+        pc = c - o
+        proj = float(pc @ d)
+        perp = np.linalg.norm(pc - proj * d)
+        disc = R * R - perp * perp
+        if disc < 0:
+            return None
+        sq = math.sqrt(disc); near, far = proj - sq, proj + sq
+        if far < 0:
+            return None
+        convex = R > 0
+        t = (near if near >= 0 else math.inf) if (convex != (d[2] < 0)) else far
+        if not math.isfinite(t):
+            return None
+        p = o + t * d
+        n = (p - c) / np.linalg.norm(p - c)
+        if not convex:
+            n = -n
+    else:
+        n = np.array([0.0, 0.0, -1.0])
+        nd = float(n @ d)
+        if abs(nd) < 5.96e-8:
+            return None
+        t = (n[2] * itf.z - float(n @ o)) / nd
+        if t < 0:
+            return None
+        p = o + t * d
+    if p[0] * p[0] + p[1] * p[1] >= itf.element_radius ** 2:
+        return None
+    if itf.kind == APERTURE:
+        return p, d
+    ext_ior, int_ior = float(itf.left.compute_ior()), float(itf.right.compute_ior())
+    cos_i = float(-d @ n)
+    r, cos_t, eta_ti = _fresnel(cos_i, int_ior / ext_ior)
+    if r > 1 - 5.96e-8:
+        return None
+    wi = -d
+    d_out = n * (float(wi @ n) * eta_ti + cos_t) - wi * eta_ti      # refract(), fresnel.h:309-313
+    return p, d_out
+
+
+def trace(interfaces, o, d, from_film=True):
+    o = np.asarray(o, dtype=np.float64); d = np.asarray(d, dtype=np.float64)
+    for itf in (interfaces if from_film else reversed(interfaces)):
+        r = _interact(itf, o, d)
+        if r is None:
+            return None
+        o, d = r
+    return o, d
+
+
+def _cardinal(start_o, end_o, end_d):
+    """compute_cardinal_points, realisticlens.cpp:2107-2113"""
+    t_focus = -end_o[0] / end_d[0]
+    z_f = end_o[2] + t_focus * end_d[2]
+    t_plane = (start_o[0] - end_o[0]) / end_d[0]
+    z_p = end_o[2] + t_plane * end_d[2]
+    return z_p, z_f
+
+
+def thick_lens_approximation(interfaces, film_half_width):
+    """compute_thick_lens_approximation, realisticlens.cpp:2115-2159"""
+    r = 0.001 * film_half_width
+    o = np.array([r, 0.0, interfaces[-1].z + 1.0])
+    res = trace(interfaces, o, [0, 0, -1.0], from_film=False)
+    if res is None:
+        raise RuntimeError("compute_thick_lens_approximation: world ray was not transmitted through lens!")
+    obj_plane, obj_focus = _cardinal(o, *res)
+    o2 = np.array([r, 0.0, interfaces[0].z - 1.0])
+    res2 = trace(interfaces, o2, [0, 0, 1.0], from_film=True)
+    if res2 is None:
+        raise RuntimeError("compute_thick_lens_approximation: film ray was not transmitted through lens!")
+    img_plane, img_focus = _cardinal(o2, *res2)
+    return obj_plane, obj_plane - obj_focus, img_plane, img_focus - img_plane      # p_img(back), f_img, p_obj(front), f_obj
+
+
+def focus_thick_lens(interfaces, film_half_width, focus_distance):
+    """focus_thick_lens, realisticlens.cpp:2161-2171"""
+    p_img, f_img, p_obj, f_obj = thick_lens_approximation(interfaces, film_half_width)
+    tmp = max(focus_distance, 4.01 * f_img) - p_obj
+    return 0.5 * (p_img - tmp + math.sqrt((p_img + tmp) ** 2 - 4 * f_img * (p_img + tmp)))
+
+
+# ---- prescriptions ------------------------------------------------------------------------------------------------
+def build_singlet(object_distance, curvature_radius, lens_radius):
+    """realisticlens.cpp:936-955"""
+    distance = max(object_distance, 4.001 * curvature_radius)
+    z = 0.5 * distance * (1 - math.sqrt(1 - 4 * curvature_radius / distance))
+    thickness = 2 * curvature_radius * (1 - math.sqrt(1 - (lens_radius / curvature_radius) ** 2))
+    glass = DispersiveMaterial("NBK7", cauchy=(1.5046, 5 * 0.00420))
+    return [Interface(SPHERE, lens_radius, z, AIR, glass, curvature_radius),
+            Interface(SPHERE, lens_radius, z + thickness, glass, AIR, -curvature_radius)]
+
+
+def build_doublet(object_distance, R, lens_radius):
+    """realisticlens.cpp:957-975"""
+    f = 2 * R
+    distance = max(object_distance, 4.001 * f)
+    z = 0.5 * distance * (1 - math.sqrt(1 - 4 * f / distance))
+    thickness = 2 * R * (1 - math.sqrt(1 - (lens_radius / R) ** 2))
+    g1 = DispersiveMaterial("NBK7", cauchy=(1.5046, 0.00420)); g2 = DispersiveMaterial("mod-NBK7", cauchy=(1.5046, 0.00860948454))
+    return [Interface(PLANE, lens_radius, z, AIR, g2), Interface(SPHERE, lens_radius, z + thickness, g2, g1, R),
+            Interface(SPHERE, lens_radius, z + 2 * thickness, g1, AIR, -R), Interface(APERTURE, lens_radius, z + 3 * thickness, AIR, AIR)]
+
+
+def build_from_data(kinds, thicknesses, curv_radii, elem_radii, mats, stop_ratio=1.0, scale=1.0):
+    """build_lens_from_data, realisticlens.cpp:1568-1652: tables are listed from the world side, in millimetres."""
+    out = []
+    z_pos = 0.0
+    for i in range(len(thicknesses) - 1, -1, -1):
+        z_pos += thicknesses[i]
+        er, z = 0.001 * scale * elem_radii[i], 0.001 * scale * z_pos
+        if kinds[i] == APERTURE:
+            out.append(Interface(APERTURE, er * stop_ratio, z, mats[i + 1], mats[i + 1]))
+        elif kinds[i] == PLANE:
+            out.append(Interface(PLANE, er, z, mats[i + 1], mats[i]))
+        else:
+            out.append(Interface(SPHERE, er, z, mats[i + 1], mats[i], -0.001 * scale * curv_radii[i]))
+    return out
+
+
+def build_exp1_doublet(cauchy_a, cauchy_b, stop_ratio=1.0):
+    """realisticlens.cpp:1283-1320 (the doublet of notebooks/doublet_full_optim)"""
+    glass_a = DispersiveMaterial("glass_A", cauchy=(1.4560798389592584, 0.021086562958141358))
+    glass_b = DispersiveMaterial("glass_B", cauchy=(cauchy_a, cauchy_b))
+    return build_from_data([APERTURE, SPHERE, SPHERE, SPHERE], [0.0, 3.0, 2.25291824, 46.74708176],
+                           [1000.0, 24.0, -24.0, -168.01068267], [8.0, 8.0, 8.0, 8.0], [AIR, AIR, glass_a, glass_b, AIR], stop_ratio)
+
+
+EXP1 = {"exp1a": (1.5689525390422485, 0.0263051608728981), "exp1b": (1.507009332993809, 0.04781645616233479),
+        "exp1c": (1.5030211256389316, 0.04920145883751409)}     # realisticlens.cpp:883-888
+UNSUPPORTED_DESIGNS = ("tessar", "helios", "jupiter", "fisheye", "gauss", "hypercentric", "asph", "exp2a", "exp2b", "exp2c")
+
+
+def build_lens(props, film_half_width):
+    """RealisticLensCamera ctor, realisticlens.cpp:832-907: prescription + fine focus.  Returns the interface list."""
+    design = str(props.get("lens_design", "singlet"))
+    object_distance = float(props.get("object_distance", 6.0))
+    focal_length = float(props.get("lens_focal_length", 0.05))
+    lens_diameter = float(props.get("lens_diameter", 0.01))
+    stop_ratio = float(props.get("stop_ratio", 1.0))
+    if design in UNSUPPORTED_DESIGNS:
+        raise NotImplementedError('lens_design "%s": prescription table not carried by this build (singlet, doublet, exp1a/b/c)' % design)
+    if design == "doublet":
+        itf = build_doublet(object_distance, focal_length / 2, lens_diameter / 2)
+    elif design in EXP1:
+        itf = build_exp1_doublet(*EXP1[design], stop_ratio=stop_ratio)
+    else:
+        itf = build_singlet(object_distance, focal_length, lens_diameter / 2)
+    delta = focus_thick_lens(itf, film_half_width, object_distance)
+    if not math.isnan(delta):
+        for i in itf:
+            i.z -= delta
+    return itf, delta
+
+
+def lens_table(interfaces):
+    return np.ascontiguousarray(np.array([i.row() for i in interfaces], dtype=np.float32))

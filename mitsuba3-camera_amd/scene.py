@@ -241,6 +241,14 @@ class Film:
         else:
             raise PluginError('rfilter plugin "%s" is outside the path (box, gaussian, tent)' % rt)
 
+        self.diagonal = 0.001 * float(props.get("diagonal", 35.0))          # fork: physical film diagonal [m], film.cpp:46-48
+
+    def physical_size(self):
+        """Film::get_physical_size (film.h:193-198): HALF extents in metres."""
+        aspect = float(self.height) / float(self.width)
+        x = math.sqrt(self.diagonal * self.diagonal / (1.0 + aspect * aspect))
+        return (x / 2, aspect * x / 2)
+
     def size(self): return (self.width, self.height)
     def crop_size(self): return (self.crop_width, self.crop_height)
     def crop_offset(self): return (self.crop_offset_x, self.crop_offset_y)
@@ -249,8 +257,9 @@ class Film:
 class Sensor:
     def __init__(self, props):
         t = props.get("type", "perspective")
-        if t != "perspective":
-            raise PluginError('sensor plugin "%s" is outside the path in this build (perspective)' % t)
+        if t not in ("perspective", "realisticlens"):
+            raise PluginError('sensor plugin "%s" is outside the path in this build (perspective, realisticlens)' % t)
+        self.type = abi.SENSOR_PERSPECTIVE if t == "perspective" else abi.SENSOR_REALISTICLENS
         self.film = Film(props.get("film", {}))
         self.to_world = props.get("to_world", Transform4f())
         if not isinstance(self.to_world, Transform4f):
@@ -258,7 +267,19 @@ class Sensor:
         if self.to_world.has_scale():
             raise PluginError("Scale factors in the camera-to-world transformation are not allowed!")
         self.near_clip = float(props.get("near_clip", 1e-2)); self.far_clip = float(props.get("far_clip", 1e4))
-        self.x_fov = float(np.float32(parse_fov(props, self.film.width / float(self.film.height))))
+        self.lens_table = None; self.interfaces = None
+        if self.type == abi.SENSOR_REALISTICLENS:       # realisticlens.cpp:832-907
+            from . import lens as _lens
+            if props.get("sample_exit_pupil", False):
+                raise PluginError("realisticlens: sample_exit_pupil=true (exit-pupil LUT) is not carried by this build")
+            try:
+                self.interfaces, self.focus_delta = _lens.build_lens(props, self.film.physical_size()[0])
+            except NotImplementedError as e:
+                raise PluginError(str(e))
+            self.lens_table = _lens.lens_table(self.interfaces)
+            self.x_fov = 0.0
+        else:
+            self.x_fov = float(np.float32(parse_fov(props, self.film.width / float(self.film.height))))
         smp = props.get("sampler", {"type": "independent"})
         if smp.get("type", "independent") != "independent":
             raise PluginError('sampler plugin "%s" is outside the path (independent)' % smp.get("type"))
@@ -322,7 +343,11 @@ class Scene:
         d.n_shapes, d.n_bsdfs, d.n_emitters, d.n_textures = len(self.shapes), len(self.bsdfs), len(self.emitters), len(self.textures)
         d.shapes, d.bsdfs, d.emitters, d.textures = sh, bs, em, tex
         se, f = self.sensor, self.sensor.film
-        d.sensor.type = abi.SENSOR_PERSPECTIVE
+        d.sensor.type = se.type
+        if se.lens_table is not None:
+            d.sensor.lens_count = se.lens_table.shape[0]
+            d.sensor.lens_data = se.lens_table.ctypes.data_as(abi.f32p); keep.append(se.lens_table)
+        d.sensor.film_diagonal = f.diagonal
         d.sensor.to_world[:] = se.to_world.affine12().tolist()
         d.sensor.x_fov, d.sensor.near_clip, d.sensor.far_clip = se.x_fov, se.near_clip, se.far_clip
         d.sensor.film_width, d.sensor.film_height = f.width, f.height
@@ -458,13 +483,13 @@ def load_dict(d):
         vt = v.get("type")
         if vt in ("path", "prb"):
             scene.integrator_props = dict(v)
-        elif vt in ("perspective",):
+        elif vt in ("perspective", "realisticlens"):
             scene.sensor = Sensor(v)
         elif vt in ("diffuse", "roughconductor", "dielectric"):
             named[key] = _make_bsdf(scene, v, key)
         elif vt in ("rectangle", "cube", "obj", "mesh", "sphere"):
             pending_shapes.append((key, v))
-        elif vt in ("thinlens", "orthographic", "realisticlens", "radialwarp", "volpath", "direct", "ptracer", "aov",
+        elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "ptracer", "aov",
                     "disk", "cylinder", "ply", "serialized", "constant", "point", "envmap", "directional",
                     "conductor", "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)

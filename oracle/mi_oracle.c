@@ -283,6 +283,7 @@ typedef struct {
     mi355_sensor_desc sensor;
     float sample_to_camera[16], camera_to_sample[16];
     float filter_coeff[10]; float filter_radius;
+    float *lens; uint32_t lens_count; float film_px, film_py;   /* realisticlens: interface table, physical half extents */
     uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
 } OScene;
 
@@ -341,6 +342,14 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
     int32_t off[2] = { (int32_t) d->sensor.crop_offset_x, (int32_t) d->sensor.crop_offset_y };
     perspective_projection(film, crop, off, d->sensor.x_fov, d->sensor.near_clip, d->sensor.far_clip,
                            s->camera_to_sample, s->sample_to_camera);
+    if (d->sensor.type == MI355_SENSOR_REALISTICLENS) {
+        s->lens_count = d->sensor.lens_count;
+        s->lens = (float *) dupmem(d->sensor.lens_data, 32u * d->sensor.lens_count);
+        s->sensor.lens_data = s->lens;
+        float aspect = (float) d->sensor.film_height / (float) d->sensor.film_width;      /* Film::get_physical_size, film.h:193-198 */
+        float x = sqrtf(d->sensor.film_diagonal * d->sensor.film_diagonal / (1.f + aspect * aspect));
+        s->film_px = x / 2; s->film_py = aspect * x / 2;
+    }
     if (d->sensor.rfilter == MI355_RFILTER_GAUSSIAN) {
         orc_gaussian_coeffs(d->sensor.rfilter_param, s->filter_coeff); s->filter_radius = 4.f * d->sensor.rfilter_param;
     } else if (d->sensor.rfilter == MI355_RFILTER_TENT) s->filter_radius = d->sensor.rfilter_param;
@@ -351,7 +360,7 @@ ORC_API void orc_scene_destroy(OScene *s) {
     if (!s) return;
     for (uint32_t i = 0; i < s->n_shapes; ++i) { free(s->shapes[i].pos); free(s->shapes[i].nrm); free(s->shapes[i].uv); free(s->shapes[i].faces); }
     for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
-    free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s);
+    free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s->lens); free(s);
 }
 /* SceneParameters.update for one parameter: src/python/python/util.py:185-232 */
 ORC_API int orc_scene_set_param(OScene *s, uint32_t kind, uint32_t index, const float *v, uint64_t n) {
@@ -976,6 +985,68 @@ static Ray sample_primary_ray(const OScene *sc, v2 sample_pos) {
 }
 
 /* ----------------------------------------------------------------------------------------
+ * RealisticLensCamera::sample_ray -- src/sensors/realisticlens.cpp:2209-2292 (rear-element sampling, :1870-1878),
+ * trace_ray_from_film :1654-1683, LensInterface::compute_interaction :269-297, SpheroidLens::intersect :359-397,
+ * PlanoLens::intersect :444-468, ApertureStop::compute_interaction :505-517.  Returns the ray weight (cos^4, 0 if blocked).
+ * ---------------------------------------------------------------------------------------- */
+static int lens_interact(const float *L, v3 *o, v3 *d) {
+    uint32_t kind = (uint32_t) L[0]; float R = L[1], er = L[2], z = L[3], n_left = L[4], n_right = L[5];
+    v3 p, n; float t;
+    if (kind == 0) {
+        v3 center = V3(0.f, 0.f, z + R);
+        v3 pc = sub3(center, *o);
+        float center_proj = dot3(pc, *d);
+        float perp = norm3(sub3(pc, scale3(*d, center_proj)));
+        float disc = R * R - perp * perp;
+        if (!(disc >= 0.f)) return 0;
+        float sq = sqrtf(disc), near_t = center_proj - sq, far_t = center_proj + sq;
+        if (!(far_t >= 0.f)) return 0;
+        int convex = R > 0.f;
+        t = (convex != (d->z < 0.f)) ? (near_t >= 0.f ? near_t : INFINITY) : far_t;
+        p = fma3s(*d, t, *o);
+        n = normalize3(sub3(p, center)); if (!convex) n = neg3(n);
+        if (!(t != INFINITY)) return 0;
+    } else {
+        n = V3(0.f, 0.f, -1.f);
+        float n_dot_d = dot3(n, *d);
+        if (!(fabsf(n_dot_d) >= ORC_EPS)) return 0;
+        t = (n.z * z - dot3(n, *o)) / n_dot_d;
+        if (!(t >= 0.f)) return 0;
+        p = fma3s(*d, t, *o);
+    }
+    if (!((p.x * p.x + p.y * p.y) < er * er)) return 0;
+    if (kind == 2) { *o = p; return 1; }
+    v3 wi = neg3(*d);
+    float cos_theta_i = dot3(wi, n), eta = n_right / n_left;
+    float r, cos_theta_t, eta_it, eta_ti; fresnel_(cos_theta_i, eta, &r, &cos_theta_t, &eta_it, &eta_ti);
+    if (!(r <= 0.99999994f)) return 0;
+    float k = fmaf(dot3(wi, n), eta_ti, cos_theta_t);                   /* refract(wi, m, cos_theta_t, eta_ti), fresnel.h:309-313 */
+    *d = V3(fmaf(n.x, k, -(wi.x * eta_ti)), fmaf(n.y, k, -(wi.y * eta_ti)), fmaf(n.z, k, -(wi.z * eta_ti)));
+    *o = p;
+    return 1;
+}
+static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample, Ray *ray_out) {
+    float sx = 1.f / (float) sc->sensor.crop_width, sy = 1.f / (float) sc->sensor.crop_height;
+    float ax = fmaf(sample_pos.x, sx, -(float) sc->sensor.crop_offset_x * sx), ay = fmaf(sample_pos.y, sy, -(float) sc->sensor.crop_offset_y * sy);
+    /* m_sample_to_film = inverse of film_to_crop_transform (sensor.h:308-345): crop -> NDC -> physical film */
+    float rsx = (float) sc->sensor.crop_width / (float) sc->sensor.film_width, rsy = (float) sc->sensor.crop_height / (float) sc->sensor.film_height;
+    float rox = (float) sc->sensor.crop_offset_x / (float) sc->sensor.film_width, roy = (float) sc->sensor.crop_offset_y / (float) sc->sensor.film_height;
+    v3 film_p = V3(sc->film_px * (2.f * fmaf(ax, rsx, rox) - 1.f), sc->film_py * (2.f * fmaf(ay, rsy, roy) - 1.f), 0.f);
+    const float *L0 = sc->lens;
+    v2 dk = square_to_uniform_disk_concentric(aperture_sample);
+    v3 aperture_p = V3(L0[2] * dk.x, L0[2] * dk.y, L0[3]);              /* sample_rear_element, :1870-1878 */
+    v3 o = film_p, d = normalize3(sub3(aperture_p, film_p));
+    int active = 1;
+    for (uint32_t i = 0; i < sc->lens_count && active; ++i) active = lens_interact(sc->lens + 8 * i, &o, &d);
+    const float *tw = sc->sensor.to_world;
+    ray_out->o = xf_point(tw, o); ray_out->d = xf_vector(tw, d);
+    float inv_z = rcpf_(d.z), near_t = sc->sensor.near_clip * inv_z, far_t = sc->sensor.far_clip * inv_z;
+    ray_out->o = add3(ray_out->o, scale3(ray_out->d, near_t)); ray_out->maxt = far_t - near_t;
+    float ct = d.z, c2 = ct * ct;
+    return active ? c2 * c2 : 0.f;
+}
+
+/* ----------------------------------------------------------------------------------------
  * PathIntegrator::sample -- src/integrators/path.cpp:95-287 (JIT masking semantics)
  * ---------------------------------------------------------------------------------------- */
 typedef struct { uint64_t isect, shade, shadow; } Cnt;
@@ -1204,14 +1275,24 @@ static void shard_bounds(const OScene *sc, const mi355_render_params *rp, uint32
     *p0 = rp->pixel_begin; *pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin;
     *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : rp->spp - rp->spp_begin;
 }
+/* render_sample head (integrator.cpp:433-455): pixel jitter, aperture sample if the sensor needs one, ray + ray weight */
+static float camera_ray(const OScene *sc, pcg32 *rng, uint32_t lane, uint32_t spp, v2 *sp, Ray *ray) {
+    int32_t px, py; lane_to_pixel(sc, lane, spp, &px, &py);
+    sp->x = (float) px + pcg32_float(rng); sp->y = (float) py + pcg32_float(rng);          /* integrator.cpp:435 */
+    if (sc->sensor.type == MI355_SENSOR_REALISTICLENS) {
+        v2 ap; ap.x = pcg32_float(rng); ap.y = pcg32_float(rng);                         /* needs_aperture_sample, :438-440 */
+        return sample_lens_ray(sc, *sp, ap, ray);
+    }
+    *ray = sample_primary_ray(sc, *sp); return 1.f;
+}
 static void trace_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane, v3 *rgb, int *valid, v2 *pos, Cnt *cnt) {
     pcg32 rng; sampler_seed(&rng, rp->seed, lane);
-    int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
-    v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);   /* integrator.cpp:435 */
-    Ray ray = sample_primary_ray(sc, sp);
+    Ray ray; float w = camera_ray(sc, &rng, lane, rp->spp, pos, &ray);
+    *rgb = V3(0, 0, 0); *valid = 0;
+    if (w == 0.f) return;                                               /* blocked by the lens barrel: weight 0, path not traced */
     if (rp->integrator == MI355_INTEGRATOR_PRB) prb_sample(sc, &rng, ray, rp, 0, V3(0,0,0), V3(0,0,0), NULL, rgb, valid, cnt);
     else path_sample(sc, &rng, ray, rp, rgb, valid, cnt);
-    *pos = sp;
+    *rgb = scale3(*rgb, w);                                             /* spec_u = ray_weight * spec, integrator.cpp:461 */
 }
 /* per-lane radiance for lanes [lane_begin, lane_begin+count): out = count x 4 (r,g,b,valid) */
 ORC_API void orc_lane_radiance(OScene *sc, const mi355_render_params *rp, uint32_t lane_begin, uint32_t count, float *out) {
@@ -1331,10 +1412,9 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
         for (int64_t p = (int64_t) p0; p < (int64_t) (p0 + pn); ++p) for (uint32_t s = s0; s < s0 + sn; ++s) {
             uint32_t lane = (uint32_t) p * rp->spp + s;
             pcg32 rng; sampler_seed(&rng, rp->seed, lane);
-            int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
-            v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);
-            Ray ray = sample_primary_ray(sc, sp);
-            v3 dL = delta_L(sc, sp, grad_in, weight_hw);
+            v2 sp; Ray ray; float cw = camera_ray(sc, &rng, lane, rp->spp, &sp, &ray);
+            if (cw == 0.f) continue;
+            v3 dL = scale3(delta_L(sc, sp, grad_in, weight_hw), cw);       /* value = L * weight, common.py:752 */
             pcg32 rng2 = rng;                                            /* sampler.clone(), common.py:767 */
             v3 L; int valid;
             prb_sample(sc, &rng2, ray, rp, 0, V3(0,0,0), V3(0,0,0), NULL, &L, &valid, &cnt);
@@ -1368,6 +1448,13 @@ ORC_API void orc_primary_rays(OScene *sc, const float *sample_pos, uint32_t n, f
     for (uint32_t i = 0; i < n; ++i) {
         v2 p = { sample_pos[2*i], sample_pos[2*i+1] }; Ray r = sample_primary_ray(sc, p); float *o = rays + 8 * i;
         o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.maxt; o[7] = 0;
+    }
+}
+/* RealisticLensCamera::sample_ray on caller samples: rays n x 8 (o, d, maxt, weight) */
+ORC_API void orc_lens_rays(OScene *sc, const float *sample_pos, const float *aperture, uint32_t n, float *rays) {
+    for (uint32_t i = 0; i < n; ++i) {
+        v2 p = { sample_pos[2*i], sample_pos[2*i+1] }, a = { aperture[2*i], aperture[2*i+1] }; Ray r; float w = sample_lens_ray(sc, p, a, &r); float *o = rays + 8 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.maxt; o[7] = w;
     }
 }
 ORC_API float orc_shape_surface_area(const OScene *sc, uint32_t shape) { return 1.f / sc->shapes[shape].inv_area; }

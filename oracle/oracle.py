@@ -64,6 +64,7 @@ def lib(abi):
     l.orc_render_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     l.orc_ray_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     l.orc_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    l.orc_lens_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     l.orc_shape_surface_area.restype = C.c_float
     l.orc_shape_surface_area.argtypes = [C.c_void_p, C.c_uint32]
     l.orc_texture_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
@@ -157,6 +158,12 @@ class OracleScene:
         sp = np.ascontiguousarray(sample_pos, dtype=np.float32).reshape(-1, 2)
         rays = np.empty((sp.shape[0], 8), dtype=np.float32)
         self.l.orc_primary_rays(self.h, _p(sp), sp.shape[0], _p(rays))
+        return rays
+
+    def lens_rays(self, sample_pos, aperture):
+        sp = np.ascontiguousarray(sample_pos, dtype=np.float32).reshape(-1, 2); ap = np.ascontiguousarray(aperture, dtype=np.float32).reshape(-1, 2)
+        rays = np.empty((sp.shape[0], 8), dtype=np.float32)
+        self.l.orc_lens_rays(self.h, _p(sp), _p(ap), sp.shape[0], _p(rays))
         return rays
 
     def surface_area(self, shape):

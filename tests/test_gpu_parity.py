@@ -300,6 +300,43 @@ def test_veach_render_and_backward(mi, orc, torch_cuda, veach64):
     assert abs(tot - img6.sum()) < 2e-3 * img6.sum()
 
 
+# ---- scope row (f)-1: realistic-lens primary rays -----------------------------------------------------------
+def _lens_cbox(mi, design, res=32):
+    T = mi.ScalarTransform4f
+    d = mi.cornell_box()
+    d["sensor"] = {"type": "realisticlens", "lens_design": design, "object_distance": 3.9, "lens_focal_length": 0.05, "lens_diameter": 0.02,
+                   "near_clip": 0.001, "far_clip": 100.0, "to_world": T.look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0]),
+                   "sampler": {"type": "independent", "sample_count": 16},
+                   "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}, "pixel_format": "rgb", "diagonal": 30.0}}
+    return mi.load_dict(d)
+
+
+@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a"])
+def test_realisticlens_matches_oracle(mi, orc, torch_cuda, design):
+    torch = torch_cuda
+    scene = _lens_cbox(mi, design)
+    o = orc.OracleScene(scene, mi.abi)
+    integ = mi.PRBIntegrator({"max_depth": 5, "rr_depth": 3})
+    spp, seed = 8, 13
+    n = 32 * 32 * spp
+    ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
+    got = integ.lane_radiance(scene, seed, spp, 0, n).cpu().numpy()
+    close = np.isclose(got[:, :3], ref[:, :3], rtol=2e-4, atol=1e-5).all(axis=1) & (got[:, 3] == ref[:, 3])
+    assert close.mean() > 0.998, "diverged lanes: %g" % (1 - close.mean())
+    assert ref[:, :3].max() > 0 and (ref[:, 3] == 0).any()                  # some rays are vignetted / miss
+    img = integ.render(scene, seed=3, spp=16).cpu().numpy()
+    img_ref, _ = o.render(o.params(integ, 3, 16))
+    assert np.abs(img - img_ref).max() < 1e-3 * img_ref.max()
+    params = mi.traverse(scene)
+    gin = np.random.default_rng(2).normal(size=(32, 32, 3)).astype(np.float32)
+    g = integ.render_backward(scene, params, torch.tensor(gin), seed=9, spp=16).cpu().numpy()
+    g_ref = o.render_backward(o.params(integ, 9, 16), gin)
+    assert np.allclose(g, g_ref, rtol=5e-3, atol=2e-3 * np.abs(g_ref).max())
+    wf = mi.PathIntegrator(); wf.mode = mi.abi.MODE_WAVEFRONT
+    with pytest.raises(mi.Mi355Error):
+        wf.render(scene, seed=1, spp=4)
+
+
 # ---- PRB adjoint --------------------------------------------------------------------------------------
 def _textured_cbox(mi, res=32):
     d = small_cbox(mi, res)

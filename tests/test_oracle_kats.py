@@ -492,3 +492,72 @@ def test_sphere_shape(orc, mi):
         nrm = si[ok, 3:6]; p = si[ok, 0:3]
         assert np.allclose(nrm, (p - [0, 1, 0]) / r, atol=1e-4) and np.allclose(np.linalg.norm(p - [0, 1, 0], axis=1), r, atol=1e-4)
         assert (si[ok, 6] >= 0).all() and (si[ok, 6] <= 1).all() and (si[ok, 7] >= 0).all() and (si[ok, 7] <= 1).all()
+
+
+# ---- scope row (f)-1: realistic lens camera --------------------------------------------------------------------
+def test_lens_materials(mi):
+    """The reference's only pins for the fork-specific lens code: inline asserts of realisticlens.cpp:2444-2461."""
+    from mitsuba3_camera_amd import lens
+    m = lens.DispersiveMaterial("BK7", cauchy=(1.5046, 0.00420))
+    assert np.allclose([m.compute_ior(w) for w in (2.3254, 0.5893, 0.3126)], [1.505376701, 1.516694179, 1.547580488], rtol=1e-6)
+    m2 = lens.DispersiveMaterial("NBK7", sellmeier=[(1.03961212, 0.006000699), (0.231792344, 0.020017914), (1.01046945, 103.560653)])
+    assert np.allclose([m2.compute_ior(w) for w in (2.3254, 0.5893, 0.3126)], [1.489211725, 1.516727674, 1.548606931], rtol=1e-6)
+    assert 60 < m2.abbe_number() < 68          # N-BK7: V_d ~ 64.2
+
+
+def _lens_scene(mi, design, res=32, diagonal=30.0, **extra):
+    T = mi.ScalarTransform4f
+    d = mi.cornell_box()
+    d["sensor"] = dict({"type": "realisticlens", "lens_design": design, "object_distance": 3.9, "lens_focal_length": 0.05, "lens_diameter": 0.02,
+                        "near_clip": 0.001, "far_clip": 100.0, "to_world": T.look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0]),
+                        "sampler": {"type": "independent", "sample_count": 16},
+                        "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}, "pixel_format": "rgb", "diagonal": diagonal}}, **extra)
+    return mi.load_dict(d)
+
+
+@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a"])
+def test_lens_focus_and_trace(orc, mi, design):
+    """Paraxial self-check in the spirit of notebooks/scripts/lens_design/design_problem.py:430-472: after the constructor's
+    thick-lens fine focus (realisticlens.cpp:899-905, :2161-2171) rays leaving one film point through different points of a
+    small central aperture zone meet again at the focus distance; the chief ray of an off-axis film point leaves on the other
+    side of the axis (inverting lens); weights are cos^4 and blocked rays carry weight 0."""
+    sc = _lens_scene(mi, design, 64)
+    o = orc.OracleScene(sc, mi.abi)
+    n = 64
+    rng = np.random.default_rng(0)
+    ap = 0.5 + (rng.random((n, 2), dtype=np.float32) - 0.5) * 0.15       # paraxial zone of the rear element
+    for px in ([32.0, 32.0], [40.0, 28.0]):
+        rays = o.lens_rays(np.tile(np.array(px, dtype=np.float32), (n, 1)), ap)
+        ok = rays[:, 7] > 0
+        assert ok.mean() > 0.9
+        r = rays[ok]
+        # camera looks down -z from z = 3.9: focus plane is z = 0
+        t = (0.0 - r[:, 2]) / r[:, 5]
+        hit = r[:, 0:3] + t[:, None] * r[:, 3:6]
+        spread = hit[:, :2].std(axis=0).max()
+        assert spread < 2e-3, (design, px, spread)                              # << the 2 m scene width
+        c4 = (r[:, 3:6] @ np.array([0, 0, -1.0])) ** 4
+        assert np.allclose(r[:, 7], c4, rtol=1e-4)
+        if px[0] != 32.0:                                                       # +x/-y on the film -> same side in the image (upright mapping, like perspective)
+            assert abs(hit[:, 0].mean()) > 1e-3
+    wide = o.lens_rays(np.tile(np.array([32.0, 32.0], dtype=np.float32), (256, 1)), rng.random((256, 2), dtype=np.float32))
+    assert (wide[:, 7] >= 0).all() and (wide[:, 7] <= 1 + 1e-5).all()
+    with pytest.raises(mi.PluginError):
+        _lens_scene(mi, "tessar")
+
+
+def test_lens_render_oracle(orc, mi):
+    sc = _lens_scene(mi, "doublet", 32, diagonal=50.0)
+    o = orc.OracleScene(sc, mi.abi)
+    integ = mi.PathIntegrator({"max_depth": 4})
+    img, n = o.render(o.params(integ, 0, 16))
+    assert np.isfinite(img).all() and img.mean() > 0.01
+    sc_p = mi.load_dict(small_cbox_for(mi, 32))
+    ref, _ = orc.OracleScene(sc_p, mi.abi).render(o.params(integ, 0, 16))
+    # same framing as the 39.3 deg pinhole would need a matched focal length; just check the gross structure: red left, green right
+    assert img[12:20, 2:6, 0].mean() > 2 * img[12:20, 2:6, 1].mean() and img[12:20, 26:30, 1].mean() > 1.5 * img[12:20, 26:30, 0].mean()
+
+
+def small_cbox_for(mi, res):
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    return d
