@@ -176,8 +176,12 @@ def main():
         orc = load_oracle()
         o = orc.OracleScene(scene, mi.abi)
         threads = o.l.orc_num_threads()
-        t0 = time.perf_counter(); _, n = o.render(o.params(integ, 0, 1)); t1 = time.perf_counter() - t0
-        spp_cpu = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
+        # two calibration points -> fixed cost + per-spp cost, then size the sample for ~cpu_seconds (10-30 s) of CPU work
+        o.render(o.params(integ, 0, 1))
+        t0 = time.perf_counter(); o.render(o.params(integ, 0, 2)); ta = time.perf_counter() - t0
+        t0 = time.perf_counter(); o.render(o.params(integ, 0, 10)); tb = time.perf_counter() - t0
+        per_spp = max((tb - ta) / 8.0, 1e-4); fixed = max(ta - 2 * per_spp, 0.0)
+        spp_cpu = int(max(1, min(4096, round((args.cpu_seconds - fixed) / per_spp))))
         t0 = time.perf_counter(); _, n = o.render(o.params(integ, 0, spp_cpu)); t2 = time.perf_counter() - t0
         cpu = {"value": round(n / t2 / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
                "sample": "same scene/integrator, %dx%d @ %d spp (%d lanes, %.1f s), oracle/mi_oracle.c with OpenMP" % (W, H, spp_cpu, n, t2)}

@@ -15,6 +15,8 @@ from .scene import (Scene, Shape, BSDF, Emitter, Texture, Sensor, Film, PluginEr
 from .integrators import (Integrator, PathIntegrator, PRBIntegrator, make_integrator, SceneParameters, traverse, render,
                           sample_tea_32, shard_pixels, scene_param_layout)
 
+from .optimizers import Adam, SGD, Optimizer
+
 __all__ = [n for n in dir() if not n.startswith("_")]
 _variant = "hip_ad_rgb"
 

@@ -291,7 +291,7 @@ class SceneParameters:
 
     def update(self, values=None):
         torch = _torch()
-        if values:
+        if values is not None:
             for k, v in values.items():
                 self[k] = v
         for key in sorted(self._dirty):

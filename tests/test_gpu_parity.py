@@ -419,3 +419,12 @@ def test_errors_are_loud(mi, torch_cuda, cbox32):
     p = mi.PathIntegrator()._params(cbox32, 0, 4, shard=(1000, 100))
     with pytest.raises(mi.Mi355Error):
         mi.abi.check(mi.abi.lib().mi355_render_accumulate(cbox32.handle(), C.byref(p), C.c_void_p(film.data_ptr()), None))
+
+
+def test_inverse_rendering_loop(mi, torch_cuda):
+    """End-to-end: mi.render op + PRB backward + Adam recover the red wall's albedo (examples/optimize_albedo.py)."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "optimize_albedo.py")
+    spec = importlib.util.spec_from_file_location("optimize_albedo", path); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    losses, errs = m.main(iterations=30, res=48, spp=16, verbose=False)
+    assert errs[-1] < 0.25 * errs[0] and min(losses[-5:]) < 0.7 * losses[0]      # the loss floor is Monte Carlo noise
