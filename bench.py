@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -60,12 +62,17 @@ def main():
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     mi = load_package()
     lib = mi.abi.lib()
@@ -80,6 +87,7 @@ def main():
     npix = W * H
     n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
     my_tiles = [t for t in range(n_tiles) if t % world == rank]
+    my_shard = mi.shard_tiles(W, H, rank, world, rows=TILE_ROWS)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     img = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -90,10 +98,8 @@ def main():
             p = integ._params(scene, seed, args.spp)
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
         else:
-            for t in my_tiles:
-                b = t * TILE_ROWS * W; n = min(TILE_ROWS * W, npix - b)
-                p = integ._params(scene, seed, args.spp, shard=(b, n))
-                mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
+            p = integ._params(scene, seed, args.spp, shard=my_shard)      # all of this rank's tiles in ONE launch
+            mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
             dist.all_reduce(film, op=dist.ReduceOp.SUM)
         mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
 
@@ -176,12 +182,16 @@ def main():
         orc = load_oracle()
         o = orc.OracleScene(scene, mi.abi)
         threads = o.l.orc_num_threads()
-        # two calibration points -> fixed cost + per-spp cost, then size the sample for ~cpu_seconds (10-30 s) of CPU work
+        # ramp the calibration sample until it takes >= 2 s (so the per-thread film setup is amortised), then scale it
+        # linearly to ~cpu_seconds (10-30 s) of CPU work
         o.render(o.params(integ, 0, 1))
-        t0 = time.perf_counter(); o.render(o.params(integ, 0, 2)); ta = time.perf_counter() - t0
-        t0 = time.perf_counter(); o.render(o.params(integ, 0, 10)); tb = time.perf_counter() - t0
-        per_spp = max((tb - ta) / 8.0, 1e-4); fixed = max(ta - 2 * per_spp, 0.0)
-        spp_cpu = int(max(1, min(4096, round((args.cpu_seconds - fixed) / per_spp))))
+        spp_cal = 8
+        while True:
+            t0 = time.perf_counter(); o.render(o.params(integ, 0, spp_cal)); tc = time.perf_counter() - t0
+            if tc >= 2.0 or spp_cal >= 1024:
+                break
+            spp_cal *= 4
+        spp_cpu = int(max(1, min(4096, round(spp_cal * args.cpu_seconds / tc))))
         t0 = time.perf_counter(); _, n = o.render(o.params(integ, 0, spp_cpu)); t2 = time.perf_counter() - t0
         cpu = {"value": round(n / t2 / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
                "sample": "same scene/integrator, %dx%d @ %d spp (%d lanes, %.1f s), oracle/mi_oracle.c with OpenMP" % (W, H, spp_cpu, n, t2)}
@@ -191,7 +201,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
-                          "lanes_per_step": lanes_per_step, "mode": "fused", "sharding": "16-row tiles round-robin, film all-reduce" if world > 1 else "none"},
+                          "lanes_per_step": lanes_per_step, "mode": "fused", "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         print(json.dumps(out), flush=True)
     scene.release()

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 1u
+#define MI355_ABI_VERSION 2u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -171,6 +171,12 @@ typedef struct mi355_render_params {
        Zero counts mean "everything". */
     uint32_t pixel_begin, pixel_count;
     uint32_t spp_begin, spp_count;
+    /* Interleaved pixel tiles (load balance across ranks, SURVEY.md 8(e) "16-row tiles round-robin") in ONE launch:
+       with pixel_tile != 0 the q-th pixel of the shard, q in [0, pixel_count), is
+           pixel_begin + (q / pixel_tile) * pixel_tile_stride + q % pixel_tile
+       (rank r of G with tiles of T pixels: pixel_begin = r*T, pixel_tile = T, pixel_tile_stride = G*T).
+       pixel_tile == 0: the contiguous range above. */
+    uint32_t pixel_tile, pixel_tile_stride;
 } mi355_render_params;
 
 /* Per-event device counters behind the algorithmic-byte formula of SURVEY.md 8(d). */

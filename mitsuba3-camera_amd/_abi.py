@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -77,7 +77,8 @@ class RenderParams(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
                 ("flags", C.c_uint32), ("mode", C.c_uint32), ("integrator", C.c_uint32),
                 ("pixel_begin", C.c_uint32), ("pixel_count", C.c_uint32),
-                ("spp_begin", C.c_uint32), ("spp_count", C.c_uint32)]
+                ("spp_begin", C.c_uint32), ("spp_count", C.c_uint32),
+                ("pixel_tile", C.c_uint32), ("pixel_tile_stride", C.c_uint32)]
 
 
 class Counters(C.Structure):

@@ -46,7 +46,14 @@ struct RenderArgs {
     uint32_t n_local;          // pixel_count * s_count
     uint32_t seg;              // lanes per pixel inside one wave for the LDS splat (0 = direct atomics)
     uint32_t lane_begin;       // OUT_LANES only
+    uint32_t tile, tile_stride; // interleaved pixel tiles (0 = contiguous shard)
 };
+// q-th pixel of the shard -> global pixel index (mi355_render_params::pixel_tile)
+MI_DEV uint32_t shard_pixel(const RenderArgs &a, uint32_t q) {
+    if (a.tile == 0u) return a.pixel_begin + q;
+    uint32_t t = q / a.tile;
+    return a.pixel_begin + t * a.tile_stride + (q - t * a.tile);
+}
 
 enum { OUT_FILM = 0, OUT_LANES = 1 };
 
@@ -55,7 +62,7 @@ struct LaneInfo { bool act; uint32_t lane; int32_t px, py; uint32_t pixel; };
 MI_DEV LaneInfo lane_info(const DScene &sc, const RenderArgs &a, uint32_t i) {
     LaneInfo li; li.act = i < a.n_local;
     uint32_t ii = li.act ? i : 0;
-    li.pixel = a.pixel_begin + ii / a.s_count;
+    li.pixel = shard_pixel(a, ii / a.s_count);
     uint32_t s = a.s_begin + ii % a.s_count;
     li.lane = li.pixel * a.spp_total + s;
     uint32_t y = li.pixel / sc.crop_w;
@@ -103,7 +110,7 @@ MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, 
             }
             uint32_t ig = i_wave_first + g * seg;
             if (ig < a.n_local && sum != 0.f) {
-                uint32_t pixel = a.pixel_begin + ig / a.s_count;
+                uint32_t pixel = shard_pixel(a, ig / a.s_count);
                 int32_t py = (int32_t) (pixel / sc.crop_w), px = (int32_t) (pixel - (uint32_t) py * sc.crop_w);
                 int32_t x = px - n + (int32_t) (t % 5u), y = py - n + (int32_t) (t / 5u);
                 if (x >= 0 && y >= 0 && x < W && y < H) atomicAdd(film + ((size_t) y * W + x) * CH + c, sum);
@@ -941,6 +948,12 @@ static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderA
     a->s_begin = p->spp_begin; a->s_count = p->spp_count ? p->spp_count : p->spp - p->spp_begin;
     if (p->pixel_begin > npix || a->pixel_count > npix - p->pixel_begin) return fail(MI355_ERR_INVALID, "pixel shard out of range");
     if (p->spp_begin > p->spp || a->s_count > p->spp - p->spp_begin) return fail(MI355_ERR_INVALID, "spp shard out of range");
+    a->tile = p->pixel_tile; a->tile_stride = p->pixel_tile_stride;
+    if (a->tile != 0u && a->pixel_count != 0u) {
+        if (a->tile_stride < a->tile) return fail(MI355_ERR_INVALID, "pixel_tile_stride must be >= pixel_tile");
+        uint64_t q = a->pixel_count - 1u, last = (uint64_t) p->pixel_begin + (q / a->tile) * a->tile_stride + q % a->tile;
+        if (last >= npix) return fail(MI355_ERR_INVALID, "tiled pixel shard out of range");
+    }
     uint64_t n = (uint64_t) a->pixel_count * a->s_count;
     if (n > 0xffffffffull - BLOCK) return fail(MI355_ERR_INVALID, "shard too large");
     a->n_local = (uint32_t) n;

@@ -49,6 +49,29 @@ def shard_pixels(n_pixels, rank, world):
     return b, e - b
 
 
+SHARD_TILE_ROWS = 16
+
+
+def shard_tiles(width, height, rank, world, rows=SHARD_TILE_ROWS):
+    """Interleaved row tiles ("16-row tiles round-robin" for load balance): tile t belongs to rank
+    t % world.  Returns (pixel_begin, pixel_count, pixel_tile, pixel_tile_stride) for mi355_render_params; every tile is
+    a contiguous range of global lane ids, and one launch covers all of a rank's tiles."""
+    tile = rows * width
+    npix = width * height
+    n_tiles = (npix + tile - 1) // tile
+    mine = range(rank, n_tiles, world)
+    count = sum(min(tile, npix - t * tile) for t in mine)
+    return (min(rank * tile, npix), count, tile, world * tile)
+
+
+def shard_of(film, rank, world):
+    """The shard a rank renders: interleaved 16-row tiles when every rank gets at least one, else contiguous bands."""
+    w, h = film.crop_width, film.crop_height
+    if world > 1 and (h + SHARD_TILE_ROWS - 1) // SHARD_TILE_ROWS >= world:
+        return shard_tiles(w, h, rank, world)
+    return shard_pixels(w * h, rank, world)
+
+
 class HipBackend:
     """The product back-end: every call goes to libmi355.so through the C ABI (no fallback).  Tests may
     substitute an object with the same five methods to exercise the sharding / collective logic on CPU."""
@@ -114,9 +137,12 @@ class Integrator:
         p.mode = self.mode; p.integrator = self.integrator_id
         npix = f.crop_width * f.crop_height
         if shard is not None:
-            p.pixel_begin, p.pixel_count = shard
+            p.pixel_begin, p.pixel_count = shard[0], shard[1]
+            if len(shard) == 4:
+                p.pixel_tile, p.pixel_tile_stride = shard[2], shard[3]
             if p.pixel_count == 0:
                 p.pixel_begin, p.pixel_count = npix, 0
+                p.pixel_tile = p.pixel_tile_stride = 0
         if spp_shard is not None:
             p.spp_begin, p.spp_count = spp_shard
         return p
@@ -137,7 +163,7 @@ class Integrator:
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
         band = None
         if shard is not None:
-            band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1])
+            band = shard_of(f, shard[0], shard[1])
         p = self._params(scene, seed, spp, shard=band)
         if band is None or band[1] > 0:
             be.accumulate(scene, p, film)
@@ -165,7 +191,7 @@ class Integrator:
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
         if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
             raise ValueError("grad_in must have shape (H, W, 3)")
-        band = shard_pixels(f.crop_width * f.crop_height, shard[0], shard[1]) if shard is not None else None
+        band = shard_of(f, shard[0], shard[1]) if shard is not None else None
         p = self._params(scene, seed, spp, shard=band)
         p.integrator = abi.INTEGRATOR_PRB
         weight = torch.zeros((f.crop_height, f.crop_width), dtype=torch.float32, device=dev)

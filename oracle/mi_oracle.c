@@ -1275,6 +1275,10 @@ static void shard_bounds(const OScene *sc, const mi355_render_params *rp, uint32
     *p0 = rp->pixel_begin; *pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin;
     *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : rp->spp - rp->spp_begin;
 }
+static inline uint32_t shard_pixel(const mi355_render_params *rp, uint32_t q) {     /* mi355.h: pixel_tile */
+    if (rp->pixel_tile == 0u) return rp->pixel_begin + q;
+    return rp->pixel_begin + (q / rp->pixel_tile) * rp->pixel_tile_stride + q % rp->pixel_tile;
+}
 /* render_sample head (integrator.cpp:433-455): pixel jitter, aperture sample if the sensor needs one, ray + ray weight */
 static float camera_ray(const OScene *sc, pcg32 *rng, uint32_t lane, uint32_t spp, v2 *sp, Ray *ray) {
     int32_t px, py; lane_to_pixel(sc, lane, spp, &px, &py);
@@ -1324,9 +1328,9 @@ ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp
 #endif
         Cnt cnt = { 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
-        for (int64_t p = (int64_t) p0; p < (int64_t) (p0 + pn); ++p) {
+        for (int64_t q = 0; q < (int64_t) pn; ++q) {
             for (uint32_t s = s0; s < s0 + sn; ++s) {
-                uint32_t lane = (uint32_t) p * rp->spp + s;
+                uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;
                 v3 rgb; int valid; v2 pos;
                 trace_lane(sc, rp, lane, &rgb, &valid, &pos, &cnt);
                 float vals[4] = { rgb.x, rgb.y, rgb.z, 1.f };           /* integrator.cpp:477-486 (no alpha) */
@@ -1359,8 +1363,8 @@ ORC_API int orc_param_layout(const OScene *sc, mi355_param_info *out, uint32_t c
 /* RBIntegrator.render_backward step 1a (common.py:741-758): W[p] = sum of filter weights */
 ORC_API void orc_prb_splat_weights(OScene *sc, const mi355_render_params *rp, float *weight_hw) {
     uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
-    for (uint32_t p = p0; p < p0 + pn; ++p) for (uint32_t s = s0; s < s0 + sn; ++s) {
-        uint32_t lane = p * rp->spp + s; pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+    for (uint32_t q = 0; q < pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
+        uint32_t lane = shard_pixel(rp, q) * rp->spp + s; pcg32 rng; sampler_seed(&rng, rp->seed, lane);
         int32_t px, py; lane_to_pixel(sc, lane, rp->spp, &px, &py);
         v2 sp; sp.x = (float) px + pcg32_float(&rng); sp.y = (float) py + pcg32_float(&rng);
         float one = 1.f; film_put(sc, weight_hw, 1, sp, &one);
@@ -1409,8 +1413,8 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
         GradCtx g = { gl, layout, (uint32_t) np, bsdf_slot, tex_slot, em_slot };
         Cnt cnt = { 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
-        for (int64_t p = (int64_t) p0; p < (int64_t) (p0 + pn); ++p) for (uint32_t s = s0; s < s0 + sn; ++s) {
-            uint32_t lane = (uint32_t) p * rp->spp + s;
+        for (int64_t q = 0; q < (int64_t) pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
+            uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;
             pcg32 rng; sampler_seed(&rng, rp->seed, lane);
             v2 sp; Ray ray; float cw = camera_ray(sc, &rng, lane, rp->spp, &sp, &ray);
             if (cw == 0.f) continue;

@@ -230,11 +230,13 @@ def test_sharded_render_equals_whole(mi, orc, torch_cuda, cbox32):
     integ = mi.PathIntegrator({"max_depth": 5})
     h = cbox32.handle(); lib = mi.abi.lib()
     whole = integ.render(cbox32, seed=4, spp=16, develop=False)
-    for split in ("pixels", "spp"):
+    for split in ("pixels", "tiles", "spp"):
         film = torch.zeros_like(whole)
         for r in range(4):
             if split == "pixels":
                 p = integ._params(cbox32, 4, 16, shard=mi.shard_pixels(32 * 32, r, 4))
+            elif split == "tiles":
+                p = integ._params(cbox32, 4, 16, shard=mi.shard_tiles(32, 32, r, 4, rows=3))     # ragged last tile
             else:
                 p = integ._params(cbox32, 4, 16, spp_shard=(4 * r, 4))
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), None))

@@ -107,6 +107,21 @@ def test_shard_pixels_partition(mi):
         assert (cover == 1).all()
 
 
+def test_shard_tiles_partition(mi):
+    """Interleaved row tiles: every pixel exactly once, through the mapping mi355.h documents for pixel_tile."""
+    for (w, h, world, rows) in [(512, 512, 8, 16), (32, 32, 4, 3), (16, 16, 3, 2), (20, 7, 2, 16), (64, 40, 5, 16)]:
+        cover = np.zeros(w * h, dtype=int)
+        for r in range(world):
+            b, n, tile, stride = mi.shard_tiles(w, h, r, world, rows=rows)
+            q = np.arange(n)
+            cover[b + (q // tile) * stride + q % tile] += 1
+        assert (cover == 1).all(), (w, h, world, rows)
+    class F: crop_width = 512; crop_height = 512
+    assert len(mi.shard_of(F, 1, 8)) == 4                      # tiles when every rank gets one
+    F.crop_height = 16
+    assert len(mi.shard_of(F, 1, 8)) == 2                      # else contiguous bands
+
+
 # ---- world_size = 2 over gloo --------------------------------------------------------------------------
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
@@ -121,7 +136,7 @@ def _worker(rank, world, port, out_dir):
     mi = load_package(); orc = load_oracle()
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    d = small_cbox(mi, 16)
+    d = small_cbox(mi, 32)
     tex = np.random.default_rng(12345).uniform(0.2, 0.8, (4, 4, 3)).astype(np.float32)
     d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}
     d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
@@ -140,14 +155,14 @@ def _worker(rank, world, port, out_dir):
         def synchronize(self, device): pass
 
     integ = mi.PRBIntegrator({"max_depth": 4}); integ.backend = OracleBackend()
-    img = integ.render(scene, seed=3, spp=8, shard=(rank, world))
-    gin = np.random.default_rng(5).normal(size=(16, 16, 3)).astype(np.float32)
-    g = integ.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=8, shard=(rank, world))
+    img = integ.render(scene, seed=3, spp=4, shard=(rank, world))
+    gin = np.random.default_rng(5).normal(size=(32, 32, 3)).astype(np.float32)
+    g = integ.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4, shard=(rank, world))
     np.save(os.path.join(out_dir, "img%d.npy" % rank), img.numpy()); np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
     if rank == 0:
         whole = mi.PRBIntegrator({"max_depth": 4}); whole.backend = OracleBackend()
-        np.save(os.path.join(out_dir, "img_ref.npy"), whole.render(scene, seed=3, spp=8).numpy())
-        np.save(os.path.join(out_dir, "g_ref.npy"), whole.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=8).numpy())
+        np.save(os.path.join(out_dir, "img_ref.npy"), whole.render(scene, seed=3, spp=4).numpy())
+        np.save(os.path.join(out_dir, "g_ref.npy"), whole.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4).numpy())
     dist.barrier(); dist.destroy_process_group()
 
 

@@ -68,6 +68,11 @@ def test_seed_and_shard_semantics(mi, orc):
         f, _ = o.render(o.params(integ, 5, 8, spp_shard=(2 * r, 2)), develop=False)
         acc += f
     assert np.allclose(acc, whole, rtol=1e-5, atol=1e-5)
+    acc = np.zeros_like(whole)                  # interleaved row tiles (2 rows of 16 pixels, 3 ranks; last tiles ragged)
+    for r in range(3):
+        f, _ = o.render(o.params(integ, 5, 8, shard=mi.shard_tiles(16, 16, r, 3, rows=2)), develop=False)
+        acc += f
+    assert np.allclose(acc, whole, rtol=1e-5, atol=1e-5)
     d = small_cbox(mi, 16); d["sensor"]["sampler"]["seed"] = 7
     sc2 = mi.load_dict(d); o2 = orc.OracleScene(sc2, mi.abi)
     assert o2.params(integ, 5, 8).seed == 12
