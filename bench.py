@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -81,6 +82,7 @@ def main():
     scene = mi.load_dict(d)
     integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
     integ.timing = True
+    integ.regen = args.regen
     h = scene.handle(local_rank)
     dev = torch.device("cuda", local_rank)
     W = H = args.res

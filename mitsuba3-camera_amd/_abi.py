@@ -20,7 +20,7 @@ SENSOR_PERSPECTIVE, SENSOR_REALISTICLENS = 0, 1
 RFILTER_BOX, RFILTER_GAUSSIAN, RFILTER_TENT = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
-FLAG_HIDE_EMITTERS, FLAG_TIMING = 1, 2
+FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN = 1, 2, 4
 MODE_FUSED, MODE_WAVEFRONT = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_PRB = 0, 1
 PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE = 0, 1, 2

@@ -327,8 +327,14 @@ MI_DEV bool mesh_any(const DScene &sc, const DShape &sh, const Ray &ray, v3 inv_
 
 // One flat primitive against one ray: 18 fma for the affine map, one v_rcp, two fma, then a branch-free
 // bounds test.  `tlim` is an EXCLUSIVE upper bound on t (next float above ray.maxt, or the closest hit so far).
-MI_DEV bool prim_test(const DPrim &pr, const Ray &ray, float tlim, float &t, float &s, float &u) {
-    const float *m = pr.m;
+// Tables indexed by a wave-uniform loop counter are read through the constant address space: the loads are then
+// scalar (s_load -> SGPR operands) no matter which stores / atomics the surrounding kernel performs.  (Through a plain
+// global pointer the compiler falls back to per-lane vector loads as soon as it cannot prove the table unclobbered.)
+#define MI_K(T) const __attribute__((address_space(4))) T
+template <typename T> MI_DEV MI_K(T) *as_const_table(const T *p) { return (MI_K(T) *) p; }
+template <typename P>
+MI_DEV bool prim_test(P pr, const Ray &ray, float tlim, float &t, float &s, float &u) {
+    auto m = pr->m;
     float os = fmaf(m[2], ray.o.z, fmaf(m[1], ray.o.y, fmaf(m[0], ray.o.x, m[3])));
     float ot = fmaf(m[6], ray.o.z, fmaf(m[5], ray.o.y, fmaf(m[4], ray.o.x, m[7])));
     float oh = fmaf(m[10], ray.o.z, fmaf(m[9], ray.o.y, fmaf(m[8], ray.o.x, m[11])));
@@ -337,15 +343,16 @@ MI_DEV bool prim_test(const DPrim &pr, const Ray &ray, float tlim, float &t, flo
     float dh = fmaf(m[10], ray.d.z, fmaf(m[9], ray.d.y, m[8] * ray.d.x));
     t = -oh * rcp_(dh);
     s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
-    return (t >= 0.f) & (t < tlim) & (fminf(s, u) >= pr.lo) & (fmaxf(s, u) <= 1.f) & (s + u <= pr.smax);
+    return (t >= 0.f) & (t < tlim) & (fminf(s, u) >= pr->lo) & (fmaxf(s, u) <= 1.f) & (s + u <= pr->smax);
 }
 MI_DEV float excl_limit(float maxt) { return maxt >= MI_LARGEST ? MI_INF : __uint_as_float(__float_as_uint(maxt) + 1u); }
 
 // Slab test of one oriented box: entering distance if the origin is outside, exiting distance if it is inside
 // (the reference's triangles are two-sided for the intersection routine, mesh.h:430-453).
 struct BoxLocal { v3 o, d; float tnear, tfar; v3 tn, tf; };
-MI_DEV BoxLocal box_local(const DBox &bx, const Ray &ray) {
-    const float *m = bx.m; BoxLocal b;
+template <typename P>
+MI_DEV BoxLocal box_local(P bx, const Ray &ray) {
+    auto m = bx->m; BoxLocal b;
     b.o = V3(fmaf(m[2], ray.o.z, fmaf(m[1], ray.o.y, fmaf(m[0], ray.o.x, m[3]))),
              fmaf(m[6], ray.o.z, fmaf(m[5], ray.o.y, fmaf(m[4], ray.o.x, m[7]))),
              fmaf(m[10], ray.o.z, fmaf(m[9], ray.o.y, fmaf(m[8], ray.o.x, m[11]))));
@@ -361,7 +368,8 @@ MI_DEV BoxLocal box_local(const DBox &bx, const Ray &ray) {
     b.tfar = fminf(fminf(b.tf.x, b.tf.y), b.tf.z);
     return b;
 }
-MI_DEV bool box_test(const DBox &bx, const Ray &ray, float tlim, float &t) {
+template <typename P>
+MI_DEV bool box_test(P bx, const Ray &ray, float tlim, float &t) {
     BoxLocal b = box_local(bx, ray);
     t = b.tnear < 0.f ? b.tfar : b.tnear;
     return (b.tnear <= b.tfar) & (t >= 0.f) & (t < tlim);
@@ -382,14 +390,15 @@ MI_DEV bool solve_quadratic(float a, float b, float c, float &x0, float &x1) {
     return valid_linear || valid_quadratic;
 }
 // Sphere::ray_intersect_preliminary_impl, src/shapes/sphere.cpp:491-563 (closest) and ray_test_impl :565-601 (any)
-MI_DEV bool sphere_intersect(const DSphere &sp, const Ray &ray, float tlim, float &t) {
-    v3 center = ld3(sp.center);
+template <typename P>
+MI_DEV bool sphere_intersect(P sp, const Ray &ray, float tlim, float &t) {
+    v3 center = V3(sp->center[0], sp->center[1], sp->center[2]);
     v3 l = ray.o - center, d = ray.d;
     float plane_t = div_(dot3(-l, d), norm3(d));
     bool no_hit = plane_t == 0.f && (ray.o.x != center.x && ray.o.y != center.y && ray.o.z != center.z);
     v3 o = ray_at(ray, plane_t) - center;
-    no_hit = no_hit && (norm3(o) > sp.radius);
-    float A = sqnorm3(d), B = 2.f * dot3(o, d), C = sqnorm3(o) - sp.radius * sp.radius;
+    no_hit = no_hit && (norm3(o) > sp->radius);
+    float A = sqnorm3(d), B = 2.f * dot3(o, d), C = sqnorm3(o) - sp->radius * sp->radius;
     float near_t, far_t; bool found = solve_quadratic(A, B, C, near_t, far_t);
     near_t += plane_t; far_t += plane_t;
     bool out_bounds = !(near_t < tlim && far_t >= 0.f), in_bounds = near_t < 0.f && !(far_t < tlim);
@@ -406,20 +415,21 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     uint32_t best = 0xffffffffu;
     const uint32_t n = sc.n_prims;
+    MI_K(DPrim) *prims = as_const_table(sc.prims); MI_K(DBox) *boxes = as_const_table(sc.boxes); MI_K(DSphere) *spheres = as_const_table(sc.spheres);
     MI_UNROLL_PRIMS
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
-        bool h = prim_test(sc.prims[k], ray, tlim, t, s, u);
+        bool h = prim_test(prims + k, ray, tlim, t, s, u);
         tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
         float t;
-        bool h = box_test(sc.boxes[k], ray, tlim, t);
+        bool h = box_test(boxes + k, ray, tlim, t);
         tlim = h ? t : tlim; best = h ? (MI_BOX_FLAG | k) : best;
     }
     if (FULL) for (uint32_t k = 0; k < sc.n_spheres; ++k) {
         float t;
-        bool h = sphere_intersect(sc.spheres[k], ray, tlim, t) && t < tlim;
+        bool h = sphere_intersect(spheres + k, ray, tlim, t) && t < tlim;
         tlim = h ? t : tlim; best = h ? (MI_SPHERE_FLAG | k) : best;
     }
     if (best != 0xffffffffu) {                                          // per-lane finalize (divergent gather, once per ray)
@@ -429,7 +439,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
             hit.shape = sc.spheres[best & ~MI_SPHERE_FLAG].shape; hit.prim = 0; hit.u = hit.v = 0.f;
         } else if (best & MI_BOX_FLAG) {
             const DBox &bx = sc.boxes[best & ~MI_BOX_FLAG];
-            BoxLocal b = box_local(bx, ray);                           // same arithmetic as in the loop -> same face decision
+            BoxLocal b = box_local(&bx, ray);                           // same arithmetic as in the loop -> same face decision
             bool inside = b.tnear < 0.f;
             v3 key = inside ? V3(-b.tf.x, -b.tf.y, -b.tf.z) : b.tn;   // entering: arg max tn, exiting: arg min tf
             uint32_t axis = (key.x >= key.y && key.x >= key.z) ? 0u : (key.y >= key.z ? 1u : 2u);
@@ -470,18 +480,19 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
     if (!__any(active)) return false;                                      // nobody in this wave asked
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     const uint32_t n = sc.n_prims;
+    MI_K(DPrim) *prims = as_const_table(sc.prims); MI_K(DBox) *boxes = as_const_table(sc.boxes); MI_K(DSphere) *spheres = as_const_table(sc.spheres);
     MI_UNROLL_PRIMS
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
-        if (prim_test(sc.prims[k], ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
+        if (prim_test(prims + k, ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
         float t;
-        if (box_test(sc.boxes[k], ray, tlim, t)) { occluded = true; tlim = 0.f; }
+        if (box_test(boxes + k, ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
     if (FULL) for (uint32_t k = 0; k < sc.n_spheres; ++k) {
         float t;
-        if (sphere_intersect(sc.spheres[k], ray, tlim, t)) { occluded = true; tlim = 0.f; }
+        if (sphere_intersect(spheres + k, ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
     if (sc.n_bvh_shapes) {
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
@@ -969,7 +980,17 @@ MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, fl
     ray = sample_primary_ray(sc, pos_x, pos_y); return 1.f;
 }
 
+// MI_PROF (diagnostic builds only, tools/section_profile.py): per-wave s_memtime deltas per section of the path loop
+#ifdef MI_PROF
+struct Counters3 { uint32_t isect, shade, shadow; uint32_t prof[8]; unsigned long long t; };
+static __device__ unsigned long long g_prof[8];
+#define PROF_START(c) { __builtin_amdgcn_sched_barrier(0); (c).t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define PROF(c, k) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_amdgcn_s_memtime(); (c).prof[k] += (uint32_t) (n_ - (c).t); (c).t = n_; __builtin_amdgcn_sched_barrier(0); }
+#else
 struct Counters3 { uint32_t isect, shade, shadow; };
+#define PROF_START(c)
+#define PROF(c, k)
+#endif
 
 // -------------------------------------------------------------------------------------------
 // PathIntegrator::sample, src/integrators/path.cpp:95-287
@@ -989,7 +1010,9 @@ MI_DEV void path_init(PathState &st, const Ray &ray, const Pcg32 &rng) {
 template <bool FULL>
 MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
                       bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
+    PROF_START(cnt);
     Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
+    PROF(cnt, 0);
     if (active) cnt.isect++;
     bool si_valid = active && hit.t != MI_INF;
     bool active_next = si_valid && (it + 1 < max_depth);                    // path.cpp:177
@@ -1008,6 +1031,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             v3 le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
             st.result = fma3(st.throughput, le * mis_bsdf, st.result);
         }
+        PROF(cnt, 1);
         // At the last vertex (it + 1 == max_depth, uniform over the wave) nothing below can change the result:
         // active_next is false for every lane, so no NEE contribution, no continuation (path.cpp:177-187).
         if (it + 1 < max_depth) {
@@ -1018,6 +1042,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
             bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;        // BSDFFlags::Smooth, path.cpp:187
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
+            PROF(cnt, 2);
             // ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33)
             float s1 = next_1d(st.rng), s2x = next_1d(st.rng), s2y = next_1d(st.rng);
             v3 wo = si_to_local(si, ds.d);
@@ -1025,7 +1050,9 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bsm, bsdf_weight);
             v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
             v3 contrib = (bsdf_val * em_weight) * mis_weight(ds.pdf, bsdf_pdf);
+            PROF(cnt, 3);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
+            PROF(cnt, 4);
             if (need_shadow) cnt.shadow++;
             if (need_shadow && !occluded) st.result = fma3(st.throughput, contrib, st.result);   // path.cpp:220-230
             // ---- BSDF sampling + loop update (path.cpp:234-280)
@@ -1039,6 +1066,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             bool rr_active = it + 1 >= rr_depth, rr_continue = next_1d(st.rng) < rr_prob;
             if (rr_active) st.throughput = st.throughput * rcp_(rr_prob);
             alive = active_next && (!rr_active || rr_continue) && tmax != 0.f;
+            PROF(cnt, 5);
         }
     }
     return alive;

@@ -47,6 +47,7 @@ struct RenderArgs {
     uint32_t seg;              // lanes per pixel inside one wave for the LDS splat (0 = direct atomics)
     uint32_t lane_begin;       // OUT_LANES only
     uint32_t tile, tile_stride; // interleaved pixel tiles (0 = contiguous shard)
+    uint32_t ppw;              // k_render_regen: shard pixels per wave
 };
 // q-th pixel of the shard -> global pixel index (mi355_render_params::pixel_tile)
 MI_DEV uint32_t shard_pixel(const RenderArgs &a, uint32_t q) {
@@ -154,11 +155,13 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
         li.pixel = li.lane / a.spp_total;
         uint32_t y = li.pixel / sc.crop_w; li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
     } else li = lane_info(sc, a, i);
+    Counters3 cnt = {};
+    PROF_START(cnt);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
     float pos_x, pos_y; Ray ray;
     float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
     bool trace = li.act && cam_w > 0.f;                                    // rays blocked inside the lens carry weight 0
-    Counters3 cnt = { 0, 0, 0 };
+    PROF(cnt, 6);
     v3 rgb; bool valid;
     if (INTEGRATOR == MI355_INTEGRATOR_PATH)
         path_sample<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, trace, stk, rgb, valid, cnt);
@@ -174,8 +177,143 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
     } else {
         Splat sp = splat_weights(sc, pos_x, pos_y);
         float values[4] = { rgb.x, rgb.y, rgb.z, 1.f };                     // integrator.cpp:477-486 (rgb film, no alpha)
+        PROF_START(cnt);
         film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+        PROF(cnt, 7);
     }
+#ifdef MI_PROF
+    if (lane_id == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long) cnt.prof[k]);
+#endif
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_render_regen: PathIntegrator::sample with PATH REGENERATION.  In k_render a wave lives until its longest path
+// ends, so on the Cornell box ~1/3 of the VALU lanes idle (measured lane utilisation 65 %).  Here a wave owns `ppw`
+// whole pixels and their samples as a pool: a lane whose path has ended writes (pos, rgb) into the wave's LDS record
+// ring and immediately starts the pool's next sample (wave ballot + mbcnt prefix assigns sample indices), so every
+// bounce runs with (nearly) all 64 lanes busy.  Whenever 64 records are waiting they are splatted together: records
+// with the same 5x5 footprint are pre-reduced through LDS exactly like film_splat does.  Lane <-> sample assignment
+// changes, the arithmetic of a sample does not: a sample is still seeded by its GLOBAL lane id (sampler.cpp:124-130).
+// Waves run independent trip counts: no workgroup barrier inside the loop, only wave-scope fences.
+// ---------------------------------------------------------------------------------------------------------------
+#define RING 128                            // records per wave: 63 waiting + 64 new at most
+#define RG_WAVE_WORDS CMAX(STACK_WORDS, WAVE_FLOATS)   // per wave and private: BVH stack | splat staging (never live together)
+MI_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// splat `n` (<= 64) records starting at ring slot `head`
+MI_DEV void ring_flush(const DScene &sc, float *stage, const float *ring, uint32_t head, uint32_t n, float *__restrict__ film) {
+    const uint32_t lane_id = threadIdx.x & 63;
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    const bool valid = lane_id < n;
+    const uint32_t slot = (head + lane_id) & (RING - 1);
+    float pos_x = valid ? ring[slot] : (float) sc.crop_x, pos_y = valid ? ring[RING + slot] : (float) sc.crop_y;
+    float v0 = ring[2 * RING + slot], v1 = ring[3 * RING + slot], v2 = ring[4 * RING + slot];
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    const uint32_t key = ((uint32_t) (sp.x0 + 16) & 0xffffu) | ((uint32_t) (sp.y0 + 16) << 16);
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const uint32_t first = (uint32_t) __ffsll((long long) todo) - 1u;
+        const uint32_t k = (uint32_t) __builtin_amdgcn_readlane((int) key, (int) first);
+        const bool m = valid && key == k;
+        wave_sync();                                                        // previous pass / BVH stack use is over
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            stage[j * ROW_STRIDE + lane_id] = m ? sp.wx[j] : 0.f;
+            stage[(5 + j) * ROW_STRIDE + lane_id] = m ? sp.wy[j] : 0.f;
+        }
+        stage[10 * ROW_STRIDE + lane_id] = m ? v0 : 0.f; stage[11 * ROW_STRIDE + lane_id] = m ? v1 : 0.f;
+        stage[12 * ROW_STRIDE + lane_id] = m ? v2 : 0.f; stage[13 * ROW_STRIDE + lane_id] = m ? 1.f : 0.f;   // integrator.cpp:477-486
+        wave_sync();
+        const int32_t x0 = (int32_t) (k & 0xffffu) - 16, y0 = (int32_t) (k >> 16) - 16;
+        for (uint32_t o = lane_id; o < 100u; o += 64) {
+            uint32_t t = o >> 2, c = o & 3u, tx = t % 5u, ty = t / 5u;
+            const float *xr = stage + tx * ROW_STRIDE, *yr = stage + (5u + ty) * ROW_STRIDE, *vr = stage + (10u + c) * ROW_STRIDE;
+            float sum = 0.f;
+#pragma unroll 4
+            for (uint32_t l = 0; l < 64; l += 4) {
+                float4 xv = *reinterpret_cast<const float4 *>(xr + l);
+                float4 yv = *reinterpret_cast<const float4 *>(yr + l);
+                float4 vv = *reinterpret_cast<const float4 *>(vr + l);
+                sum = fmaf(yv.x * xv.x, vv.x, sum); sum = fmaf(yv.y * xv.y, vv.y, sum);      // weight = wy*wx (imageblock.cpp:486)
+                sum = fmaf(yv.z * xv.z, vv.z, sum); sum = fmaf(yv.w * xv.w, vv.w, sum);
+            }
+            int32_t x = x0 + (int32_t) tx, y = y0 + (int32_t) ty;
+            if (sum != 0.f && x >= 0 && y >= 0 && x < W && y < H) atomicAdd(film + ((size_t) y * W + x) * 4 + c, sum);
+        }
+        todo &= ~__ballot(m);
+    }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS];
+    __shared__ float s_ring[WAVES * 5 * RING];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    const uint32_t lane_id = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    float *stage = smem + wave * RG_WAVE_WORDS;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + lane_id;
+    float *ring = s_ring + wave * 5 * RING;
+    // pool of this wave: shard pixels [q, q_end), all s_count samples of each
+    uint32_t q = (blockIdx.x * WAVES + wave) * a.ppw;
+    const uint32_t q_end = min(q + a.ppw, a.pixel_count);
+    uint32_t s_next = 0, r_head = 0, r_count = 0;
+    PathState st; path_init(st, Ray{ V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 1.f), 0.f }, Pcg32{ 0, 1 });
+    float pos_x = 0.f, pos_y = 0.f, cam_w = 1.f;
+    uint32_t depth = 0;
+    bool active = false, pending = false;
+    Counters3 cnt = {};
+    for (;;) {
+        // The sample-generation and splat sections read the scene through a pointer the optimiser cannot see through,
+        // re-derived every trip: otherwise LICM hoists their camera / filter constants out of the loop, where they
+        // sit in ~80 spilled SGPRs across the (much hotter) bounce code.  DScene is kernel argument 0.
+        typedef const __attribute__((address_space(4))) DScene *KScene;
+        KScene scp = (KScene) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(scp));
+        const DScene &scl = *(const DScene *) scp;
+        // (1) paths that ended in the previous bounce (or were blocked inside the lens) become film records
+        unsigned long long fin = __ballot(pending);
+        if (fin) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fin >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fin, 0u));
+            if (pending) {
+                uint32_t slot = (r_head + r_count + rank) & (RING - 1);
+                ring[slot] = pos_x; ring[RING + slot] = pos_y;
+                ring[2 * RING + slot] = st.result.x * cam_w; ring[3 * RING + slot] = st.result.y * cam_w;   // spec_u = ray_weight * spec, integrator.cpp:461
+                ring[4 * RING + slot] = st.result.z * cam_w;
+            }
+            r_count += (uint32_t) __popcll(fin); pending = false;
+        }
+        // (2) 64 records waiting: one pre-reduced splat
+        if (r_count >= 64u) { ring_flush(scl, stage, ring, r_head, 64u, film); r_head = (r_head + 64u) & (RING - 1); r_count -= 64u; }
+        // (3) idle lanes take the next samples of the current pixel (render_sample head, integrator.cpp:433-455)
+        unsigned long long idle = __ballot(!active);
+        if (idle && q < q_end) {
+            const uint32_t remaining = a.s_count - s_next;
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+            const uint32_t pixel = shard_pixel(a, q);                          // wave-uniform
+            const uint32_t y = pixel / scl.crop_w;
+            const int32_t py = (int32_t) (y + scl.crop_y), px = (int32_t) (pixel - y * scl.crop_w + scl.crop_x);
+            if (!active && rank < remaining) {
+                uint32_t lane = pixel * a.spp_total + a.s_begin + s_next + rank;   // global lane id, integrator.cpp:293-305
+                Pcg32 rng; sampler_seed(rng, a.seed, lane);
+                Ray ray; cam_w = camera_ray<FULL>(scl, rng, px, py, pos_x, pos_y, ray);
+                path_init(st, ray, rng);
+                depth = 0; active = cam_w > 0.f; pending = !active;          // rays blocked inside the lens carry weight 0
+            }
+            s_next += min((uint32_t) __popcll(idle), remaining);
+            if (s_next == a.s_count) { s_next = 0; ++q; }
+        }
+        if (!__any(active)) { if (q >= q_end && !__any(pending)) break; continue; }
+        // (4) one bounce of every live path (path.cpp:142-281); the depth is per lane now
+        bool hit_any;
+        bool alive = path_step<FULL>(scl, st, depth, a.max_depth, a.rr_depth, active, stk, hit_any, cnt);
+        pending = pending || (active && !alive); active = alive; ++depth;
+    }
+    if (r_count) ring_flush(sc, stage, ring, r_head, r_count, film);       // r_count < 64 here
+    __syncthreads();
     flush_counters(s_cnt, cnt, g_counters);
 }
 
@@ -201,7 +339,7 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
     float pos_x, pos_y; Ray ray0;
     (void) camera_ray<false>(sc, rng, li.px, li.py, pos_x, pos_y, ray0);   // perspective sensors only (checked by the host)
     PathState st; path_init(st, ray0, rng);
-    Counters3 cnt = { 0, 0, 0 };
+    Counters3 cnt = {};
     fin[tid] = 0.f; fin[BLOCK + tid] = 0.f; fin[2 * BLOCK + tid] = 0.f; fin[3 * BLOCK + tid] = 0.f;
     uint32_t orig = tid;                       // which original slot the path in this thread belongs to
     bool valid_ray = false;
@@ -321,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
             }
     }
     dL = dL * cam_w;                                                        // value = L * weight, common.py:752
-    Counters3 cnt = { 0, 0, 0 };
+    Counters3 cnt = {};
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
     GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE };
     Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
@@ -961,6 +1099,7 @@ static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderA
     uint32_t sc = a->s_count; a->seg = 0;
     if (sc % 64 == 0) a->seg = 64; else if (sc >= 4 && (sc & (sc - 1)) == 0) a->seg = sc;
     a->lane_begin = 0;
+    a->ppw = std::max(1u, 1024u / a->s_count);
     return MI355_OK;
 }
 static int ensure_events(mi355_scene *s) {
@@ -1006,6 +1145,11 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     } else if (p->mode == MI355_MODE_WAVEFRONT)
         hipLaunchKernelGGL(k_render_compact, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+    else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN)) {       // enough samples per pixel to keep a wave's pool full
+        uint32_t n_waves = (a.pixel_count + a.ppw - 1) / a.ppw; dim3 rgrid((n_waves + WAVES - 1) / WAVES);
+        if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else hipLaunchKernelGGL(k_render_regen<false>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+    }
     else if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     HIP_TRY(hipGetLastError());
@@ -1068,6 +1212,12 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
     unsigned long long h[8]; HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->n_gen = s->n_gen; out->n_isect = h[1]; out->n_shade = h[2]; out->n_shadow = h[3]; out->n_splat = s->n_splat;
     out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum;
+#ifdef MI_PROF
+    { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), sizeof(pr)));
+      fprintf(stderr, "MI_PROF cycles: isect %llu si+hit %llu emitter %llu bsdf %llu shadow %llu tail %llu gen %llu splat %llu\n",
+              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+      if (reset) { memset(pr, 0, sizeof(pr)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), pr, sizeof(pr))); } }
+#endif
     if (reset) { HIP_TRY(hipMemset(s->d_counters, 0, sizeof(h))); s->n_gen = s->n_splat = 0; s->ms_accum = 0.f; s->launches_accum = 0; }
     return MI355_OK;
 }

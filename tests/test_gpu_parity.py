@@ -175,6 +175,38 @@ def test_render_matches_oracle(mi, orc, torch_cuda, cbox32, spp):
     assert np.allclose(raw[:, :, 3], raw_ref[:, :, 3], rtol=1e-4, atol=1e-4)          # W channel: pure filter weights
 
 
+@pytest.mark.parametrize("spp,max_depth,rr_depth,crop", [(128, 6, 5, None), (200, -1, 2, None), (256, 3, 5, (5, 7, 20, 11)), (130, 1, 5, None)])
+def test_path_regeneration_matches_static(mi, orc, torch_cuda, spp, max_depth, rr_depth, crop):
+    """MI355_FLAG_REGEN: a wave hands the lanes of finished paths to its next samples.  Samples are still pure functions of
+    (seed, global lane id), so film, event counters and the oracle's image must agree with the static assignment; ragged
+    pools (spp not a multiple of 64, pixel count not a multiple of the pixels per wave) and the sharded launch included."""
+    torch = torch_cuda
+    film = {} if crop is None else {"crop_offset_x": crop[0], "crop_offset_y": crop[1], "crop_width": crop[2], "crop_height": crop[3]}
+    scene = mi.load_dict(small_cbox(mi, 32, **film))
+    integ = mi.PathIntegrator({"max_depth": max_depth, "rr_depth": rr_depth})
+    integ.counters(scene, reset=True)
+    static = integ.render(scene, seed=8, spp=spp, develop=False)
+    c_static = integ.counters(scene, reset=True)
+    integ.regen = True
+    regen = integ.render(scene, seed=8, spp=spp, develop=False)
+    c_regen = integ.counters(scene, reset=True)
+    assert torch.allclose(regen, static, rtol=2e-4, atol=2e-4)
+    for k in ("n_isect", "n_shade", "n_shadow"):
+        assert c_regen[k] == c_static[k], k
+    o = orc.OracleScene(scene, mi.abi)
+    ref, _ = o.render(o.params(integ, 8, spp))
+    img = integ.render(scene, seed=8, spp=spp).cpu().numpy()
+    assert np.abs(img - ref).max() < 1e-3 * ref.max()
+    h = scene.handle(); lib = mi.abi.lib()
+    acc = torch.zeros_like(static)
+    W, H = scene.sensor.film.crop_width, scene.sensor.film.crop_height
+    for r in range(3):                                           # tiles of 2 rows over 3 ranks + an spp slice
+        p = integ._params(scene, 8, spp, shard=mi.shard_tiles(W, H, r, 3, rows=2))
+        mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, static, rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("spp,max_depth,rr_depth", [(16, 6, 5), (64, -1, 2), (3, 4, 5), (128, 2, 5)])
 def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_depth, rr_depth):
     """MI355_MODE_WAVEFRONT re-packs lanes between bounces; lanes are still pure functions of (seed, lane id), so the film
