@@ -149,6 +149,8 @@ typedef struct mi355_scene_desc {
 
 #define MI355_FLAG_HIDE_EMITTERS  1u   /* MonteCarloIntegrator::m_hide_emitters */
 #define MI355_FLAG_TIMING         2u   /* bracket the path kernel with HIP events on `stream` */
+#define MI355_FLAG_TWO_PASS       8u   /* render_backward: primal walk + adjoint walk per path as prb.py does (common.py:760-796)
+                                          instead of the default single walk with deferred L_total ("one-pass adjoint") */
 #define MI355_FLAG_REGEN          4u   /* path integrator, >= 128 spp: a wave re-uses the lanes of finished paths for its next samples
                                           (path regeneration).  Same samples, same film; opt-in because on the Cornell box it
                                           measured 11.3 ms against 10.8 ms for the static assignment */
@@ -187,6 +189,8 @@ typedef struct mi355_counters {
     uint64_t n_gen, n_isect, n_shade, n_shadow, n_splat;
     float    kernel_ms;                 /* HIP-event duration of the last timed path kernel (MI355_FLAG_TIMING) */
     uint32_t kernel_launches;           /* launches covered by kernel_ms */
+    uint64_t n_redo_groups;             /* render_backward: workgroups whose one-pass record queue overflowed and that the
+                                           two-pass kernel redid (0 on the benchmark scenes) */
 } mi355_counters;
 
 /* One differentiable parameter (ParamFlags::Differentiable in traverse()). */

@@ -20,7 +20,7 @@ SENSOR_PERSPECTIVE, SENSOR_REALISTICLENS = 0, 1
 RFILTER_BOX, RFILTER_GAUSSIAN, RFILTER_TENT = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
-FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN = 1, 2, 4
+FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS = 1, 2, 4, 8
 MODE_FUSED, MODE_WAVEFRONT = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_PRB = 0, 1
 PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE = 0, 1, 2
@@ -84,7 +84,7 @@ class RenderParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_gen", C.c_uint64), ("n_isect", C.c_uint64), ("n_shade", C.c_uint64),
                 ("n_shadow", C.c_uint64), ("n_splat", C.c_uint64),
-                ("kernel_ms", C.c_float), ("kernel_launches", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("kernel_launches", C.c_uint32), ("n_redo_groups", C.c_uint64)]
 
 
 class ParamInfo(C.Structure):

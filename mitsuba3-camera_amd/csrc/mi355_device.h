@@ -1186,7 +1186,8 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                 dLo = dLo + ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
                 v3 ga = dL * dLo;
                 bool textured = is_diffuse && bsdf.texture >= 0 && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0 && sink.g_grad != nullptr;
-                bool queued = textured && sc.textures[bsdf.texture].c == 3 && sink.q != nullptr;
+                // (nearest-filter lookups have one tap and take the direct path; a slot that is allocated must be written)
+                bool queued = textured && sc.textures[bsdf.texture].c == 3 && sink.q != nullptr && taps.idx[3] >= 0;
                 {   // wave-aggregated slot allocation: one LDS atomic per wave, one record per textured lane
                     unsigned long long m = __ballot(queued);
                     if (m) {
@@ -1195,7 +1196,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                         if (rank == 0 && queued) base = atomicAdd(sink.qn, (uint32_t) __popcll(m));
                         base = (uint32_t) __shfl((int) base, __ffsll((long long) m) - 1);
                         uint32_t slot = base + rank;
-                        if (queued && slot < sink.qcap && taps.idx[3] >= 0) {
+                        if (queued && slot < sink.qcap) {
                             float *r = sink.q + 8u * slot;
                             float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];     // w = (w0y|w1y) * (w0x|w1x), sums to 1
                             r[0] = __uint_as_float((uint32_t) bsdf.texture); r[1] = __uint_as_float((uint32_t) taps.idx[0]);
@@ -1235,6 +1236,147 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
         }
     }
     L_out = L; valid_out = depth != 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// ONE-PASS adjoint.  prb.py needs the primal pass only for L_total: the adjoint walks the path again with
+// L_k = L_total - P_k (P_k = everything collected up to and including vertex k) and every albedo gradient is LINEAR in it:
+//     ga_k = dL * ((L_k * inv_k) * dval_k + direct_k) = L_total * A'_k + C'_k,
+//     A'_k = dL * (inv_k * dval_k),   C'_k = dL * (direct_k - (P_k * inv_k) * dval_k).
+// So one walk suffices: each vertex queues (target, A', C') in LDS, the lane publishes L_total = P_last when its path ends,
+// and the workgroup resolves the records when all of its paths are done.  Emitter-radiance gradients do not depend on L
+// and are accumulated at once, exactly as in the two-pass kernel.  Records live in 16-byte granules of one LDS queue; the
+// first dword of a record's first granule is a tag  kind << 30 | index << 8 | lane  (continuation granules start with a
+// dword whose top two bits are clear, so the resolver can scan granules in parallel):
+//   constant reflectance : 1 granule  (GK_SMALL | slot | lane, A'rgb)                      -- C' goes to s_grad immediately
+//   texture              : 3 granules (GK_TEX | tex | lane, texel(0,0), texel(1,1), w1x) (w1y in [0,1], A'rgb) (0, C'rgb)
+// A workgroup whose queue overflows raises `overflow`, publishes nothing and is redone by the two-pass kernel, so the result
+// never depends on the queue size.
+// -------------------------------------------------------------------------------------------
+struct GradSink1 { float *s_grad; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad; };
+#define GK_SMALL 0x40000000u
+#define GK_TEX   0x80000000u
+
+template <bool FULL>
+MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
+                          bool active, uint32_t *stk, v3 dL, GradSink1 sink, v3 &L_out, Counters3 &cnt) {
+    const uint32_t lane_in_block = threadIdx.x;
+    uint32_t depth = 0; v3 P = V3(0.f, 0.f, 0.f); v3 beta = V3(1.f, 1.f, 1.f); float eta = 1.f;
+    v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
+        if (active) cnt.isect++;
+        bool si_valid = active && hit.t != MI_INF;
+        bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
+        active = false;
+        if (si_valid) {
+            cnt.shade++;
+            SI si = compute_si<FULL>(sc, ray, hit);
+            const DShape &sh = sc.shapes[hit.shape];
+            int32_t emitter = sh.emitter;
+            v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
+            if (emitter >= 0) {                                            // prb.py:126-134
+                v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
+                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, prev_p, d, si.sh_n, dist);
+                le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
+                le_front = si.wi.z > 0.f;
+                v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
+                Le = (beta * le_mis) * e;
+                if (le_front && sc.emitters[emitter].grad_slot >= 0) {     // d Le / d radiance
+                    float *gb = sink.s_grad + sc.emitters[emitter].grad_slot;
+                    atomicAdd(gb + 0, dL.x * beta.x * le_mis); atomicAdd(gb + 1, dL.y * beta.y * le_mis); atomicAdd(gb + 2, dL.z * beta.z * le_mis);
+                }
+            }
+            active_next = active_next && (depth + 1 < max_depth);          // prb.py:139
+            if (!(it + 1 < max_depth)) { P = P + Le; depth += 1; continue; }   // last vertex: only Le remains (see prb_sample)
+            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+            TexTaps taps; v3 refl;
+            if (bsdf.texture >= 0) refl = texture_eval(sc, sc.textures[bsdf.texture], si.uv, &taps);
+            else refl = ld3(bsdf.reflectance);
+            // ---- emitter sampling (prb.py:142-162)
+            float ex = next_1d(rng), ey = next_1d(rng);
+            DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
+            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+            bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
+            bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
+            if (need_shadow) cnt.shadow++;
+            bool active_em = need_shadow && !occluded;
+            if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
+            v3 wo = si_to_local(si, ds.d);
+            v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+            const bool is_diffuse = !FULL || bsdf.type == MI355_BSDF_DIFFUSE;
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+            v3 Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
+            // ---- detached BSDF sampling (prb.py:166-169)
+            float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
+            BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, active_next, bsm, bsdf_weight);
+            v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
+            // ---- update (prb.py:173-182)
+            v3 beta_pre = beta;
+            P = (P + Le) + Lr_dir;
+            ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
+            beta = beta * bsdf_weight;
+            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = FULL ? bsm.delta : false;
+            if (FULL) eta *= bsm.eta;
+            // ---- stopping criterion (prb.py:186-198)
+            float bmax = max3(beta);
+            active_next = active_next && bmax != 0.f;
+            float rr_prob = fminf(bmax * (eta * eta), .95f);
+            bool rr_active = depth >= rr_depth;
+            if (rr_active) beta = beta * rcp_(rr_prob);
+            bool rr_continue = next_1d(rng) < rr_prob;
+            active_next = active_next && (!rr_active || rr_continue);
+            // ---- gradients (prb.py:202-247 in closed form, split into the L_total-proportional and the known part)
+            {
+                float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f && is_diffuse;
+                v3 det = bsdf_weight * bs_pdf;
+                v3 inv = V3(det.x != 0.f ? rcp_(det.x) : 0.f, det.y != 0.f ? rcp_(det.y) : 0.f, det.z != 0.f ? rcp_(det.z) : 0.f);
+                float dval = ev_active ? MI_INV_PI * co : 0.f;
+                bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f && is_diffuse;
+                float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
+                v3 direct = ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
+                v3 A = dL * (inv * dval);
+                v3 Cc = dL * (direct - (P * inv) * dval);
+                bool want_tex = is_diffuse && bsdf.texture >= 0 && sink.have_tex_grad && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0;
+                bool want_small = is_diffuse && bsdf.texture < 0 && bsdf.grad_slot >= 0;
+                if (want_small) {                                          // the known part needs no queue
+                    float *gb = sink.s_grad + bsdf.grad_slot;
+                    atomicAdd(gb + 0, Cc.x); atomicAdd(gb + 1, Cc.y); atomicAdd(gb + 2, Cc.z);
+                    want_small = ev_active;                                // A' == 0 otherwise
+                }
+                unsigned long long mt = __ballot(want_tex), ms = __ballot(want_small);
+                if (mt | ms) {                                             // wave-aggregated granule allocation: one LDS atomic per wave
+                    uint32_t rt = __builtin_amdgcn_mbcnt_hi((uint32_t) (mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mt, 0u));
+                    uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
+                    uint32_t total = 3u * (uint32_t) __popcll(mt) + (uint32_t) __popcll(ms);
+                    const uint32_t leader = (uint32_t) __ffsll((long long) (mt | ms)) - 1u;   // lane 0 may be masked off here
+                    const bool lead = (threadIdx.x & 63u) == leader;
+                    uint32_t base = 0;
+                    if (lead) base = atomicAdd(sink.qn, total);
+                    base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
+                    uint32_t g = base + 3u * rt + rs;
+                    if (base + total > sink.qcap) { if (lead) *sink.overflow = 1u; }
+                    else if (want_tex) {
+                        int32_t i11 = taps.idx[3] >= 0 ? taps.idx[3] : taps.idx[0];          // nearest filter: one tap of weight 1
+                        float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];   // w = (w0y|w1y) * (w0x|w1x), sums to 1
+                        sink.q[g] = make_float4(__uint_as_float(GK_TEX | ((uint32_t) bsdf.texture << 8) | lane_in_block), __uint_as_float((uint32_t) taps.idx[0]),
+                                                __uint_as_float((uint32_t) i11), w1x);
+                        sink.q[g + 1] = make_float4(w1y, A.x, A.y, A.z);
+                        sink.q[g + 2] = make_float4(0.f, Cc.x, Cc.y, Cc.z);
+                    } else if (want_small)
+                        sink.q[g] = make_float4(__uint_as_float(GK_SMALL | ((uint32_t) bsdf.grad_slot << 8) | lane_in_block), A.x, A.y, A.z);
+                }
+                if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
+                    float *gb = sink.s_grad + sc.emitters[ds.emitter].grad_slot;
+                    v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
+                    atomicAdd(gb + 0, dL.x * w.x); atomicAdd(gb + 1, dL.y * w.y); atomicAdd(gb + 2, dL.z * w.z);
+                }
+            }
+            depth += 1;                                                    // prb.py:249
+            active = active_next;
+        }
+    }
+    L_out = P;
 }
 
 // -------------------------------------------------------------------------------------------

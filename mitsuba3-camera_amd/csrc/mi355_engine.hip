@@ -424,7 +424,8 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
-                                                        unsigned long long *g_counters) {
+                                                        unsigned long long *g_counters, const uint32_t *redo) {
+    if (redo && !redo[blockIdx.x]) return;                                  // second launch: only the workgroups the one-pass kernel gave up on
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
     __shared__ float s_grad[MAX_SMALL_GRAD];
     __shared__ float s_q[GRAD_QUEUE * 8];
@@ -483,6 +484,96 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
             float v = (wy * wx) * r[5 + ch];
             if (v != 0.f) atomicAdd(g_grad + tx.grad_offset + (size_t) idx * 3u + ch, v);
         }
+    }
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
+// One-pass adjoint (prb_sample_1p): the path is walked ONCE; gradient records wait in LDS for the lane's L_total.
+// BVH = the scene has meshes that need the per-lane traversal stack (20 KB of LDS).  The small-parameter accumulators and
+// the record queue live in dynamic LDS: the host hands over whatever is left of 40 KB (four workgroups per CU) --
+// ~36 KB of queue on the Cornell box, ~16 KB with a traversal stack.
+template <bool FULL, bool BVH>
+__global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward_1p(DScene sc, RenderArgs a, const float4 *gw,
+                                                        float *g_grad, const uint32_t *small_map, uint32_t n_small,
+                                                        unsigned long long *g_counters, uint32_t *redo, uint32_t q_granules) {
+    extern __shared__ __attribute__((aligned(16))) float4 dyn_lds[];        // [n_small rounded up to 4 floats][q_granules x 16 B]
+    __shared__ __attribute__((aligned(16))) float smem[BVH ? WAVES * STACK_WORDS : 64];
+    __shared__ float s_ltot[3 * BLOCK];
+    float *s_grad = reinterpret_cast<float *>(dyn_lds);
+    float4 *s_q = dyn_lds + (n_small + 3u) / 4u;
+    __shared__ uint32_t s_qn, s_over;
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_qn = 0; s_over = 0; }
+    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) s_grad[k] = 0.f;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + (BVH ? wave * STACK_WORDS : 0u)) + (BVH ? lane_id : 0u);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    LaneInfo li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x, pos_y; Ray ray;
+    float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
+    bool trace = li.act && cam_w > 0.f;
+    // dL = adjoint of splat + develop: sum over taps of w(p) * grad_in[p] / W[p]   (hdrfilm.cpp:400); gw = grad_in / W
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    v3 dL = V3(0.f, 0.f, 0.f);
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    if (li.act) {
+#pragma unroll
+        for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+                int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+                if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+                float4 g = gw[(size_t) y * W + x];
+                float w = sp.wy[ty] * sp.wx[tx];
+                dL.x = fmaf(g.x, w, dL.x); dL.y = fmaf(g.y, w, dL.y); dL.z = fmaf(g.z, w, dL.z);
+            }
+    }
+    dL = dL * cam_w;                                                        // value = L * weight, common.py:752
+    Counters3 cnt = {};
+    bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
+    GradSink1 sink = { s_grad, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr };
+    v3 L;
+    prb_sample_1p<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, dL, sink, L, cnt);
+    s_ltot[threadIdx.x] = L.x; s_ltot[BLOCK + threadIdx.x] = L.y; s_ltot[2 * BLOCK + threadIdx.x] = L.z;
+    __syncthreads();
+    if (s_over) {                                                           // uniform: leave this workgroup to the two-pass kernel
+        if (threadIdx.x == 0) { redo[blockIdx.x] = 1u; if (g_counters) atomicAdd(&g_counters[4], 1ull); }
+        flush_counters(s_cnt, Counters3{}, g_counters);                     // its events are counted when it is redone
+        return;
+    }
+    // resolve: ga = L_total(lane) * A' + C'
+    const uint32_t n_gran = min(s_qn, q_granules);
+    for (uint32_t g = threadIdx.x; g < n_gran; g += BLOCK) {
+        float4 r = s_q[g];
+        uint32_t tag = __float_as_uint(r.x), lane = tag & 255u, slot = (tag >> 8) & 0x3fffffu;
+        if ((tag >> 30) != (GK_SMALL >> 30)) continue;
+        atomicAdd(&s_grad[slot + 0], s_ltot[lane] * r.y); atomicAdd(&s_grad[slot + 1], s_ltot[BLOCK + lane] * r.z);
+        atomicAdd(&s_grad[slot + 2], s_ltot[2 * BLOCK + lane] * r.w);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
+    // texture records: 12 consecutive lanes expand one record into its (tap, channel) atomics, so the three channels of a
+    // texel (12 contiguous bytes) leave in one wave-instruction and share a 64-B request
+    for (uint32_t e = threadIdx.x; e < n_gran * 12u; e += BLOCK) {
+        uint32_t g = e / 12u, k = e - g * 12u, tap = k / 3u, ch = k - tap * 3u;
+        float4 r0 = s_q[g];
+        uint32_t tag = __float_as_uint(r0.x), lane = tag & 255u;
+        if ((tag >> 30) != (GK_TEX >> 30)) continue;
+        float4 r1 = s_q[g + 1], r2 = s_q[g + 2];
+        const DTexture &tx = sc.textures[(tag >> 8) & 0x3fffffu];
+        uint32_t i00 = __float_as_uint(r0.y), i11 = __float_as_uint(r0.z);
+        uint32_t x0 = i00 % tx.w, x1 = i11 % tx.w;
+        uint32_t idx = tap == 0 ? i00 : (tap == 3 ? i11 : (tap == 1 ? i00 - x0 + x1 : i11 - x1 + x0));
+        float wx = (tap & 1u) ? r0.w : 1.f - r0.w, wy = (tap & 2u) ? r1.x : 1.f - r1.x;
+        float Av = ch == 0 ? r1.y : (ch == 1 ? r1.z : r1.w), Cv = ch == 0 ? r2.y : (ch == 1 ? r2.z : r2.w);
+        float ga = fmaf(s_ltot[ch * BLOCK + lane], Av, Cv);
+        float v = (wy * wx) * ga;
+        if (v == 0.f) continue;
+        if (tx.c == 3) atomicAdd(g_grad + tx.grad_offset + (size_t) idx * 3u + ch, v);
+        else atomicAdd(g_grad + tx.grad_offset + idx, v);                   // 1-channel texture: the three channel gradients add up
     }
     flush_counters(s_cnt, cnt, g_counters);
 }
@@ -610,7 +701,8 @@ struct mi355_scene {
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
-    unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow
+    uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
+    unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow, [4] redone backward workgroups
     uint64_t n_gen = 0, n_splat = 0;
     hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
     float ms_accum = 0.f; uint32_t launches_accum = 0;
@@ -1028,7 +1120,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -1193,12 +1285,34 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
     if ((rc = tm.begin())) return rc;
     uint32_t npix = s->ds.crop_w * s->ds.crop_h;
     hipLaunchKernelGGL(k_prepare_grad, dim3((npix + 255) / 256), dim3(256), 0, st, d_grad_in, d_weight, s->d_gw, npix);
-    if (s->ds.features != 0u)
-        hipLaunchKernelGGL(k_prb_backward<true>, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
-                           d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
-    else
-        hipLaunchKernelGGL(k_prb_backward<false>, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, s->ds, a, (const float4 *) s->d_gw,
-                           d_grad_params, s->d_small_map, (uint32_t) s->small_map.size(), s->d_counters);
+    const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    const uint32_t n_small = (uint32_t) s->small_map.size();
+    const bool full = s->ds.features != 0u;
+    uint32_t *redo = nullptr;
+    if (!(p->flags & MI355_FLAG_TWO_PASS)) {
+        // one walk per path; workgroups whose LDS record queue overflowed are flagged in `redo` and redone below
+        if (s->redo_capacity < grid.x) {
+            if (s->d_redo) HIP_TRY(hipFree(s->d_redo));
+            s->d_redo = nullptr; s->redo_capacity = 0;
+            HIP_TRY(hipMalloc((void **) &s->d_redo, (size_t) grid.x * sizeof(uint32_t))); s->redo_capacity = grid.x;
+        }
+        redo = s->d_redo;
+        HIP_TRY(hipMemsetAsync(redo, 0, (size_t) grid.x * sizeof(uint32_t), st));
+        const bool bvh = s->ds.n_bvh_shapes != 0u;
+        if (n_small > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant parameters for the LDS accumulators");
+        // dynamic LDS = small-parameter accumulators + record queue, sized so that 4 workgroups share a CU's 160 KB
+        const uint32_t static_lds = (bvh ? WAVES * STACK_WORDS * 4u : 256u) + 3u * BLOCK * 4u + 64u;
+        const uint32_t small_bytes = ((n_small + 3u) / 4u) * 16u;
+        const uint32_t q_granules = (40960u - 256u - static_lds - small_bytes) / 16u;
+        const uint32_t dyn_bytes = small_bytes + q_granules * 16u;
+#define LAUNCH_1P(F, B) hipLaunchKernelGGL((k_prb_backward_1p<F, B>), grid, block, dyn_bytes, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, redo, q_granules)
+        if (full) { if (bvh) LAUNCH_1P(true, true); else LAUNCH_1P(true, false); }
+        else { if (bvh) LAUNCH_1P(false, true); else LAUNCH_1P(false, false); }
+#undef LAUNCH_1P
+        HIP_TRY(hipGetLastError());
+    }
+    if (full) hipLaunchKernelGGL(k_prb_backward<true>, grid, block, 0, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, (const uint32_t *) redo);
+    else hipLaunchKernelGGL(k_prb_backward<false>, grid, block, 0, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, (const uint32_t *) redo);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
     s->n_gen += a.n_local;
@@ -1211,7 +1325,7 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[8]; HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->n_gen = s->n_gen; out->n_isect = h[1]; out->n_shade = h[2]; out->n_shadow = h[3]; out->n_splat = s->n_splat;
-    out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum;
+    out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum; out->n_redo_groups = h[4];
 #ifdef MI_PROF
     { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), sizeof(pr)));
       fprintf(stderr, "MI_PROF cycles: isect %llu si+hit %llu emitter %llu bsdf %llu shadow %llu tail %llu gen %llu splat %llu\n",

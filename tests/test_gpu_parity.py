@@ -417,6 +417,53 @@ def test_render_backward_matches_oracle(mi, orc, torch_cuda, textured):
     assert np.allclose(params.grad(key).cpu().numpy(), g_ref[[o for k, i, o, s in lay_cpu if k == 0 and scene.bsdfs[i].id == "red"][0]:][:3], rtol=2e-3, atol=1e-5)
 
 
+def _all_textured_cbox(mi, res=32):
+    d = small_cbox(mi, res)
+    rng = np.random.default_rng(3)
+    for name in ("white", "red", "green"):
+        d[name] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": rng.uniform(0.3, 0.9, (8, 8, 3)).astype(np.float32),
+                                                      "raw": True, "filter_type": "bilinear" if name != "red" else "nearest", "wrap_mode": "repeat"}}
+    return d
+
+
+@pytest.mark.parametrize("case", ["constant", "textured", "overflow", "veach"])
+def test_one_pass_adjoint_equals_two_pass(mi, orc, torch_cuda, case):
+    """The default backward kernel walks every path once and resolves gradient records with L_total afterwards;
+    MI355_FLAG_TWO_PASS is prb.py's primal + adjoint replay.  Same gradients (the difference is fp32 rounding of
+    L_total - P_k), same event counts per walk; a workgroup whose record queue overflows is redone by the two-pass kernel
+    ("overflow": every wall textured, long paths -> 3 granules per vertex, more than the queue holds)."""
+    torch = torch_cuda
+    if case == "veach":
+        scene = mi.load_dict(mi.veach_mis_scene(48)); integ_args = {"max_depth": 5, "rr_depth": 3}; res = 48
+    else:
+        d = {"constant": small_cbox(mi, 32), "textured": _textured_cbox(mi), "overflow": _all_textured_cbox(mi)}[case]
+        scene = mi.load_dict(d); res = 32
+        integ_args = {"max_depth": 12, "rr_depth": 12} if case == "overflow" else {"max_depth": 6, "rr_depth": 5}
+    gin = np.random.default_rng(11).normal(size=(res, res, 3)).astype(np.float32)
+    out = {}
+    for two_pass in (False, True):
+        integ = mi.PRBIntegrator(integ_args); integ.two_pass = two_pass
+        params = mi.traverse(scene)
+        integ.counters(scene, reset=True)
+        out[two_pass] = integ.render_backward(scene, params, torch.tensor(gin), seed=5, spp=32).cpu().numpy().copy()
+        c = integ.counters(scene, reset=True)
+        out[(two_pass, "c")] = c
+    a, b = out[False], out[True]
+    assert np.isfinite(a).all() and np.abs(b).max() > 0
+    lay, total = mi.scene_param_layout(scene)
+    for kind, index, off, size in lay:
+        scale = max(np.abs(b[off:off + size]).max(), 1e-6)
+        assert np.abs(a[off:off + size] - b[off:off + size]).max() < 1e-3 * scale, (case, kind, index)
+    c1, c2 = out[(False, "c")], out[(True, "c")]
+    assert c2["n_redo_groups"] == 0
+    if case == "overflow":
+        assert c1["n_redo_groups"] > 0
+    else:
+        assert c1["n_redo_groups"] == 0, c1["n_redo_groups"]
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert 2 * c1[k] == c2[k], k                                  # one walk instead of two
+
+
 def test_render_op_autograd(mi, orc, torch_cuda, cbox32):
     """mi.render as a differentiable op (util.py:410-523): loss.backward() fills the leaf's .grad with what
     render_backward computes for grad_in = dLoss/dImage, using seed_grad = tea32(seed, 1)[0]."""
