@@ -1245,17 +1245,22 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
 //     A'_k = dL * (inv_k * dval_k),   C'_k = dL * (direct_k - (P_k * inv_k) * dval_k).
 // So one walk suffices: each vertex queues (target, A', C') in LDS, the lane publishes L_total = P_last when its path ends,
 // and the workgroup resolves the records when all of its paths are done.  Emitter-radiance gradients do not depend on L
-// and are accumulated at once, exactly as in the two-pass kernel.  Records live in 16-byte granules of one LDS queue; the
-// first dword of a record's first granule is a tag  kind << 30 | index << 8 | lane  (continuation granules start with a
-// dword whose top two bits are clear, so the resolver can scan granules in parallel):
-//   constant reflectance : 1 granule  (GK_SMALL | slot | lane, A'rgb)                      -- C' goes to s_grad immediately
-//   texture              : 3 granules (GK_TEX | tex | lane, texel(0,0), texel(1,1), w1x) (w1y in [0,1], A'rgb) (0, C'rgb)
+// and are accumulated at once, exactly as in the two-pass kernel.  Records live in 16-byte granules of one LDS queue that
+// is filled from both ends (one 32-bit counter: low half = granules used at the bottom, high half = records at the top),
+// so the resolver walks two dense lists:
+//   constant reflectance, from the bottom : 1 granule  (slot << 8 | lane, A'rgb)         -- C' goes to s_grad immediately
+//   texture, from the top                 : 3 granules (tex << 8 | lane, texel(0,0), texel(1,1), w1x) (w1y, A'rgb) (0, C'rgb)
 // A workgroup whose queue overflows raises `overflow`, publishes nothing and is redone by the two-pass kernel, so the result
 // never depends on the queue size.
 // -------------------------------------------------------------------------------------------
-struct GradSink1 { float *s_grad; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad; };
-#define GK_SMALL 0x40000000u
-#define GK_TEX   0x80000000u
+// s_grad holds 2^copy_shift copies of every small-parameter accumulator, copy = lane % copies: the lanes of a wave mostly
+// add to the SAME parameter (the one light, the white walls), which on a single LDS word serialises 64-fold.
+struct GradSink1 { float *s_grad; uint32_t copy_shift; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad; };
+MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {
+    const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
+    float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
+    atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
+}
 
 template <bool FULL>
 MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
@@ -1282,10 +1287,8 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                 le_front = si.wi.z > 0.f;
                 v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
                 Le = (beta * le_mis) * e;
-                if (le_front && sc.emitters[emitter].grad_slot >= 0) {     // d Le / d radiance
-                    float *gb = sink.s_grad + sc.emitters[emitter].grad_slot;
-                    atomicAdd(gb + 0, dL.x * beta.x * le_mis); atomicAdd(gb + 1, dL.y * beta.y * le_mis); atomicAdd(gb + 2, dL.z * beta.z * le_mis);
-                }
+                if (le_front && sc.emitters[emitter].grad_slot >= 0)       // d Le / d radiance
+                    small_grad_add(sink, sc.emitters[emitter].grad_slot, V3(dL.x * beta.x * le_mis, dL.y * beta.y * le_mis, dL.z * beta.z * le_mis));
             }
             active_next = active_next && (depth + 1 < max_depth);          // prb.py:139
             if (!(it + 1 < max_depth)) { P = P + Le; depth += 1; continue; }   // last vertex: only Le remains (see prb_sample)
@@ -1340,36 +1343,35 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                 bool want_tex = is_diffuse && bsdf.texture >= 0 && sink.have_tex_grad && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0;
                 bool want_small = is_diffuse && bsdf.texture < 0 && bsdf.grad_slot >= 0;
                 if (want_small) {                                          // the known part needs no queue
-                    float *gb = sink.s_grad + bsdf.grad_slot;
-                    atomicAdd(gb + 0, Cc.x); atomicAdd(gb + 1, Cc.y); atomicAdd(gb + 2, Cc.z);
+                    small_grad_add(sink, bsdf.grad_slot, Cc);
                     want_small = ev_active;                                // A' == 0 otherwise
                 }
                 unsigned long long mt = __ballot(want_tex), ms = __ballot(want_small);
                 if (mt | ms) {                                             // wave-aggregated granule allocation: one LDS atomic per wave
                     uint32_t rt = __builtin_amdgcn_mbcnt_hi((uint32_t) (mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mt, 0u));
                     uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
-                    uint32_t total = 3u * (uint32_t) __popcll(mt) + (uint32_t) __popcll(ms);
+                    const uint32_t nt = (uint32_t) __popcll(mt), ns = (uint32_t) __popcll(ms);
                     const uint32_t leader = (uint32_t) __ffsll((long long) (mt | ms)) - 1u;   // lane 0 may be masked off here
                     const bool lead = (threadIdx.x & 63u) == leader;
                     uint32_t base = 0;
-                    if (lead) base = atomicAdd(sink.qn, total);
+                    if (lead) base = atomicAdd(sink.qn, ns | (nt << 16));
                     base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
-                    uint32_t g = base + 3u * rt + rs;
-                    if (base + total > sink.qcap) { if (lead) *sink.overflow = 1u; }
+                    const uint32_t base_s = base & 0xffffu, base_t = base >> 16;
+                    const uint32_t g = want_tex ? sink.qcap - 3u * (base_t + rt + 1u) : base_s + rs;
+                    if ((base_s + ns) + 3u * (base_t + nt) > sink.qcap || base_s + ns > 0xffffu || base_t + nt > 0xffffu) { if (lead) *sink.overflow = 1u; }
                     else if (want_tex) {
                         int32_t i11 = taps.idx[3] >= 0 ? taps.idx[3] : taps.idx[0];          // nearest filter: one tap of weight 1
                         float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];   // w = (w0y|w1y) * (w0x|w1x), sums to 1
-                        sink.q[g] = make_float4(__uint_as_float(GK_TEX | ((uint32_t) bsdf.texture << 8) | lane_in_block), __uint_as_float((uint32_t) taps.idx[0]),
+                        sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.texture << 8) | lane_in_block), __uint_as_float((uint32_t) taps.idx[0]),
                                                 __uint_as_float((uint32_t) i11), w1x);
                         sink.q[g + 1] = make_float4(w1y, A.x, A.y, A.z);
                         sink.q[g + 2] = make_float4(0.f, Cc.x, Cc.y, Cc.z);
                     } else if (want_small)
-                        sink.q[g] = make_float4(__uint_as_float(GK_SMALL | ((uint32_t) bsdf.grad_slot << 8) | lane_in_block), A.x, A.y, A.z);
+                        sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.grad_slot << 8) | lane_in_block), A.x, A.y, A.z);
                 }
                 if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
-                    float *gb = sink.s_grad + sc.emitters[ds.emitter].grad_slot;
                     v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
-                    atomicAdd(gb + 0, dL.x * w.x); atomicAdd(gb + 1, dL.y * w.y); atomicAdd(gb + 2, dL.z * w.z);
+                    small_grad_add(sink, sc.emitters[ds.emitter].grad_slot, dL * w);
                 }
             }
             depth += 1;                                                    // prb.py:249

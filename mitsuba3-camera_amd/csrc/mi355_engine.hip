@@ -495,17 +495,18 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
 template <bool FULL, bool BVH>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward_1p(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
-                                                        unsigned long long *g_counters, uint32_t *redo, uint32_t q_granules) {
-    extern __shared__ __attribute__((aligned(16))) float4 dyn_lds[];        // [n_small rounded up to 4 floats][q_granules x 16 B]
+                                                        unsigned long long *g_counters, uint32_t *redo, uint32_t q_granules, uint32_t copy_shift) {
+    extern __shared__ __attribute__((aligned(16))) float4 dyn_lds[];        // [(n_small << copy_shift) rounded up to 4 floats][q_granules x 16 B]
     __shared__ __attribute__((aligned(16))) float smem[BVH ? WAVES * STACK_WORDS : 64];
     __shared__ float s_ltot[3 * BLOCK];
     float *s_grad = reinterpret_cast<float *>(dyn_lds);
-    float4 *s_q = dyn_lds + (n_small + 3u) / 4u;
+    const uint32_t n_acc = n_small << copy_shift;
+    float4 *s_q = dyn_lds + (n_acc + 3u) / 4u;
     __shared__ uint32_t s_qn, s_over;
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_qn = 0; s_over = 0; }
-    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) s_grad[k] = 0.f;
+    for (uint32_t k = threadIdx.x; k < n_acc; k += BLOCK) s_grad[k] = 0.f;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + (BVH ? wave * STACK_WORDS : 0u)) + (BVH ? lane_id : 0u);
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
     dL = dL * cam_w;                                                        // value = L * weight, common.py:752
     Counters3 cnt = {};
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
-    GradSink1 sink = { s_grad, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr };
+    GradSink1 sink = { s_grad, copy_shift, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr };
     v3 L;
     prb_sample_1p<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, dL, sink, L, cnt);
     s_ltot[threadIdx.x] = L.x; s_ltot[BLOCK + threadIdx.x] = L.y; s_ltot[2 * BLOCK + threadIdx.x] = L.z;
@@ -545,25 +546,26 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
         return;
     }
     // resolve: ga = L_total(lane) * A' + C'
-    const uint32_t n_gran = min(s_qn, q_granules);
-    for (uint32_t g = threadIdx.x; g < n_gran; g += BLOCK) {
+    const uint32_t n_rec_small = s_qn & 0xffffu, n_rec_tex = s_qn >> 16;
+    for (uint32_t g = threadIdx.x; g < n_rec_small; g += BLOCK) {
         float4 r = s_q[g];
-        uint32_t tag = __float_as_uint(r.x), lane = tag & 255u, slot = (tag >> 8) & 0x3fffffu;
-        if ((tag >> 30) != (GK_SMALL >> 30)) continue;
-        atomicAdd(&s_grad[slot + 0], s_ltot[lane] * r.y); atomicAdd(&s_grad[slot + 1], s_ltot[BLOCK + lane] * r.z);
-        atomicAdd(&s_grad[slot + 2], s_ltot[2 * BLOCK + lane] * r.w);
+        uint32_t tag = __float_as_uint(r.x), lane = tag & 255u, slot = tag >> 8;
+        small_grad_add(sink, (int32_t) slot, V3(s_ltot[lane] * r.y, s_ltot[BLOCK + lane] * r.z, s_ltot[2 * BLOCK + lane] * r.w));
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) { float v = s_grad[k]; if (v != 0.f) atomicAdd(g_grad + small_map[k], v); }
+    for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) {
+        float v = 0.f;
+        for (uint32_t c = 0; c < (1u << copy_shift); ++c) v += s_grad[(k << copy_shift) + c];
+        if (v != 0.f) atomicAdd(g_grad + small_map[k], v);
+    }
     // texture records: 12 consecutive lanes expand one record into its (tap, channel) atomics, so the three channels of a
     // texel (12 contiguous bytes) leave in one wave-instruction and share a 64-B request
-    for (uint32_t e = threadIdx.x; e < n_gran * 12u; e += BLOCK) {
-        uint32_t g = e / 12u, k = e - g * 12u, tap = k / 3u, ch = k - tap * 3u;
-        float4 r0 = s_q[g];
+    for (uint32_t e = threadIdx.x; e < n_rec_tex * 12u; e += BLOCK) {
+        uint32_t rec = e / 12u, k = e - rec * 12u, tap = k / 3u, ch = k - tap * 3u;
+        const uint32_t g = q_granules - 3u * (rec + 1u);
+        float4 r0 = s_q[g], r1 = s_q[g + 1], r2 = s_q[g + 2];
         uint32_t tag = __float_as_uint(r0.x), lane = tag & 255u;
-        if ((tag >> 30) != (GK_TEX >> 30)) continue;
-        float4 r1 = s_q[g + 1], r2 = s_q[g + 2];
-        const DTexture &tx = sc.textures[(tag >> 8) & 0x3fffffu];
+        const DTexture &tx = sc.textures[tag >> 8];
         uint32_t i00 = __float_as_uint(r0.y), i11 = __float_as_uint(r0.z);
         uint32_t x0 = i00 % tx.w, x1 = i11 % tx.w;
         uint32_t idx = tap == 0 ? i00 : (tap == 3 ? i11 : (tap == 1 ? i00 - x0 + x1 : i11 - x1 + x0));
@@ -1302,10 +1304,12 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         if (n_small > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant parameters for the LDS accumulators");
         // dynamic LDS = small-parameter accumulators + record queue, sized so that 4 workgroups share a CU's 160 KB
         const uint32_t static_lds = (bvh ? WAVES * STACK_WORDS * 4u : 256u) + 3u * BLOCK * 4u + 64u;
-        const uint32_t small_bytes = ((n_small + 3u) / 4u) * 16u;
+        uint32_t copy_shift = 5;                                            // 32 copies (one per LDS bank) while they fit in 8 KB
+        while (copy_shift > 0 && (n_small << copy_shift) > 2048u) --copy_shift;
+        const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u;
         const uint32_t q_granules = (40960u - 256u - static_lds - small_bytes) / 16u;
         const uint32_t dyn_bytes = small_bytes + q_granules * 16u;
-#define LAUNCH_1P(F, B) hipLaunchKernelGGL((k_prb_backward_1p<F, B>), grid, block, dyn_bytes, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, redo, q_granules)
+#define LAUNCH_1P(F, B) hipLaunchKernelGGL((k_prb_backward_1p<F, B>), grid, block, dyn_bytes, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, redo, q_granules, copy_shift)
         if (full) { if (bvh) LAUNCH_1P(true, true); else LAUNCH_1P(true, false); }
         else { if (bvh) LAUNCH_1P(false, true); else LAUNCH_1P(false, false); }
 #undef LAUNCH_1P

@@ -30,7 +30,7 @@ def main(d, out):
             for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU_TRANS_F32"):
                 if n in m:
                     lines.append("per-wave %-22s %.1f" % (n, m[n] / w))
-        if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+        if "SQ_THREAD_CYCLES_VALU" in m and m.get("SQ_ACTIVE_INST_VALU"):
             lines.append("VALU lane utilisation        %.3f" % (m["SQ_THREAD_CYCLES_VALU"] / (64 * m["SQ_ACTIVE_INST_VALU"])))
         if "FETCH_SIZE" in m:   # KiB units; gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2 upper bound
             lines.append("HBM read bytes (FETCH_SIZE*1024, x2 corrected) %.4g .. %.4g" % (m["FETCH_SIZE"] * 1024, 2 * m["FETCH_SIZE"] * 1024))
