@@ -153,7 +153,8 @@ def main():
         rng = np.random.default_rng(12345)
         d3["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
                                                          "data": rng.uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
-        d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+        if not os.environ.get("MI355_BENCH_PLAIN"):                 # experiment switch: constant albedos only
+            d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
         scene3 = mi.load_dict(d3)
         prb_i = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb_i.timing = True
         params = mi.traverse(scene3)
@@ -171,11 +172,11 @@ def main():
         c3 = prb_i.counters(scene3, reset=True)
         if dist is not None:
             tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
-        g = params.grad("tex.reflectance.data")
-        prb = {"metric": "Msamples/s PRB backward (primal replay + adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
+        g = params.grad("tex.reflectance.data") if not os.environ.get("MI355_BENCH_PLAIN") else params.grad_buffer(dev)
+        prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
                "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
-               "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
+               "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
         scene3.release()
 
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------

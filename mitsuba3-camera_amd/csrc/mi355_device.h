@@ -1249,7 +1249,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
 // is filled from both ends (one 32-bit counter: low half = granules used at the bottom, high half = records at the top),
 // so the resolver walks two dense lists:
 //   constant reflectance, from the bottom : 1 granule  (slot << 8 | lane, A'rgb)         -- C' goes to s_grad immediately
-//   texture, from the top                 : 3 granules (tex << 8 | lane, texel(0,0), texel(1,1), w1x) (w1y, A'rgb) (0, C'rgb)
+//   texture, from the top                 : 3 granules (tex << 8 | lane, texel(0,0), texel(1,1), w1x) (w1y, A'rgb) (x1 - x0, C'rgb)
 // A workgroup whose queue overflows raises `overflow`, publishes nothing and is redone by the two-pass kernel, so the result
 // never depends on the queue size.
 // -------------------------------------------------------------------------------------------
@@ -1365,7 +1365,8 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                         sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.texture << 8) | lane_in_block), __uint_as_float((uint32_t) taps.idx[0]),
                                                 __uint_as_float((uint32_t) i11), w1x);
                         sink.q[g + 1] = make_float4(w1y, A.x, A.y, A.z);
-                        sink.q[g + 2] = make_float4(0.f, Cc.x, Cc.y, Cc.z);
+                        const int32_t dx = taps.idx[1] >= 0 ? taps.idx[1] - taps.idx[0] : 0;   // x1 - x0 (negative when the tap wraps)
+                        sink.q[g + 2] = make_float4(__uint_as_float((uint32_t) dx), Cc.x, Cc.y, Cc.z);
                     } else if (want_small)
                         sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.grad_slot << 8) | lane_in_block), A.x, A.y, A.z);
                 }
