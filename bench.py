@@ -176,6 +176,13 @@ def main():
         prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
                "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
+               "roofline": (lambda kms, L: {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "k_prepare_grad + k_prb_backward_1p (+ redo)",
+                                            "algorithmic_bytes_per_launch": int(L), "achieved": round(L / (kms * 1e-3) / 1e9, 1),
+                                            "frac": round(L / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})(
+                   c3["kernel_ms"] / max(c3["kernel_launches"], 1),
+                   # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
+                   ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
+                   + 8 * params.grad_buffer(dev).numel()),
                "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
         scene3.release()
 
