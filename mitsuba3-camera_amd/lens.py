@@ -202,9 +202,68 @@ def build_exp1_doublet(cauchy_a, cauchy_b, stop_ratio=1.0):
                            [1000.0, 24.0, -24.0, -168.01068267], [8.0, 8.0, 8.0, 8.0], [AIR, AIR, glass_a, glass_b, AIR], stop_ratio)
 
 
+S, A = SPHERE, APERTURE
+
+
+def _cauchy(name, a, b):
+    return DispersiveMaterial(name, cauchy=(a, b))
+
+
+def build_tessar(stop_ratio=1.0):
+    """realisticlens.cpp:977-1029 (prescription: henryquach.org/tessar.html); Sellmeier glasses"""
+    nlak9 = DispersiveMaterial("NLAK9", sellmeier=[(1.462319050, 0.007242702), (0.344399589, 0.0243353131), (1.155083720, 85.46868680)])
+    k10 = DispersiveMaterial("K10", sellmeier=[(1.156870820, 0.008094243), (0.064262544, 0.0386051284), (0.872376139, 104.74773000)])
+    f2 = DispersiveMaterial("F2", sellmeier=[(1.397570370, 0.009959061), (0.159201403, 0.0546931752), (1.268654300, 119.24834600)])
+    return build_from_data([S, S, S, S, A, S, S, S], [3.567, 2.286, 2.290, 2.289, 1.999, 2.286, 9.941, 86.917],
+                           [35.034, -296.111, -63.028, 31.297, 1e8, -86.620, 45.344, -43.567], [9.0, 9.0, 6.0, 6.0, 4.65, 8.0, 8.0, 8.0],
+                           [AIR, nlak9, AIR, f2, AIR, AIR, k10, nlak9, AIR], stop_ratio)
+
+
+def build_helios(stop_ratio=1.0):
+    """realisticlens.cpp:1032-1086 (Helios 44M-4, photonstophotos.net OpticalBench GOI/ST01FB06)"""
+    bf16, tk14, lf7 = _cauchy("BF16", 1.648275034, 0.007806736), _cauchy("TK14", 1.597547619, 0.005351918), _cauchy("LF7", 1.551328271, 0.008025103)
+    return build_from_data([S, S, S, S, S, A, S, S, S, S, S], [4.81, 2.26, 9.07, 1.31, 4.7, 4.63, 1.32, 6.25, 0.5, 4.94, 38.08],
+                           [38.07, 136.365, 25.33, -124.225, 15.995, 1e8, -16.62, 66.085, -22.21, 191.54, -52.725],
+                           [14.75, 14.75, 13.2, 11.6, 9.75, 9.575, 9.35, 10.2, 10.6, 12.35, 12.35],
+                           [AIR, tk14, AIR, tk14, lf7, AIR, AIR, lf7, tk14, AIR, bf16, AIR], stop_ratio)
+
+
+def build_jupiter(stop_ratio=1.0):
+    """realisticlens.cpp:1089-1149 (Jupiter-9, photonstophotos.net OpticalBench GOI/ST01FB43)"""
+    tk16, bf13, k1 = _cauchy("TK16", 1.596466676, 0.00558386), _cauchy("BF13", 1.618336084, 0.007302944), _cauchy("K1", 1.486688667, 0.00398663)
+    tf2, of1, bf7 = _cauchy("TF2", 1.637217608, 0.012112489), _cauchy("OF1", 1.513488027, 0.005500433), _cauchy("BF7", 1.562693323, 0.005811246)
+    return build_from_data([S, S, S, S, S, S, A, S, S, S, S], [5.6, 0.4, 5.8, 7.5, 1.8, 10.0, 3.8, 2.8, 10.6, 2.9, 40.53],
+                           [46.45, 268.5, 25.94, 52.0, -264.2, 16.444, 1e8, -1043.65, 44.51, -15.031, -95.06],
+                           [22.0, 22.0, 19.015, 19.015, 19.015, 12.68, 12.275, 24.57 * 0.5, 13.5, 13.5, 15.15],
+                           [AIR, tk16, AIR, bf13, k1, tf2, AIR, AIR, of1, bf13, bf7, AIR], stop_ratio)
+
+
+def build_fisheye(stop_ratio=1.0):
+    """realisticlens.cpp:1152-1220 (JP1988-017421 example 3, photonstophotos.net OpticalBench)"""
+    ga, gb, gc = _cauchy("glass_A", 1.5881276381075704, 0.005202992085188941), _cauchy("glass_B", 1.793242496642434, 0.018550536235572006), \
+        _cauchy("glass_C", 1.4770186893501427, 0.003636419065560783)
+    gd, ge = _cauchy("glass_D", 1.6021851259042148, 0.005144827846028017), _cauchy("glass_E", 1.4983808648479255, 0.004423976662977713)
+    return build_from_data([S] * 8 + [A] + [S] * 7, [2.5, 11.83, 2.5, 7.54, 5.34, 1.85, 6.71, 3.84, 3.53, 2.72, 0.15, 3.99, 5.14, 0.15, 4.84, 39.67],
+                           [78.06, 15.9, 22.22, 13.27, 127.88, 22.35, 32.04, -190.22, -1000000.0, -289.77, -29.1, -100.42, 29.39, -25.73, 43.88, -43.88],
+                           [31.725, 15.9, 13.89, 10.69, 9.955, 7.61, 6.73, 6.73, 6.659, 7.21, 7.21, 9.52, 9.52, 9.52, 11.71, 11.71],
+                           [AIR, ga, AIR, gd, AIR, ga, AIR, gb, AIR, AIR, ge, AIR, gb, gc, AIR, gc, AIR], stop_ratio)
+
+
+def build_double_gauss(stop_ratio=1.0):
+    """realisticlens.cpp:1223-1280 (double Gauss from Smith, Modern Optical Engineering)"""
+    ga, gb, gc = _cauchy("glass_A", 1.64855004723031, 0.00744902140861971), _cauchy("glass_B", 1.66398266226799, 0.0121606281020403), \
+        _cauchy("glass_C", 1.57907201321296, 0.00830957940819446)
+    gd, ge = _cauchy("glass_D", 1.64068415393588, 0.00601335161083744), _cauchy("glass_E", 1.69447574875623, 0.00782209786331075)
+    return build_from_data([S, S, S, S, S, A, S, S, S, S, S], [7.52, 0.24, 8.05, 6.55, 11.41, 9.0, 2.36, 12.13, 0.38, 6.44, 72.228],
+                           [58.95, 169.66, 38.55, 81.54, 25.5, 10000000.0, -28.99, 81.54, -40.77, 874.13, -79.46],
+                           [25.2, 25.2, 23.0, 23.0, 18.0, 17.1, 17.0, 20.0, 20.0, 20.0, 20.0],
+                           [AIR, ga, AIR, ga, gb, AIR, AIR, gc, gd, AIR, ge, AIR], stop_ratio)
+
+
+TABLE_DESIGNS = {"tessar": build_tessar, "helios": build_helios, "jupiter": build_jupiter, "fisheye": build_fisheye, "gauss": build_double_gauss}
 EXP1 = {"exp1a": (1.5689525390422485, 0.0263051608728981), "exp1b": (1.507009332993809, 0.04781645616233479),
         "exp1c": (1.5030211256389316, 0.04920145883751409)}     # realisticlens.cpp:883-888
-UNSUPPORTED_DESIGNS = ("tessar", "helios", "jupiter", "fisheye", "gauss", "hypercentric", "asph", "exp2a", "exp2b", "exp2c")
+UNSUPPORTED_DESIGNS = ("hypercentric", "asph", "exp2a", "exp2b", "exp2c")     # need aspherical interfaces / their own focusing
 
 
 def build_lens(props, film_half_width):
@@ -215,9 +274,12 @@ def build_lens(props, film_half_width):
     lens_diameter = float(props.get("lens_diameter", 0.01))
     stop_ratio = float(props.get("stop_ratio", 1.0))
     if design in UNSUPPORTED_DESIGNS:
-        raise NotImplementedError('lens_design "%s": prescription table not carried by this build (singlet, doublet, exp1a/b/c)' % design)
+        raise NotImplementedError('lens_design "%s": aspherical interfaces are not built (carried: singlet, doublet, tessar, helios, '
+                                  'jupiter, fisheye, gauss, exp1a/b/c)' % design)
     if design == "doublet":
         itf = build_doublet(object_distance, focal_length / 2, lens_diameter / 2)
+    elif design in TABLE_DESIGNS:
+        itf = TABLE_DESIGNS[design](stop_ratio=stop_ratio)
     elif design in EXP1:
         itf = build_exp1_doublet(*EXP1[design], stop_ratio=stop_ratio)
     else:

@@ -219,6 +219,89 @@ def _load_obj(filename):
     return pos, nrm, uv, np.array(tris, dtype=np.uint32)
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def _load_ply(filename):
+    """Stanford PLY reader (ascii / binary_little_endian / binary_big_endian), the vertex/face buffer format of
+    src/shapes/ply.cpp: vertex x y z [nx ny nz] [u v | s t], faces as `vertex_indices` / `vertex_index` lists (triangles, or
+    convex polygons fanned like obj.cpp).  Other elements and properties are skipped."""
+    with open(filename, "rb") as fh:
+        if fh.readline().strip() != b"ply":
+            raise PluginError('"%s" is not a PLY file' % filename)
+        fmt, elements = None, []
+        while True:
+            line = fh.readline()
+            if not line:
+                raise PluginError("PLY header of \"%s\" is truncated" % filename)
+            t = line.decode("ascii", "replace").split()
+            if not t or t[0] in ("comment", "obj_info"):
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "element":
+                elements.append({"name": t[1], "count": int(t[2]), "props": []})
+            elif t[0] == "property":
+                if t[1] == "list":
+                    elements[-1]["props"].append(("list", _PLY_TYPES[t[2]], _PLY_TYPES[t[3]], t[4]))
+                else:
+                    elements[-1]["props"].append(("scalar", _PLY_TYPES[t[1]], None, t[2]))
+            elif t[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise PluginError('PLY format "%s" is not supported' % fmt)
+        end = "<" if fmt != "binary_big_endian" else ">"
+        verts, faces = {}, []
+        for el in elements:
+            scalar_only = all(p[0] == "scalar" for p in el["props"])
+            if fmt == "ascii":
+                rows = [fh.readline().split() for _ in range(el["count"])]
+                if el["name"] == "vertex":
+                    for j, p in enumerate(el["props"]):
+                        verts[p[3]] = np.array([float(r[j]) for r in rows], dtype=np.float64)
+                elif el["name"] == "face":
+                    for r in rows:
+                        k = 0
+                        for p in el["props"]:
+                            if p[0] == "list":
+                                n = int(r[k]); vals = [int(x) for x in r[k + 1:k + 1 + n]]; k += 1 + n
+                                if p[3] in ("vertex_indices", "vertex_index"):
+                                    faces.extend([vals[0], vals[i], vals[i + 1]] for i in range(1, n - 1))
+                            else:
+                                k += 1
+                continue
+            if scalar_only:
+                dt = np.dtype([(p[3], end + p[1]) for p in el["props"]])
+                data = np.frombuffer(fh.read(dt.itemsize * el["count"]), dtype=dt, count=el["count"])
+                if el["name"] == "vertex":
+                    for p in el["props"]:
+                        verts[p[3]] = data[p[3]].astype(np.float64)
+                continue
+            for _ in range(el["count"]):                      # lists: variable-length rows
+                for p in el["props"]:
+                    if p[0] == "list":
+                        n = int(np.frombuffer(fh.read(np.dtype(p[1]).itemsize), dtype=end + p[1])[0])
+                        vals = np.frombuffer(fh.read(np.dtype(p[2]).itemsize * n), dtype=end + p[2]).astype(np.int64)
+                        if el["name"] == "face" and p[3] in ("vertex_indices", "vertex_index"):
+                            faces.extend([int(vals[0]), int(vals[i]), int(vals[i + 1])] for i in range(1, n - 1))
+                    else:
+                        fh.read(np.dtype(p[1]).itemsize)
+    if not all(k in verts for k in ("x", "y", "z")) or not faces:
+        raise PluginError('PLY file "%s" has no x/y/z vertices or no faces' % filename)
+    pos = np.stack([verts["x"], verts["y"], verts["z"]], axis=1).astype(np.float32)
+    nrm = np.stack([verts["nx"], verts["ny"], verts["nz"]], axis=1).astype(np.float32) if all(k in verts for k in ("nx", "ny", "nz")) else None
+    uv = None
+    for a, b in (("u", "v"), ("s", "t"), ("texture_u", "texture_v")):
+        if a in verts and b in verts:
+            uv = np.stack([verts[a], verts[b]], axis=1).astype(np.float32)
+            break
+    f = np.array(faces, dtype=np.uint32)
+    if f.max() >= pos.shape[0]:
+        raise PluginError('PLY file "%s": face index out of range' % filename)
+    return pos, nrm, uv, f
+
+
 class Film:
     def __init__(self, props):
         t = props.get("type", "hdrfilm")
@@ -487,10 +570,10 @@ def load_dict(d):
             scene.sensor = Sensor(v)
         elif vt in ("diffuse", "roughconductor", "dielectric"):
             named[key] = _make_bsdf(scene, v, key)
-        elif vt in ("rectangle", "cube", "obj", "mesh", "sphere"):
+        elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere"):
             pending_shapes.append((key, v))
         elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "ptracer", "aov",
-                    "disk", "cylinder", "ply", "serialized", "constant", "point", "envmap", "directional",
+                    "disk", "cylinder", "serialized", "constant", "point", "envmap", "directional",
                     "conductor", "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)
         else:
@@ -518,8 +601,8 @@ def load_dict(d):
         shape = Shape(key, kind, tw, bsdf, flip_normals=bool(v.get("flip_normals", False)))
         if vt == "cube":
             _make_cube(shape)
-        elif vt == "obj":
-            pos, nrm, uv, faces = _load_obj(v["filename"])
+        elif vt in ("obj", "ply"):
+            pos, nrm, uv, faces = (_load_obj if vt == "obj" else _load_ply)(v["filename"])
             m, it = tw.matrix, tw.inverse_transpose
             shape.vertex_positions = np.ascontiguousarray((pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
             if nrm is not None and not v.get("face_normals", False):

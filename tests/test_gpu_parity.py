@@ -345,7 +345,7 @@ def _lens_cbox(mi, design, res=32):
     return mi.load_dict(d)
 
 
-@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a"])
+@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a", "tessar", "fisheye"])
 def test_realisticlens_matches_oracle(mi, orc, torch_cuda, design):
     torch = torch_cuda
     scene = _lens_cbox(mi, design)

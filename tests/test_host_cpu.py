@@ -98,6 +98,27 @@ def test_obj_loader(mi, tmp_path):
     assert np.isclose(s.surface_area(), 1.0) and s.vertex_normals is not None and s.vertex_texcoords is not None
 
 
+def test_ply_loader(mi, tmp_path):
+    """ASCII and binary PLY (src/shapes/ply.cpp's buffer format): same quad as the OBJ test, a skipped extra property, a fan."""
+    import struct
+    v = [(0, 0, 0, 0, 0), (1, 0, 0, 1, 0), (1, 1, 0, 1, 1), (0, 1, 0, 0, 1)]
+    hdr = "ply\nformat %s 1.0\ncomment test\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n" \
+          "property float u\nproperty float v\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n"
+    a = tmp_path / "a.ply"
+    a.write_text(hdr % "ascii" + "".join("%g %g %g 7 %g %g\n" % (x, y, z, s, t) for x, y, z, s, t in v) + "4 0 1 2 3\n")
+    b = tmp_path / "b.ply"
+    b.write_bytes((hdr % "binary_little_endian").encode() + b"".join(struct.pack("<fffBff", x, y, z, 7, s, t) for x, y, z, s, t in v)
+                  + struct.pack("<Biiii", 4, 0, 1, 2, 3))
+    for p in (a, b):
+        sc = mi.load_dict({"type": "scene", "q": {"type": "ply", "filename": str(p), "to_world": mi.ScalarTransform4f.translate([0, 0, 2])}})
+        s = sc.shapes[0]
+        assert s.primitive_count() == 2 and s.vertex_positions.shape == (4, 3) and np.allclose(s.vertex_positions[:, 2], 2)
+        assert np.isclose(s.surface_area(), 1.0) and s.vertex_normals is None and np.allclose(s.vertex_texcoords[2], [1, 1])
+    bad = tmp_path / "bad.ply"; bad.write_text("plx\n")
+    with pytest.raises(mi.PluginError):
+        mi.load_dict({"type": "scene", "q": {"type": "ply", "filename": str(bad)}})
+
+
 def test_shard_pixels_partition(mi):
     for n, w in [(1024, 1), (1024, 3), (1000, 8), (7, 8)]:
         cover = np.zeros(n, dtype=int)

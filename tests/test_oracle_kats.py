@@ -515,7 +515,7 @@ def _lens_scene(mi, design, res=32, diagonal=30.0, **extra):
     return mi.load_dict(d)
 
 
-@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a"])
+@pytest.mark.parametrize("design", ["singlet", "doublet", "exp1a", "tessar", "helios", "jupiter", "fisheye", "gauss"])
 def test_lens_focus_and_trace(orc, mi, design):
     """Paraxial self-check in the spirit of notebooks/scripts/lens_design/design_problem.py:430-472: after the constructor's
     thick-lens fine focus (realisticlens.cpp:899-905, :2161-2171) rays leaving one film point through different points of a
@@ -543,7 +543,7 @@ def test_lens_focus_and_trace(orc, mi, design):
     wide = o.lens_rays(np.tile(np.array([32.0, 32.0], dtype=np.float32), (256, 1)), rng.random((256, 2), dtype=np.float32))
     assert (wide[:, 7] >= 0).all() and (wide[:, 7] <= 1 + 1e-5).all()
     with pytest.raises(mi.PluginError):
-        _lens_scene(mi, "tessar")
+        _lens_scene(mi, "asph")
 
 
 def test_lens_render_oracle(orc, mi):
