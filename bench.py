@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -186,6 +187,35 @@ def main():
                "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
         scene3.release()
 
+    # ---- optional: config C4 (FULL kernels: glossy / specular BSDFs, spheres), tile-sharded like the headline leg ----
+    c4 = None
+    if args.veach:
+        sc4 = mi.load_dict(mi.veach_mis_scene(1024))
+        i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); i4.timing = True
+        sh4 = mi.shard_tiles(1024, 1024, rank, world, rows=TILE_ROWS) if world > 1 else None
+        film4 = torch.zeros((1024, 1024, 4), dtype=torch.float32, device=dev)
+        h4 = sc4.handle(local_rank)
+        def step4(seed):
+            film4.zero_()
+            p = i4._params(sc4, seed, 512, shard=sh4)
+            mi.abi.check(lib.mi355_render_accumulate(h4, C.byref(p), C.c_void_p(film4.data_ptr()), stream))
+            if dist is not None:
+                dist.all_reduce(film4, op=dist.ReduceOp.SUM)
+        step4(99); barrier(); i4.counters(sc4, reset=True)
+        n4 = max(2, args.steps // 3)
+        t0 = time.perf_counter()
+        for i in range(n4):
+            step4(i)
+        barrier(); dt4 = time.perf_counter() - t0
+        k4 = i4.counters(sc4, reset=True)
+        if dist is not None:
+            tt = torch.tensor([dt4], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt4 = float(tt.item())
+        c4 = {"metric": "Msamples/s forward, Veach-MIS scene 1024^2 @512spp (BASELINE configs[3])", "value": round(1024 * 1024 * 512 * n4 / dt4 / 1e6, 2),
+              "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2), "kernel_ms": round(k4["kernel_ms"] / max(k4["kernel_launches"], 1), 3),
+              "events_per_lane": {k: round(k4[k] / max(k4["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")},
+              "finite": bool(torch.isfinite(film4).all().item())}
+        sc4.release()
+
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -213,6 +243,8 @@ def main():
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
                           "lanes_per_step": lanes_per_step, "mode": "fused", "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
+        if c4 is not None:
+            out["veach"] = c4
         print(json.dumps(out), flush=True)
     scene.release()
     if dist is not None:

@@ -981,6 +981,8 @@ MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, fl
 }
 
 // MI_PROF (diagnostic builds only, tools/section_profile.py): per-wave s_memtime deltas per section of the path loop
+// Event counters are WAVE totals kept in SGPRs (ballot + s_bcnt1): no VGPR and no VALU instruction is spent on them.
+MI_DEV uint32_t wave_count(bool pred) { return (uint32_t) __popcll(__ballot(pred)); }
 #ifdef MI_PROF
 struct Counters3 { uint32_t isect, shade, shadow; uint32_t prof[8]; unsigned long long t; };
 static __device__ unsigned long long g_prof[8];
@@ -1013,13 +1015,13 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     PROF_START(cnt);
     Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
     PROF(cnt, 0);
-    if (active) cnt.isect++;
+    cnt.isect += wave_count(active);
     bool si_valid = active && hit.t != MI_INF;
     bool active_next = si_valid && (it + 1 < max_depth);                    // path.cpp:177
     bool alive = false;
     hit_any = si_valid;
     if (si_valid) {
-        cnt.shade++;
+        cnt.shade += wave_count(true);
         SI si = compute_si<FULL>(sc, st.ray, hit);
         const DShape &sh = sc.shapes[hit.shape];
         int32_t emitter = sh.emitter;
@@ -1053,7 +1055,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             PROF(cnt, 3);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
             PROF(cnt, 4);
-            if (need_shadow) cnt.shadow++;
+            cnt.shadow += wave_count(need_shadow);
             if (need_shadow && !occluded) st.result = fma3(st.throughput, contrib, st.result);   // path.cpp:220-230
             // ---- BSDF sampling + loop update (path.cpp:234-280)
             st.ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
@@ -1108,12 +1110,12 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
     v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
-        if (active) cnt.isect++;
+        cnt.isect += wave_count(active);
         bool si_valid = active && hit.t != MI_INF;
         bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
         active = false;
         if (si_valid) {
-            cnt.shade++;
+            cnt.shade += wave_count(true);
             SI si = compute_si<FULL>(sc, ray, hit);
             const DShape &sh = sc.shapes[hit.shape];
             int32_t emitter = sh.emitter;
@@ -1148,7 +1150,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
-            if (need_shadow) cnt.shadow++;
+            cnt.shadow += wave_count(need_shadow);
             bool active_em = need_shadow && !occluded;
             if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
             v3 wo = si_to_local(si, ds.d);
@@ -1270,12 +1272,12 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
     v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
-        if (active) cnt.isect++;
+        cnt.isect += wave_count(active);
         bool si_valid = active && hit.t != MI_INF;
         bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
         active = false;
         if (si_valid) {
-            cnt.shade++;
+            cnt.shade += wave_count(true);
             SI si = compute_si<FULL>(sc, ray, hit);
             const DShape &sh = sc.shapes[hit.shape];
             int32_t emitter = sh.emitter;
@@ -1302,7 +1304,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
             bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
-            if (need_shadow) cnt.shadow++;
+            cnt.shadow += wave_count(need_shadow);
             bool active_em = need_shadow && !occluded;
             if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
             v3 wo = si_to_local(si, ds.d);

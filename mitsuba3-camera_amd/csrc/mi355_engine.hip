@@ -137,7 +137,7 @@ MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, 
 
 MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long long *g_counters) {
     // s_cnt zeroed + synced by the caller
-    atomicAdd(&s_cnt[0], cnt.isect); atomicAdd(&s_cnt[1], cnt.shade); atomicAdd(&s_cnt[2], cnt.shadow);
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s_cnt[0], cnt.isect); atomicAdd(&s_cnt[1], cnt.shade); atomicAdd(&s_cnt[2], cnt.shadow); }   // wave totals
     __syncthreads();
     if (threadIdx.x < 3 && g_counters) atomicAdd(&g_counters[1 + threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
 }
