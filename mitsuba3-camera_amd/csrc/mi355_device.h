@@ -1017,11 +1017,11 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     PROF(cnt, 0);
     cnt.isect += wave_count(active);
     bool si_valid = active && hit.t != MI_INF;
+    cnt.shade += wave_count(si_valid);                                      // (counted here: ballot(true) inside the branch gets hoisted)
     bool active_next = si_valid && (it + 1 < max_depth);                    // path.cpp:177
-    bool alive = false;
+    bool alive = false, shadow_req = false;      // counters are only touched where control flow is wave-uniform (they live in SGPRs)
     hit_any = si_valid;
     if (si_valid) {
-        cnt.shade += wave_count(true);
         SI si = compute_si<FULL>(sc, st.ray, hit);
         const DShape &sh = sc.shapes[hit.shape];
         int32_t emitter = sh.emitter;
@@ -1055,7 +1055,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             PROF(cnt, 3);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);  // scene.cpp:341-346
             PROF(cnt, 4);
-            cnt.shadow += wave_count(need_shadow);
+            shadow_req = need_shadow;
             if (need_shadow && !occluded) st.result = fma3(st.throughput, contrib, st.result);   // path.cpp:220-230
             // ---- BSDF sampling + loop update (path.cpp:234-280)
             st.ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
@@ -1071,6 +1071,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             PROF(cnt, 5);
         }
     }
+    cnt.shadow += wave_count(shadow_req);
     return alive;
 }
 template <bool FULL>
@@ -1112,11 +1113,12 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
         cnt.isect += wave_count(active);
         bool si_valid = active && hit.t != MI_INF;
+        cnt.shade += wave_count(si_valid);                                  // (counted here: ballot(true) inside the branch gets hoisted)
         bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
         active = false;
+        bool shadow_req = false;                 // counted after the divergent region: counters live in SGPRs
         if (si_valid) {
-            cnt.shade += wave_count(true);
-            SI si = compute_si<FULL>(sc, ray, hit);
+                SI si = compute_si<FULL>(sc, ray, hit);
             const DShape &sh = sc.shapes[hit.shape];
             int32_t emitter = sh.emitter;
             v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
@@ -1150,7 +1152,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
-            cnt.shadow += wave_count(need_shadow);
+            shadow_req = need_shadow;
             bool active_em = need_shadow && !occluded;
             if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
             v3 wo = si_to_local(si, ds.d);
@@ -1236,6 +1238,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             depth += 1;                                                    // prb.py:249
             active = active_next;
         }
+        cnt.shadow += wave_count(shadow_req);
     }
     L_out = L; valid_out = depth != 0;
 }
@@ -1274,11 +1277,12 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
         cnt.isect += wave_count(active);
         bool si_valid = active && hit.t != MI_INF;
+        cnt.shade += wave_count(si_valid);                                  // (counted here: ballot(true) inside the branch gets hoisted)
         bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
         active = false;
+        bool shadow_req = false;                 // counted after the divergent region: counters live in SGPRs
         if (si_valid) {
-            cnt.shade += wave_count(true);
-            SI si = compute_si<FULL>(sc, ray, hit);
+                SI si = compute_si<FULL>(sc, ray, hit);
             const DShape &sh = sc.shapes[hit.shape];
             int32_t emitter = sh.emitter;
             v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
@@ -1304,7 +1308,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
             bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
-            cnt.shadow += wave_count(need_shadow);
+            shadow_req = need_shadow;
             bool active_em = need_shadow && !occluded;
             if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
             v3 wo = si_to_local(si, ds.d);
@@ -1380,6 +1384,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
             depth += 1;                                                    // prb.py:249
             active = active_next;
         }
+        cnt.shadow += wave_count(shadow_req);
     }
     L_out = P;
 }
