@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
+    ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (workgroup re-packing)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -84,6 +85,8 @@ def main():
     integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
     integ.timing = True
     integ.regen = args.regen
+    if args.wavefront:
+        integ.mode = mi.abi.MODE_WAVEFRONT
     h = scene.handle(local_rank)
     dev = torch.device("cuda", local_rank)
     W = H = args.res
@@ -241,7 +244,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
-                          "lanes_per_step": lanes_per_step, "mode": "fused", "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
+                          "lanes_per_step": lanes_per_step, "mode": "wavefront" if args.wavefront else ("fused+regen" if args.regen else "fused"), "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4

@@ -155,9 +155,11 @@ typedef struct mi355_scene_desc {
                                           (path regeneration).  Same samples, same film; opt-in because on the Cornell box it
                                           measured 11.3 ms against 10.8 ms for the static assignment */
 
-enum { MI355_MODE_FUSED = 0,           /* one launch per pass, a lane keeps its path in registers until it ends (default) */
-       MI355_MODE_WAVEFRONT = 1 };     /* after every bounce the workgroup re-packs surviving lanes (wave ballot + prefix sum,
-                                          SoA state exchanged through LDS) so that waves stay full; path integrator only */
+enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path state in registers; the path integrator re-packs the
+                                          live paths of a workgroup (wave ballot + prefix sum, SoA state exchanged through LDS) from
+                                          bounce 2 on whenever that empties a whole wave */
+       MI355_MODE_WAVEFRONT = 1,       /* re-pack after EVERY bounce, unconditionally; path integrator only */
+       MI355_MODE_STATIC = 2 };        /* never re-pack: a lane keeps its path until the longest path of its wave ends */
 
 enum { MI355_INTEGRATOR_PATH = 0,      /* src/integrators/path.cpp */
        MI355_INTEGRATOR_PRB  = 1 };    /* src/python/python/ad/integrators/prb.py (primal estimator differs in RR timing) */

@@ -36,7 +36,7 @@
 #define SPLAT_ROWS 14                       // 5 x-weights + 5 y-weights + 4 channel values (separable filter)
 #define WAVE_FLOATS (SPLAT_ROWS * ROW_STRIDE)
 #define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
-#define CSTATE_WORDS 21                     // per lane, k_render_compact
+#define CSTATE_WORDS 23                     // per lane, k_render_compact (21 + eta, prev_delta in FULL scenes)
 #define MAX_SMALL_GRAD 1024
 #define GRAD_QUEUE 496                      // texture-gradient records per workgroup (16 KB, 2 per lane); overflow -> direct atomics
 // one LDS region per workgroup, reused in turn by: BVH traversal stacks | compaction state exchange | film splat staging
@@ -51,6 +51,8 @@ struct RenderArgs {
     uint32_t lane_begin;       // OUT_LANES only
     uint32_t tile, tile_stride; // interleaved pixel tiles (0 = contiguous shard)
     uint32_t ppw;              // k_render_regen: shard pixels per wave
+    uint32_t compact_mask;     // k_render_compact: bit `it` set = re-pack the workgroup's live paths after bounce `it`
+    uint32_t compact_adaptive; // ... but only when that empties at least one wave
 };
 // q-th pixel of the shard -> global pixel index (mi355_render_params::pixel_tile)
 MI_DEV uint32_t shard_pixel(const RenderArgs &a, uint32_t q) {
@@ -327,11 +329,12 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen
 // from "6 bounces x 4 waves" to "sum over bounces of ceil(alive / 64)".  Final radiance returns to the lane's ORIGINAL
 // slot (`fin`) so that the per-pixel LDS film reduction still sees all samples of a pixel side by side.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
     __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_wcnt[WAVES];
+    __shared__ uint32_t s_wcnt[2 * WAVES];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_id = tid & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
@@ -340,18 +343,19 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
     float pos_x, pos_y; Ray ray0;
-    (void) camera_ray<false>(sc, rng, li.px, li.py, pos_x, pos_y, ray0);   // perspective sensors only (checked by the host)
+    const float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray0);   // stays with the ORIGINAL slot, like pos
     PathState st; path_init(st, ray0, rng);
     Counters3 cnt = {};
     fin[tid] = 0.f; fin[BLOCK + tid] = 0.f; fin[2 * BLOCK + tid] = 0.f; fin[3 * BLOCK + tid] = 0.f;
     uint32_t orig = tid;                       // which original slot the path in this thread belongs to
     bool valid_ray = false;
-    uint32_t n_alive = min((uint32_t) BLOCK, a.n_local - min(a.n_local, blockIdx.x * BLOCK));   // slots [0, n_alive) hold live paths
-    for (uint32_t it = 0; it < a.max_depth && n_alive > 0; ++it) {
-        bool mine = tid < n_alive, alive = false;
+    bool alive = li.act && cam_w > 0.f;                                      // this thread currently holds a live path
+    for (uint32_t it = 0; it < a.max_depth; ++it) {
+        const bool mine = alive;
+        alive = false;
         if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
             bool hit_any;
-            alive = path_step<false>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            alive = path_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
             valid_ray = valid_ray || hit_any;
         }
         if (mine && !alive) {                                               // path over: park its radiance in its original slot
@@ -359,13 +363,17 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
             fin[orig] = v ? st.result.x : 0.f; fin[BLOCK + orig] = v ? st.result.y : 0.f; fin[2 * BLOCK + orig] = v ? st.result.z : 0.f;
             fin[3 * BLOCK + orig] = v ? 1.f : 0.f;
         }
+        if (!((a.compact_mask >> (it < 31u ? it : 31u)) & 1u) || it + 1 >= a.max_depth) continue;   // no re-pack after this bounce
         unsigned long long m = __ballot(alive);
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-        if (lane_id == 0) s_wcnt[wave] = (uint32_t) __popcll(m);
+        uint32_t *wcnt = s_wcnt + (it & 1u) * WAVES;                        // double-buffered: a fast wave may already be one bounce ahead
+        if (lane_id == 0) wcnt[wave] = (uint32_t) __popcll(m);
         __syncthreads();                                                    // everyone is done with the stack / previous state
-        uint32_t base = 0, total = 0;
+        uint32_t base = 0, total = 0, busy = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < WAVES; ++w) { uint32_t c = s_wcnt[w]; base += w < wave ? c : 0u; total += c; }
+        for (uint32_t w = 0; w < WAVES; ++w) { uint32_t c = wcnt[w]; base += w < wave ? c : 0u; total += c; busy += c ? 1u : 0u; }
+        if (total == 0u) break;                                             // (workgroup-uniform) every path of the workgroup has ended
+        if (a.compact_adaptive && (total + 63u) / 64u >= busy) continue;    // (workgroup-uniform) re-packing would not empty a wave
         if (alive) {
             uint32_t j = base + rank;
             float *q = smem + j;
@@ -378,10 +386,11 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
             q[16 * BLOCK] = __uint_as_float((uint32_t) st.rng.state); q[17 * BLOCK] = __uint_as_float((uint32_t) (st.rng.state >> 32));
             q[18 * BLOCK] = __uint_as_float((uint32_t) st.rng.inc); q[19 * BLOCK] = __uint_as_float((uint32_t) (st.rng.inc >> 32));
             q[20 * BLOCK] = __uint_as_float(orig);
+            if (FULL) { q[21 * BLOCK] = st.eta; q[22 * BLOCK] = st.prev_delta ? 1.f : 0.f; }
         }
         __syncthreads();
-        n_alive = total;
-        if (tid < n_alive) {
+        alive = tid < total;
+        if (alive) {
             const float *q = smem + tid;
             st.ray.o = V3(q[0 * BLOCK], q[1 * BLOCK], q[2 * BLOCK]); st.ray.d = V3(q[3 * BLOCK], q[4 * BLOCK], q[5 * BLOCK]);
             st.ray.maxt = MI_LARGEST;
@@ -390,12 +399,13 @@ __global__ __launch_bounds__(BLOCK, MI_MIN_WAVES) void k_render_compact(DScene s
             st.rng.state = (uint64_t) __float_as_uint(q[16 * BLOCK]) | ((uint64_t) __float_as_uint(q[17 * BLOCK]) << 32);
             st.rng.inc = (uint64_t) __float_as_uint(q[18 * BLOCK]) | ((uint64_t) __float_as_uint(q[19 * BLOCK]) << 32);
             orig = __float_as_uint(q[20 * BLOCK]);
+            if (FULL) { st.eta = q[21 * BLOCK]; st.prev_delta = q[22 * BLOCK] != 0.f; }
             valid_ray = true;                                               // a path that continues has hit a surface
         }
         if (sc.n_bvh_shapes) __syncthreads();                               // the BVH stack aliases the state just read
     }
     __syncthreads();
-    float values[4] = { fin[tid], fin[BLOCK + tid], fin[2 * BLOCK + tid], 1.f };          // integrator.cpp:477-486 (rgb film, no alpha)
+    float values[4] = { fin[tid] * cam_w, fin[BLOCK + tid] * cam_w, fin[2 * BLOCK + tid] * cam_w, 1.f };   // integrator.cpp:461, 477-486
     Splat sp = splat_weights(sc, pos_x, pos_y);
     __syncthreads();
     film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
@@ -1244,6 +1254,7 @@ static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderA
     if (sc % 64 == 0) a->seg = 64; else if (sc >= 4 && (sc & (sc - 1)) == 0) a->seg = sc;
     a->lane_begin = 0;
     a->ppw = std::max(1u, 1024u / a->s_count);
+    a->compact_mask = 0u; a->compact_adaptive = 0u;
     return MI355_OK;
 }
 static int ensure_events(mi355_scene *s) {
@@ -1272,7 +1283,7 @@ struct Timed {
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
-    if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT) return fail(MI355_ERR_INVALID, "unknown mode");
+    if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT && p->mode != MI355_MODE_STATIC) return fail(MI355_ERR_INVALID, "unknown mode");
     if (p->mode == MI355_MODE_WAVEFRONT && p->integrator != MI355_INTEGRATOR_PATH)
         return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for the path integrator only");
     HIP_TRY(hipSetDevice(s->device));
@@ -1281,18 +1292,23 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
-    if (p->mode == MI355_MODE_WAVEFRONT && (full || s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE))
-        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for all-diffuse scenes with a perspective sensor only");
     float *nof = nullptr;
+    // path integrator: re-pack the workgroup's live paths from bounce 2 on, whenever that empties a wave (MODE_FUSED);
+    // after every bounce unconditionally (MODE_WAVEFRONT); never (MODE_STATIC)
+    // (bit 31 stands for every bounce >= 31 and must stay set: the count exchange is also the loop's exit test when max_depth = -1)
+    a.compact_mask = p->mode == MI355_MODE_WAVEFRONT ? 0xffffffffu : 0xfffffffcu;
+    a.compact_adaptive = p->mode == MI355_MODE_WAVEFRONT ? 0u : 1u;
     if (p->integrator == MI355_INTEGRATOR_PRB) {
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
-    } else if (p->mode == MI355_MODE_WAVEFRONT)
-        hipLaunchKernelGGL(k_render_compact, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
-    else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN)) {       // enough samples per pixel to keep a wave's pool full
+    } else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN) && p->mode != MI355_MODE_WAVEFRONT) {       // enough samples per pixel to keep a wave's pool full
         uint32_t n_waves = (a.pixel_count + a.ppw - 1) / a.ppw; dim3 rgrid((n_waves + WAVES - 1) / WAVES);
         if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL(k_render_regen<false>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+    }
+    else if (p->mode != MI355_MODE_STATIC) {
+        if (full) hipLaunchKernelGGL(k_render_compact<true>, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else hipLaunchKernelGGL(k_render_compact<false>, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     }
     else if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);

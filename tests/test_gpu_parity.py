@@ -209,15 +209,23 @@ def test_path_regeneration_matches_static(mi, orc, torch_cuda, spp, max_depth, r
 
 @pytest.mark.parametrize("spp,max_depth,rr_depth", [(16, 6, 5), (64, -1, 2), (3, 4, 5), (128, 2, 5)])
 def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_depth, rr_depth):
-    """MI355_MODE_WAVEFRONT re-packs lanes between bounces; lanes are still pure functions of (seed, lane id), so the film
-    must equal the fused mode's (up to float-atomic order) and the oracle's."""
+    """Re-packing modes: MODE_FUSED (default: from bounce 2 on, when it empties a wave), MODE_WAVEFRONT (after every bounce),
+    MODE_STATIC (never).  Lanes are still pure functions of (seed, lane id), so the films must agree (up to float-atomic
+    order) with each other and with the oracle's, and the event counts must be identical."""
     integ = mi.PathIntegrator({"max_depth": max_depth, "rr_depth": rr_depth})
     fused = integ.render(cbox32, seed=8, spp=spp, develop=False)
+    integ.mode = mi.abi.MODE_STATIC
+    integ.counters(cbox32, reset=True)
+    static = integ.render(cbox32, seed=8, spp=spp, develop=False)
+    c_static = integ.counters(cbox32, reset=True)
+    assert torch_cuda.allclose(static, fused, rtol=1e-4, atol=1e-4)
     integ.mode = mi.abi.MODE_WAVEFRONT
     integ.counters(cbox32, reset=True)
     wf = integ.render(cbox32, seed=8, spp=spp, develop=False)
     c_wf = integ.counters(cbox32, reset=True)
     assert torch_cuda.allclose(wf, fused, rtol=1e-4, atol=1e-4)
+    for k in ("n_isect", "n_shade", "n_shadow"):
+        assert c_wf[k] == c_static[k], k
     o = orc.OracleScene(cbox32, mi.abi)
     o.counters(reset=True)
     ref, _ = o.render(o.params(integ, 8, spp))
@@ -311,6 +319,22 @@ def test_veach_lane_radiance(mi, orc, torch_cuda, veach64, integrator_name, max_
     assert np.allclose(got[:, :3].mean(0), ref[:, :3].mean(0), rtol=2e-2)
 
 
+def test_veach_repacking_modes_agree(mi, orc, torch_cuda, veach64):
+    """FULL kernels (glossy / specular BSDFs, spheres): the re-packed state also carries eta and prev_bsdf_delta."""
+    films, counts = {}, {}
+    for mode in (mi.abi.MODE_STATIC, mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):
+        pi = mi.PathIntegrator({"max_depth": 7, "rr_depth": 3}); pi.mode = mode
+        pi.counters(veach64, reset=True)
+        films[mode] = pi.render(veach64, seed=4, spp=32, develop=False)
+        counts[mode] = pi.counters(veach64, reset=True)
+    for mode in (mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):
+        ref = films[mi.abi.MODE_STATIC]
+        err = (films[mode] - ref).abs()
+        assert float(err.max()) <= 2e-4 * float(ref.abs().max()) + 1e-4
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert counts[mode][k] == counts[mi.abi.MODE_STATIC][k], k
+
+
 def test_veach_render_and_backward(mi, orc, torch_cuda, veach64):
     torch = torch_cuda
     integ = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5})
@@ -366,9 +390,12 @@ def test_realisticlens_matches_oracle(mi, orc, torch_cuda, design):
     g = integ.render_backward(scene, params, torch.tensor(gin), seed=9, spp=16).cpu().numpy()
     g_ref = o.render_backward(o.params(integ, 9, 16), gin)
     assert np.allclose(g, g_ref, rtol=5e-3, atol=2e-3 * np.abs(g_ref).max())
-    wf = mi.PathIntegrator(); wf.mode = mi.abi.MODE_WAVEFRONT
-    with pytest.raises(mi.Mi355Error):
-        wf.render(scene, seed=1, spp=4)
+    films = {}
+    for mode in (mi.abi.MODE_STATIC, mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):      # re-packing carries eta / prev_delta and the lens weight too
+        pi = mi.PathIntegrator({"max_depth": 5}); pi.mode = mode
+        films[mode] = pi.render(scene, seed=1, spp=16, develop=False)
+    assert torch.allclose(films[mi.abi.MODE_FUSED], films[mi.abi.MODE_STATIC], rtol=2e-4, atol=2e-4)
+    assert torch.allclose(films[mi.abi.MODE_WAVEFRONT], films[mi.abi.MODE_STATIC], rtol=2e-4, atol=2e-4)
 
 
 # ---- PRB adjoint --------------------------------------------------------------------------------------
