@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
-    ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (workgroup re-packing)")
+    ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
+    ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -85,6 +86,8 @@ def main():
     integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
     integ.timing = True
     integ.regen = args.regen
+    if args.static:
+        integ.mode = mi.abi.MODE_STATIC
     if args.wavefront:
         integ.mode = mi.abi.MODE_WAVEFRONT
     h = scene.handle(local_rank)
@@ -132,6 +135,8 @@ def main():
     lanes_per_step = npix * args.spp
     value = lanes_per_step * args.steps / dt / 1e6
 
+    MODE_NAME = "wavefront" if args.wavefront else ("static" if args.static else ("fused+regen" if args.regen else "fused"))
+    KERNEL_NAME = {"static": "k_render<path,film>", "fused+regen": "k_render_regen"}.get(MODE_NAME, "k_render_compact")
     # ---- roofline of the dominant kernel (this rank's launches) ------------------------------------
     launches = max(cnt["kernel_launches"], 1)
     kernel_ms = cnt["kernel_ms"] / launches
@@ -140,12 +145,12 @@ def main():
     traffic = None                      # measured HBM bytes per launch of this kernel: a separate --pmc run (tools/pmc.sh), committed
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)["k_render<path,film>"]["bytes_per_launch"] if (world == 1 and args.res == 512 and args.spp == 256) else None
+            traffic = json.load(f)[KERNEL_NAME]["bytes_per_launch"] if (world == 1 and args.res == 512 and args.spp == 256) else None
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_render<path,film>", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                "kernel": KERNEL_NAME, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg),
                 "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}
 
@@ -244,7 +249,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
-                          "lanes_per_step": lanes_per_step, "mode": "wavefront" if args.wavefront else ("fused+regen" if args.regen else "fused"), "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
+                          "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4

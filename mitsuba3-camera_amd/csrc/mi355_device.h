@@ -1253,8 +1253,10 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
 // and are accumulated at once, exactly as in the two-pass kernel.  Records live in 16-byte granules of one LDS queue that
 // is filled from both ends (one 32-bit counter: low half = granules used at the bottom, high half = records at the top),
 // so the resolver walks two dense lists:
-//   constant reflectance, from the bottom : 1 granule  (slot << 8 | lane, A'rgb)         -- C' goes to s_grad immediately
-//   texture, from the top                 : 3 granules (tex << 8 | lane, texel(0,0), texel(1,1), w1x) (w1y, A'rgb) (x1 - x0, C'rgb)
+//   constant reflectance, from the bottom : 1 DWORD (bsdf << 8 | lane); C' goes to s_grad immediately and, for a diffuse
+//                                           BSDF, inv * dval = 1 / (albedo * pdf) * pdf is re-formed at resolve time as 1 / albedo
+//   texture, from the top                 : 3 granules (tex << 8 | lane, texel(0,0), texel(1,1), w1x) (w1y, A''rgb) (x1 - x0, C'rgb)
+// with A'' = inv * dval (dL is folded into what the lane publishes: L_total * dL).
 // A workgroup whose queue overflows raises `overflow`, publishes nothing and is redone by the two-pass kernel, so the result
 // never depends on the queue size.
 // -------------------------------------------------------------------------------------------
@@ -1344,7 +1346,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                 bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f && is_diffuse;
                 float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
                 v3 direct = ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
-                v3 A = dL * (inv * dval);
+                v3 A = inv * dval;                                         // the lane publishes L_total * dL
                 v3 Cc = dL * (direct - (P * inv) * dval);
                 bool want_tex = is_diffuse && bsdf.texture >= 0 && sink.have_tex_grad && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0;
                 bool want_small = is_diffuse && bsdf.texture < 0 && bsdf.grad_slot >= 0;
@@ -1363,8 +1365,8 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                     if (lead) base = atomicAdd(sink.qn, ns | (nt << 16));
                     base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
                     const uint32_t base_s = base & 0xffffu, base_t = base >> 16;
-                    const uint32_t g = want_tex ? sink.qcap - 3u * (base_t + rt + 1u) : base_s + rs;
-                    if ((base_s + ns) + 3u * (base_t + nt) > sink.qcap || base_s + ns > 0xffffu || base_t + nt > 0xffffu) { if (lead) *sink.overflow = 1u; }
+                    const uint32_t g = want_tex ? sink.qcap - 3u * (base_t + rt + 1u) : base_s + rs;   // granule (texture) or dword (constant) index
+                    if ((base_s + ns + 3u) / 4u + 3u * (base_t + nt) > sink.qcap || base_s + ns > 0xffffu || base_t + nt > 0xffffu) { if (lead) *sink.overflow = 1u; }
                     else if (want_tex) {
                         int32_t i11 = taps.idx[3] >= 0 ? taps.idx[3] : taps.idx[0];          // nearest filter: one tap of weight 1
                         float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];   // w = (w0y|w1y) * (w0x|w1x), sums to 1
@@ -1374,7 +1376,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
                         const int32_t dx = taps.idx[1] >= 0 ? taps.idx[1] - taps.idx[0] : 0;   // x1 - x0 (negative when the tap wraps)
                         sink.q[g + 2] = make_float4(__uint_as_float((uint32_t) dx), Cc.x, Cc.y, Cc.z);
                     } else if (want_small)
-                        sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.grad_slot << 8) | lane_in_block), A.x, A.y, A.z);
+                        reinterpret_cast<uint32_t *>(sink.q)[g] = ((uint32_t) sh.bsdf << 8) | lane_in_block;
                 }
                 if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
                     v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);

@@ -365,18 +365,28 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
         }
         if (!((a.compact_mask >> (it < 31u ? it : 31u)) & 1u) || it + 1 >= a.max_depth) continue;   // no re-pack after this bounce
         unsigned long long m = __ballot(alive);
-        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
         uint32_t *wcnt = s_wcnt + (it & 1u) * WAVES;                        // double-buffered: a fast wave may already be one bounce ahead
         if (lane_id == 0) wcnt[wave] = (uint32_t) __popcll(m);
         __syncthreads();                                                    // everyone is done with the stack / previous state
-        uint32_t base = 0, total = 0, busy = 0;
+        uint32_t total = 0, busy = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < WAVES; ++w) { uint32_t c = wcnt[w]; base += w < wave ? c : 0u; total += c; busy += c ? 1u : 0u; }
+        for (uint32_t w = 0; w < WAVES; ++w) { uint32_t c = wcnt[w]; total += c; busy += c ? 1u : 0u; }
         if (total == 0u) break;                                             // (workgroup-uniform) every path of the workgroup has ended
-        if (a.compact_adaptive && (total + 63u) / 64u >= busy) continue;    // (workgroup-uniform) re-packing would not empty a wave
-        if (alive) {
-            uint32_t j = base + rank;
-            float *q = smem + j;
+        const uint32_t needed = (total + 63u) / 64u;                        // waves that stay busy
+        if (a.compact_adaptive && needed >= busy) continue;                 // (workgroup-uniform) re-packing would not empty a wave
+        // Waves [0, needed) keep their live paths where they are; the live paths of the other waves ("movers") fill the dead
+        // slots ("holes") of the kept waves, rank to rank.  total <= 64 * needed guarantees a hole for every mover.
+        uint32_t hole_base = 0, mover_base = 0, n_movers = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < WAVES; ++w) {
+            uint32_t c = wcnt[w];
+            if (w < needed) hole_base += w < wave ? 64u - c : 0u;
+            else { mover_base += w < wave ? c : 0u; n_movers += c; }
+        }
+        const bool kept = wave < needed;
+        if (!kept && alive) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+            float *q = smem + mover_base + rank;
             q[0 * BLOCK] = st.ray.o.x; q[1 * BLOCK] = st.ray.o.y; q[2 * BLOCK] = st.ray.o.z;
             q[3 * BLOCK] = st.ray.d.x; q[4 * BLOCK] = st.ray.d.y; q[5 * BLOCK] = st.ray.d.z;
             q[6 * BLOCK] = st.throughput.x; q[7 * BLOCK] = st.throughput.y; q[8 * BLOCK] = st.throughput.z;
@@ -389,18 +399,23 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
             if (FULL) { q[21 * BLOCK] = st.eta; q[22 * BLOCK] = st.prev_delta ? 1.f : 0.f; }
         }
         __syncthreads();
-        alive = tid < total;
-        if (alive) {
-            const float *q = smem + tid;
-            st.ray.o = V3(q[0 * BLOCK], q[1 * BLOCK], q[2 * BLOCK]); st.ray.d = V3(q[3 * BLOCK], q[4 * BLOCK], q[5 * BLOCK]);
-            st.ray.maxt = MI_LARGEST;
-            st.throughput = V3(q[6 * BLOCK], q[7 * BLOCK], q[8 * BLOCK]); st.result = V3(q[9 * BLOCK], q[10 * BLOCK], q[11 * BLOCK]);
-            st.prev_p = V3(q[12 * BLOCK], q[13 * BLOCK], q[14 * BLOCK]); st.prev_bsdf_pdf = q[15 * BLOCK];
-            st.rng.state = (uint64_t) __float_as_uint(q[16 * BLOCK]) | ((uint64_t) __float_as_uint(q[17 * BLOCK]) << 32);
-            st.rng.inc = (uint64_t) __float_as_uint(q[18 * BLOCK]) | ((uint64_t) __float_as_uint(q[19 * BLOCK]) << 32);
-            orig = __float_as_uint(q[20 * BLOCK]);
-            if (FULL) { st.eta = q[21 * BLOCK]; st.prev_delta = q[22 * BLOCK] != 0.f; }
-            valid_ray = true;                                               // a path that continues has hit a surface
+        if (!kept) alive = false;
+        else if (!alive) {
+            const unsigned long long dm = ~m;                               // dead slots of this (kept) wave
+            uint32_t hr = hole_base + __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u));
+            if (hr < n_movers) {
+                const float *q = smem + hr;
+                st.ray.o = V3(q[0 * BLOCK], q[1 * BLOCK], q[2 * BLOCK]); st.ray.d = V3(q[3 * BLOCK], q[4 * BLOCK], q[5 * BLOCK]);
+                st.ray.maxt = MI_LARGEST;
+                st.throughput = V3(q[6 * BLOCK], q[7 * BLOCK], q[8 * BLOCK]); st.result = V3(q[9 * BLOCK], q[10 * BLOCK], q[11 * BLOCK]);
+                st.prev_p = V3(q[12 * BLOCK], q[13 * BLOCK], q[14 * BLOCK]); st.prev_bsdf_pdf = q[15 * BLOCK];
+                st.rng.state = (uint64_t) __float_as_uint(q[16 * BLOCK]) | ((uint64_t) __float_as_uint(q[17 * BLOCK]) << 32);
+                st.rng.inc = (uint64_t) __float_as_uint(q[18 * BLOCK]) | ((uint64_t) __float_as_uint(q[19 * BLOCK]) << 32);
+                orig = __float_as_uint(q[20 * BLOCK]);
+                if (FULL) { st.eta = q[21 * BLOCK]; st.prev_delta = q[22 * BLOCK] != 0.f; }
+                valid_ray = true;                                           // a path that continues has hit a surface
+                alive = true;
+            }
         }
         if (sc.n_bvh_shapes) __syncthreads();                               // the BVH stack aliases the state just read
     }
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     GradSink1 sink = { s_grad, copy_shift, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr };
     v3 L;
     prb_sample_1p<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, dL, sink, L, cnt);
-    s_ltot[threadIdx.x] = L.x; s_ltot[BLOCK + threadIdx.x] = L.y; s_ltot[2 * BLOCK + threadIdx.x] = L.z;
+    s_ltot[threadIdx.x] = L.x * dL.x; s_ltot[BLOCK + threadIdx.x] = L.y * dL.y; s_ltot[2 * BLOCK + threadIdx.x] = L.z * dL.z;   // L_total * dL
     __syncthreads();
     if (s_over) {                                                           // uniform: leave this workgroup to the two-pass kernel
         if (threadIdx.x == 0) { redo[blockIdx.x] = 1u; if (g_counters) atomicAdd(&g_counters[4], 1ull); }
@@ -565,10 +580,12 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     }
     // resolve: ga = L_total(lane) * A' + C'
     const uint32_t n_rec_small = s_qn & 0xffffu, n_rec_tex = s_qn >> 16;
-    for (uint32_t g = threadIdx.x; g < n_rec_small; g += BLOCK) {
-        float4 r = s_q[g];
-        uint32_t tag = __float_as_uint(r.x), lane = tag & 255u, slot = tag >> 8;
-        small_grad_add(sink, (int32_t) slot, V3(s_ltot[lane] * r.y, s_ltot[BLOCK + lane] * r.z, s_ltot[2 * BLOCK + lane] * r.w));
+    for (uint32_t g = threadIdx.x; g < n_rec_small; g += BLOCK) {           // one dword per record: bsdf << 8 | lane
+        const uint32_t tag = reinterpret_cast<const uint32_t *>(s_q)[g], lane = tag & 255u;
+        const DBsdf &b = sc.bsdfs[tag >> 8];
+        const float i0 = b.reflectance[0] != 0.f ? rcp_(b.reflectance[0]) : 0.f, i1 = b.reflectance[1] != 0.f ? rcp_(b.reflectance[1]) : 0.f,
+                    i2 = b.reflectance[2] != 0.f ? rcp_(b.reflectance[2]) : 0.f;           // inv = 0 where bsdf_weight * pdf = 0 (prb.py:213-227)
+        small_grad_add(sink, b.grad_slot, V3(s_ltot[lane] * i0, s_ltot[BLOCK + lane] * i1, s_ltot[2 * BLOCK + lane] * i2));
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) {
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     const uint32_t EMPTY = 0xffffffffu;
     uint32_t T = 0;
     if (n_rec_tex) {                                                        // table of ~2 entries per record, whatever the free granules allow
-        const uint32_t free_gran = q_granules - 3u * n_rec_tex;
+        const uint32_t free_gran = q_granules - 3u * n_rec_tex;             // (the dword records at the bottom are resolved by now)
         T = 64u; while (T < 2u * n_rec_tex && T < 2048u) T <<= 1;
         while (T > free_gran) T >>= 1;
         if (T < 64u) T = 0u;
@@ -1375,7 +1392,10 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u;
         const uint32_t lds_budget = (full ? 40960u : 163840u / MI_MIN_WAVES_1P);
         if (static_lds + small_bytes + 256u + 64u * 16u > lds_budget) return fail(MI355_ERR_UNSUPPORTED, "no LDS left for the gradient record queue");
-        const uint32_t q_granules = (lds_budget - 256u - static_lds - small_bytes) / 16u;
+        uint32_t q_granules = (lds_budget - 256u - static_lds - small_bytes) / 16u;
+#ifdef MI_EXP_QCAP                                                          // experiment: how small may the queue be?
+        if (const char *qc = getenv("MI355_Q_GRANULES")) q_granules = std::min(q_granules, (uint32_t) atoi(qc));
+#endif
         const uint32_t dyn_bytes = small_bytes + q_granules * 16u;
 #define LAUNCH_1P(F, B) hipLaunchKernelGGL((k_prb_backward_1p<F, B>), grid, block, dyn_bytes, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, redo, q_granules, copy_shift)
         if (full) { if (bvh) LAUNCH_1P(true, true); else LAUNCH_1P(true, false); }
