@@ -1269,126 +1269,137 @@ MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {
     atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
 }
 
+// One bounce of the one-pass adjoint walk at depth `it` (for a live path the loop counter IS its depth, prb.py:249).
+struct Prb1State { Ray ray; v3 beta, P, prev_p, dL; float prev_bsdf_pdf, eta; bool prev_delta; Pcg32 rng; };
+MI_DEV void prb1_init(Prb1State &st, const Ray &ray, const Pcg32 &rng, v3 dL) {
+    st.ray = ray; st.beta = V3(1.f, 1.f, 1.f); st.P = V3(0.f, 0.f, 0.f); st.prev_p = V3(0.f, 0.f, 0.f); st.dL = dL;
+    st.prev_bsdf_pdf = 1.f; st.eta = 1.f; st.prev_delta = true; st.rng = rng;
+}
+// `lane_tag` = the workgroup slot the path STARTED in (records and the published L_total * dL are keyed by it).
+template <bool FULL>
+MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
+                      bool active, uint32_t *stk, const GradSink1 &sink, uint32_t lane_tag, Counters3 &cnt) {
+    Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
+    cnt.isect += wave_count(active);
+    bool si_valid = active && hit.t != MI_INF;
+    cnt.shade += wave_count(si_valid);                                  // (counted here: ballot(true) inside the branch gets hoisted)
+    bool active_next = si_valid && !(hide_emitters && it == 0 && !si_valid);
+    bool alive = false;
+    bool shadow_req = false;                 // counted after the divergent region: counters live in SGPRs
+    if (si_valid) {
+            SI si = compute_si<FULL>(sc, st.ray, hit);
+        const DShape &sh = sc.shapes[hit.shape];
+        int32_t emitter = sh.emitter;
+        v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
+        if (emitter >= 0) {                                            // prb.py:126-134
+            v3 rel = si.p - st.prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
+            float em_pdf = st.prev_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, st.prev_p, d, si.sh_n, dist);
+            le_mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
+            le_front = si.wi.z > 0.f;
+            v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
+            Le = (st.beta * le_mis) * e;
+            if (le_front && sc.emitters[emitter].grad_slot >= 0)       // d Le / d radiance
+                small_grad_add(sink, sc.emitters[emitter].grad_slot, V3(st.dL.x * st.beta.x * le_mis, st.dL.y * st.beta.y * le_mis, st.dL.z * st.beta.z * le_mis));
+        }
+        active_next = active_next && (it + 1 < max_depth);          // prb.py:139
+        if (!(it + 1 < max_depth)) st.P = st.P + Le;                   // last vertex: only Le remains (see prb_sample)
+        else {
+        const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+        TexTaps taps; v3 refl;
+        if (bsdf.texture >= 0) refl = texture_eval(sc, sc.textures[bsdf.texture], si.uv, &taps);
+        else refl = ld3(bsdf.reflectance);
+        // ---- emitter sampling (prb.py:142-162)
+        float ex = next_1d(st.rng), ey = next_1d(st.rng);
+        DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
+        bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+        bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
+        bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
+        shadow_req = need_shadow;
+        bool active_em = need_shadow && !occluded;
+        if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
+        v3 wo = si_to_local(si, ds.d);
+        v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+        const bool is_diffuse = !FULL || bsdf.type == MI355_BSDF_DIFFUSE;
+        float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+        v3 Lr_dir = ((st.beta * mis_em) * bsdf_value_em) * em_weight;
+        // ---- detached BSDF sampling (prb.py:166-169)
+        float s1 = next_1d(st.rng), s2x = next_1d(st.rng), s2y = next_1d(st.rng);
+        BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, active_next, bsm, bsdf_weight);
+        v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
+        // ---- update (prb.py:173-182)
+        v3 beta_pre = st.beta;
+        st.P = (st.P + Le) + Lr_dir;
+        st.ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
+        st.beta = st.beta * bsdf_weight;
+        st.prev_p = si.p; st.prev_bsdf_pdf = bs_pdf; st.prev_delta = FULL ? bsm.delta : false;
+        if (FULL) st.eta *= bsm.eta;
+        // ---- stopping criterion (prb.py:186-198)
+        float bmax = max3(st.beta);
+        active_next = active_next && bmax != 0.f;
+        float rr_prob = fminf(bmax * (st.eta * st.eta), .95f);
+        bool rr_active = it >= rr_depth;
+        if (rr_active) st.beta = st.beta * rcp_(rr_prob);
+        bool rr_continue = next_1d(st.rng) < rr_prob;
+        active_next = active_next && (!rr_active || rr_continue);
+        // ---- gradients (prb.py:202-247 in closed form, split into the L_total-proportional and the known part)
+        {
+            float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f && is_diffuse;
+            v3 det = bsdf_weight * bs_pdf;
+            v3 inv = V3(det.x != 0.f ? rcp_(det.x) : 0.f, det.y != 0.f ? rcp_(det.y) : 0.f, det.z != 0.f ? rcp_(det.z) : 0.f);
+            float dval = ev_active ? MI_INV_PI * co : 0.f;
+            bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f && is_diffuse;
+            float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
+            v3 direct = ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
+            v3 A = inv * dval;                                         // the lane publishes L_total * st.dL
+            v3 Cc = st.dL * (direct - (st.P * inv) * dval);
+            bool want_tex = is_diffuse && bsdf.texture >= 0 && sink.have_tex_grad && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0;
+            bool want_small = is_diffuse && bsdf.texture < 0 && bsdf.grad_slot >= 0;
+            if (want_small) {                                          // the known part needs no queue
+                small_grad_add(sink, bsdf.grad_slot, Cc);
+                want_small = ev_active;                                // A' == 0 otherwise
+            }
+            unsigned long long mt = __ballot(want_tex), ms = __ballot(want_small);
+            if (mt | ms) {                                             // wave-aggregated granule allocation: one LDS atomic per wave
+                uint32_t rt = __builtin_amdgcn_mbcnt_hi((uint32_t) (mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mt, 0u));
+                uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
+                const uint32_t nt = (uint32_t) __popcll(mt), ns = (uint32_t) __popcll(ms);
+                const uint32_t leader = (uint32_t) __ffsll((long long) (mt | ms)) - 1u;   // lane 0 may be masked off here
+                const bool lead = (threadIdx.x & 63u) == leader;
+                uint32_t base = 0;
+                if (lead) base = atomicAdd(sink.qn, ns | (nt << 16));
+                base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
+                const uint32_t base_s = base & 0xffffu, base_t = base >> 16;
+                const uint32_t g = want_tex ? sink.qcap - 3u * (base_t + rt + 1u) : base_s + rs;   // granule (texture) or dword (constant) index
+                if ((base_s + ns + 3u) / 4u + 3u * (base_t + nt) > sink.qcap || base_s + ns > 0xffffu || base_t + nt > 0xffffu) { if (lead) *sink.overflow = 1u; }
+                else if (want_tex) {
+                    int32_t i11 = taps.idx[3] >= 0 ? taps.idx[3] : taps.idx[0];          // nearest filter: one tap of weight 1
+                    float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];   // w = (w0y|w1y) * (w0x|w1x), sums to 1
+                    sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.texture << 8) | lane_tag), __uint_as_float((uint32_t) taps.idx[0]),
+                                            __uint_as_float((uint32_t) i11), w1x);
+                    sink.q[g + 1] = make_float4(w1y, A.x, A.y, A.z);
+                    const int32_t dx = taps.idx[1] >= 0 ? taps.idx[1] - taps.idx[0] : 0;   // x1 - x0 (negative when the tap wraps)
+                    sink.q[g + 2] = make_float4(__uint_as_float((uint32_t) dx), Cc.x, Cc.y, Cc.z);
+                } else if (want_small)
+                    reinterpret_cast<uint32_t *>(sink.q)[g] = ((uint32_t) sh.bsdf << 8) | lane_tag;
+            }
+            if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
+                v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
+                small_grad_add(sink, sc.emitters[ds.emitter].grad_slot, st.dL * w);
+            }
+        }
+        alive = active_next;
+        }
+    }
+    cnt.shadow += wave_count(shadow_req);
+    return alive;
+}
 template <bool FULL>
 MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                           bool active, uint32_t *stk, v3 dL, GradSink1 sink, v3 &L_out, Counters3 &cnt) {
-    const uint32_t lane_in_block = threadIdx.x;
-    uint32_t depth = 0; v3 P = V3(0.f, 0.f, 0.f); v3 beta = V3(1.f, 1.f, 1.f); float eta = 1.f;
-    v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
-    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
-        Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
-        cnt.isect += wave_count(active);
-        bool si_valid = active && hit.t != MI_INF;
-        cnt.shade += wave_count(si_valid);                                  // (counted here: ballot(true) inside the branch gets hoisted)
-        bool active_next = si_valid && !(hide_emitters && depth == 0 && !si_valid);
-        active = false;
-        bool shadow_req = false;                 // counted after the divergent region: counters live in SGPRs
-        if (si_valid) {
-                SI si = compute_si<FULL>(sc, ray, hit);
-            const DShape &sh = sc.shapes[hit.shape];
-            int32_t emitter = sh.emitter;
-            v3 Le = V3(0.f, 0.f, 0.f); float le_mis = 0.f; bool le_front = false;
-            if (emitter >= 0) {                                            // prb.py:126-134
-                v3 rel = si.p - prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
-                float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, prev_p, d, si.sh_n, dist);
-                le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
-                le_front = si.wi.z > 0.f;
-                v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
-                Le = (beta * le_mis) * e;
-                if (le_front && sc.emitters[emitter].grad_slot >= 0)       // d Le / d radiance
-                    small_grad_add(sink, sc.emitters[emitter].grad_slot, V3(dL.x * beta.x * le_mis, dL.y * beta.y * le_mis, dL.z * beta.z * le_mis));
-            }
-            active_next = active_next && (depth + 1 < max_depth);          // prb.py:139
-            if (!(it + 1 < max_depth)) { P = P + Le; depth += 1; continue; }   // last vertex: only Le remains (see prb_sample)
-            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
-            TexTaps taps; v3 refl;
-            if (bsdf.texture >= 0) refl = texture_eval(sc, sc.textures[bsdf.texture], si.uv, &taps);
-            else refl = ld3(bsdf.reflectance);
-            // ---- emitter sampling (prb.py:142-162)
-            float ex = next_1d(rng), ey = next_1d(rng);
-            DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
-            bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
-            bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
-            shadow_req = need_shadow;
-            bool active_em = need_shadow && !occluded;
-            if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
-            v3 wo = si_to_local(si, ds.d);
-            v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
-            const bool is_diffuse = !FULL || bsdf.type == MI355_BSDF_DIFFUSE;
-            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
-            v3 Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
-            // ---- detached BSDF sampling (prb.py:166-169)
-            float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
-            BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, active_next, bsm, bsdf_weight);
-            v3 bs_wo = bsm.wo; float bs_pdf = bsm.pdf;
-            // ---- update (prb.py:173-182)
-            v3 beta_pre = beta;
-            P = (P + Le) + Lr_dir;
-            ray = spawn_ray(si.p, si.n, si_to_world(si, bs_wo));
-            beta = beta * bsdf_weight;
-            prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = FULL ? bsm.delta : false;
-            if (FULL) eta *= bsm.eta;
-            // ---- stopping criterion (prb.py:186-198)
-            float bmax = max3(beta);
-            active_next = active_next && bmax != 0.f;
-            float rr_prob = fminf(bmax * (eta * eta), .95f);
-            bool rr_active = depth >= rr_depth;
-            if (rr_active) beta = beta * rcp_(rr_prob);
-            bool rr_continue = next_1d(rng) < rr_prob;
-            active_next = active_next && (!rr_active || rr_continue);
-            // ---- gradients (prb.py:202-247 in closed form, split into the L_total-proportional and the known part)
-            {
-                float co = bs_wo.z; bool ev_active = active_next && si.wi.z > 0.f && co > 0.f && is_diffuse;
-                v3 det = bsdf_weight * bs_pdf;
-                v3 inv = V3(det.x != 0.f ? rcp_(det.x) : 0.f, det.y != 0.f ? rcp_(det.y) : 0.f, det.z != 0.f ? rcp_(det.z) : 0.f);
-                float dval = ev_active ? MI_INV_PI * co : 0.f;
-                bool em_act = active_em && si.wi.z > 0.f && wo.z > 0.f && is_diffuse;
-                float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
-                v3 direct = ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
-                v3 A = inv * dval;                                         // the lane publishes L_total * dL
-                v3 Cc = dL * (direct - (P * inv) * dval);
-                bool want_tex = is_diffuse && bsdf.texture >= 0 && sink.have_tex_grad && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0;
-                bool want_small = is_diffuse && bsdf.texture < 0 && bsdf.grad_slot >= 0;
-                if (want_small) {                                          // the known part needs no queue
-                    small_grad_add(sink, bsdf.grad_slot, Cc);
-                    want_small = ev_active;                                // A' == 0 otherwise
-                }
-                unsigned long long mt = __ballot(want_tex), ms = __ballot(want_small);
-                if (mt | ms) {                                             // wave-aggregated granule allocation: one LDS atomic per wave
-                    uint32_t rt = __builtin_amdgcn_mbcnt_hi((uint32_t) (mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mt, 0u));
-                    uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u));
-                    const uint32_t nt = (uint32_t) __popcll(mt), ns = (uint32_t) __popcll(ms);
-                    const uint32_t leader = (uint32_t) __ffsll((long long) (mt | ms)) - 1u;   // lane 0 may be masked off here
-                    const bool lead = (threadIdx.x & 63u) == leader;
-                    uint32_t base = 0;
-                    if (lead) base = atomicAdd(sink.qn, ns | (nt << 16));
-                    base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
-                    const uint32_t base_s = base & 0xffffu, base_t = base >> 16;
-                    const uint32_t g = want_tex ? sink.qcap - 3u * (base_t + rt + 1u) : base_s + rs;   // granule (texture) or dword (constant) index
-                    if ((base_s + ns + 3u) / 4u + 3u * (base_t + nt) > sink.qcap || base_s + ns > 0xffffu || base_t + nt > 0xffffu) { if (lead) *sink.overflow = 1u; }
-                    else if (want_tex) {
-                        int32_t i11 = taps.idx[3] >= 0 ? taps.idx[3] : taps.idx[0];          // nearest filter: one tap of weight 1
-                        float w1x = taps.w[1] + taps.w[3], w1y = taps.w[2] + taps.w[3];   // w = (w0y|w1y) * (w0x|w1x), sums to 1
-                        sink.q[g] = make_float4(__uint_as_float(((uint32_t) bsdf.texture << 8) | lane_in_block), __uint_as_float((uint32_t) taps.idx[0]),
-                                                __uint_as_float((uint32_t) i11), w1x);
-                        sink.q[g + 1] = make_float4(w1y, A.x, A.y, A.z);
-                        const int32_t dx = taps.idx[1] >= 0 ? taps.idx[1] - taps.idx[0] : 0;   // x1 - x0 (negative when the tap wraps)
-                        sink.q[g + 2] = make_float4(__uint_as_float((uint32_t) dx), Cc.x, Cc.y, Cc.z);
-                    } else if (want_small)
-                        reinterpret_cast<uint32_t *>(sink.q)[g] = ((uint32_t) sh.bsdf << 8) | lane_in_block;
-                }
-                if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
-                    v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
-                    small_grad_add(sink, sc.emitters[ds.emitter].grad_slot, dL * w);
-                }
-            }
-            depth += 1;                                                    // prb.py:249
-            active = active_next;
-        }
-        cnt.shadow += wave_count(shadow_req);
-    }
-    L_out = P;
+    Prb1State st; prb1_init(st, ray, rng, dL);
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it)
+        active = prb1_step<FULL>(sc, st, it, max_depth, rr_depth, hide_emitters, active, stk, sink, threadIdx.x, cnt);
+    rng = st.rng; L_out = st.P;
 }
 
 // -------------------------------------------------------------------------------------------
