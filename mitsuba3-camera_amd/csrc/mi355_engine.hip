@@ -609,11 +609,15 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     }
     for (uint32_t k = threadIdx.x; k < T; k += BLOCK) s_q[k] = make_float4(__uint_as_float(EMPTY), 0.f, 0.f, 0.f);
     __syncthreads();
+    // Records sit in the queue in allocation order, i.e. the 64 first-hit records of one pixel (same texels!) are neighbours.
+    // Walking them with a stride that is coprime to their number puts different pixels into the lanes of one LDS atomic
+    // instruction, which would otherwise serialise on the shared table entry (PMC: LDS unit 50 % busy before this).
+    const uint32_t stride = n_rec_tex % 61u ? 61u : (n_rec_tex % 67u ? 67u : 1u);
 #ifdef MI_EXP_SKIP_TEX_FLUSH                                                 // timing experiment only
     if (false)
 #endif
     for (uint32_t e = threadIdx.x; e < n_rec_tex * 4u; e += BLOCK) {
-        const uint32_t rec = e >> 2, tap = e & 3u;
+        const uint32_t rec = (uint32_t) (((uint64_t) (e >> 2) * stride) % n_rec_tex), tap = e & 3u;
         const uint32_t g = q_granules - 3u * (rec + 1u);
         float4 r0 = s_q[g], r1 = s_q[g + 1], r2 = s_q[g + 2];
         const uint32_t tag = __float_as_uint(r0.x), lane = tag & 255u, tex = tag >> 8;
