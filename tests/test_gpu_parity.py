@@ -491,6 +491,74 @@ def test_one_pass_adjoint_equals_two_pass(mi, orc, torch_cuda, case):
             assert 2 * c1[k] == c2[k], k                                  # one walk instead of two
 
 
+def test_full_size_properties(mi, torch_cuda):
+    """BASELINE configs[1] and [2] at their FULL sizes (512^2 x 256 spp forward, 512^2 x 64 spp PRB backward with the 256^2
+    albedo texture) through properties that need no oracle run of that size:
+      * radiance is linear in the emitter radiance and scaling by 2 is exact in fp32, so the film doubles up to the order of
+        its float atomics (rel 1e-5);
+      * the three shard shapes (bands, interleaved tiles, spp slices) and the three re-packing modes give the same film;
+      * W channel = sum of filter weights: every sample deposits the same total weight away from the border;
+      * PRB: sum_c radiance_c * dLoss/dradiance_c = <grad_in, image> (the image is linear in the radiance), and the one-pass
+        adjoint agrees with the two-pass one."""
+    torch = torch_cuda
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 512; d["sensor"]["film"]["height"] = 512
+    scene = mi.load_dict(d)
+    integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); integ.mode = mi.abi.MODE_STATIC
+    film = integ.render(scene, seed=1, spp=256, develop=False)
+    assert torch.isfinite(film).all()
+    w = film[8:-8, 8:-8, 3]
+    assert float((w / w.mean() - 1).abs().max()) < 0.2 and abs(float(film[..., 3].sum()) / (512 * 512 * 256) - float(w.mean()) / 256) < 0.02 * float(w.mean()) / 256
+    params = mi.traverse(scene)
+    key = [k for k in params.keys() if k.endswith("radiance.value")][0]
+    rad = params[key].clone()
+    params[key] = rad * 2; params.update()
+    film2 = integ.render(scene, seed=1, spp=256, develop=False)
+    params[key] = rad; params.update()
+    assert float(film[..., :3].mean()) > 1.0
+    assert torch.allclose(film2[..., :3], film[..., :3] * 2, rtol=1e-5, atol=1e-4) and torch.allclose(film2[..., 3], film[..., 3], rtol=1e-5)
+    for mode in (mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):
+        im = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); im.mode = mode
+        other = im.render(scene, seed=1, spp=256, develop=False)
+        assert torch.allclose(other, film, rtol=2e-4, atol=2e-3)
+    h = scene.handle(); lib = mi.abi.lib()
+    fast = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+    for shards in ([mi.shard_tiles(512, 512, r, 8) for r in range(8)], [mi.shard_pixels(512 * 512, r, 3) for r in range(3)]):
+        acc = torch.zeros_like(film)
+        for sh in shards:
+            p = fast._params(scene, 1, 256, shard=sh)
+            mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert torch.allclose(acc, film, rtol=2e-4, atol=2e-3)
+    acc = torch.zeros_like(film)
+    for s0 in range(0, 256, 64):
+        p = fast._params(scene, 1, 256, spp_shard=(s0, 64))
+        mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, film, rtol=2e-4, atol=2e-3)
+    scene.release()
+    # ---- config 3
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
+                                                     "data": np.random.default_rng(12345).uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    scene3 = mi.load_dict(d)
+    gin = torch.tensor(np.random.default_rng(3).uniform(0.5, 1.5, (512, 512, 3)).astype(np.float32), device="cuda")
+    grads = {}
+    for two_pass in (False, True):
+        prb = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb.two_pass = two_pass
+        params3 = mi.traverse(scene3)
+        grads[two_pass] = prb.render_backward(scene3, params3, gin, seed=5, spp=64).clone()
+        if not two_pass:
+            assert prb.counters(scene3)["n_redo_groups"] == 0
+            key3 = [k for k in params3.keys() if k.endswith("radiance.value")][0]
+            lhs = float((params3.grad(key3) * params3[key3]).sum())
+            img = prb.render(scene3, seed=5, spp=64)
+            rhs = float((gin * img).sum())
+            assert abs(lhs - rhs) < 2e-3 * abs(rhs), (lhs, rhs)
+    a, b = grads[False], grads[True]
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-3 * float(b.abs().max())
+    assert float((a - b).abs().sum()) < 1e-4 * float(b.abs().sum())
+
+
 def test_render_op_autograd(mi, orc, torch_cuda, cbox32):
     """mi.render as a differentiable op (util.py:410-523): loss.backward() fills the leaf's .grad with what
     render_backward computes for grad_in = dLoss/dImage, using seed_grad = tea32(seed, 1)[0]."""
