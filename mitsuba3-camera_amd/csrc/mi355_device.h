@@ -1243,6 +1243,73 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
     L_out = L; valid_out = depth != 0;
 }
 
+// One bounce of PRBIntegrator.sample in PRIMAL mode (prb.py:59-257, same arithmetic as prb_sample<false>) on the path
+// integrator's state record (throughput = beta, result = L), so that the re-packing kernel serves both integrators.
+// For a live path the loop counter is its depth (prb.py:249).
+template <bool FULL>
+MI_DEV bool prb_primal_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
+                            bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
+    Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
+    cnt.isect += wave_count(active);
+    bool si_valid = active && hit.t != MI_INF;
+    cnt.shade += wave_count(si_valid);
+    hit_any = si_valid;
+    bool alive = false, shadow_req = false;
+    if (si_valid) {
+        SI si = compute_si<FULL>(sc, st.ray, hit);
+        const DShape &sh = sc.shapes[hit.shape];
+        int32_t emitter = sh.emitter;
+        v3 Le = V3(0.f, 0.f, 0.f);
+        if (emitter >= 0) {                                                // prb.py:126-134
+            v3 rel = si.p - st.prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);
+            bool prev_delta = FULL ? st.prev_delta : (it == 0);
+            float em_pdf = prev_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, st.prev_p, d, si.sh_n, dist);
+            float le_mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
+            v3 e = si.wi.z > 0.f ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
+            Le = (st.throughput * le_mis) * e;
+        }
+        bool active_next = it + 1 < max_depth;                             // prb.py:139
+        if (!active_next) st.result = st.result + Le;                      // last vertex: only Le remains (see prb_sample)
+        else {
+            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
+            // ---- emitter sampling (prb.py:142-162)
+            float ex = next_1d(st.rng), ey = next_1d(st.rng);
+            DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
+            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+            bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
+            bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
+            shadow_req = need_shadow;
+            bool active_em = need_shadow && !occluded;
+            if (!active_em) { ds.pdf = 0.f; em_weight = V3(0.f, 0.f, 0.f); }
+            v3 wo = si_to_local(si, ds.d);
+            v3 bsdf_value_em; float bsdf_pdf_em; bsdf_eval_pdf<FULL>(bsdf, refl, si.wi, wo, active_em, bsdf_value_em, bsdf_pdf_em);
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+            v3 Lr_dir = ((st.throughput * mis_em) * bsdf_value_em) * em_weight;
+            // ---- detached BSDF sampling (prb.py:166-169)
+            float s1 = next_1d(st.rng), s2x = next_1d(st.rng), s2y = next_1d(st.rng);
+            BSample bsm; v3 bsdf_weight; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, active_next, bsm, bsdf_weight);
+            // ---- update (prb.py:173-182)
+            st.result = (st.result + Le) + Lr_dir;
+            st.ray = spawn_ray(si.p, si.n, si_to_world(si, bsm.wo));
+            st.throughput = st.throughput * bsdf_weight;
+            st.prev_p = si.p; st.prev_bsdf_pdf = bsm.pdf;
+            if (FULL) { st.eta *= bsm.eta; st.prev_delta = bsm.delta; }
+            // ---- stopping criterion (prb.py:186-198)
+            const float eta = FULL ? st.eta : 1.f;
+            float bmax = max3(st.throughput);
+            active_next = active_next && bmax != 0.f;
+            float rr_prob = fminf(bmax * (eta * eta), .95f);
+            bool rr_active = it >= rr_depth;
+            if (rr_active) st.throughput = st.throughput * rcp_(rr_prob);
+            bool rr_continue = next_1d(st.rng) < rr_prob;
+            alive = active_next && (!rr_active || rr_continue);
+        }
+    }
+    cnt.shadow += wave_count(shadow_req);
+    return alive;
+}
+
 // -------------------------------------------------------------------------------------------
 // ONE-PASS adjoint.  prb.py needs the primal pass only for L_total: the adjoint walks the path again with
 // L_k = L_total - P_k (P_k = everything collected up to and including vertex k) and every albedo gradient is LINEAR in it:

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen
 // from "6 bounces x 4 waves" to "sum over bounces of ceil(alive / 64)".  Final radiance returns to the lane's ORIGINAL
 // slot (`fin`) so that the per-pixel LDS film reduction still sees all samples of a pixel side by side.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FULL>
+template <int INTEGRATOR, bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
         alive = false;
         if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
             bool hit_any;
-            alive = path_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            if (INTEGRATOR == MI355_INTEGRATOR_PATH) alive = path_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            else alive = prb_primal_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
             valid_ray = valid_ray || hit_any;
         }
         if (mine && !alive) {                                               // path over: park its radiance in its original slot
@@ -1305,8 +1306,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
     if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT && p->mode != MI355_MODE_STATIC) return fail(MI355_ERR_INVALID, "unknown mode");
-    if (p->mode == MI355_MODE_WAVEFRONT && p->integrator != MI355_INTEGRATOR_PATH)
-        return fail(MI355_ERR_UNSUPPORTED, "wavefront (re-packing) mode is implemented for the path integrator only");
+
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
@@ -1319,17 +1319,20 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     // (bit 31 stands for every bounce >= 31 and must stay set: the count exchange is also the loop's exit test when max_depth = -1)
     a.compact_mask = p->mode == MI355_MODE_WAVEFRONT ? 0xffffffffu : 0xfffffffcu;
     a.compact_adaptive = p->mode == MI355_MODE_WAVEFRONT ? 0u : 1u;
-    if (p->integrator == MI355_INTEGRATOR_PRB) {
+    if (p->integrator == MI355_INTEGRATOR_PRB && p->mode == MI355_MODE_STATIC) {
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+    } else if (p->integrator == MI355_INTEGRATOR_PRB) {
+        if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     } else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN) && p->mode != MI355_MODE_WAVEFRONT) {       // enough samples per pixel to keep a wave's pool full
         uint32_t n_waves = (a.pixel_count + a.ppw - 1) / a.ppw; dim3 rgrid((n_waves + WAVES - 1) / WAVES);
         if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL(k_render_regen<false>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     }
     else if (p->mode != MI355_MODE_STATIC) {
-        if (full) hipLaunchKernelGGL(k_render_compact<true>, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
-        else hipLaunchKernelGGL(k_render_compact<false>, grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     }
     else if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);

@@ -234,9 +234,15 @@ def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_dept
     r = o.counters()
     for k in ("n_isect", "n_shade", "n_shadow"):
         assert abs(int(c_wf[k]) - r[k]) <= 2e-3 * r[k] + 2, (k, c_wf[k], r[k])
-    prb = mi.PRBIntegrator(); prb.mode = mi.abi.MODE_WAVEFRONT
-    with pytest.raises(mi.Mi355Error):
-        prb.render(cbox32, seed=1, spp=4)
+    films = {}
+    for mode in (mi.abi.MODE_STATIC, mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):      # the PRB primal estimator re-packs the same way
+        prb = mi.PRBIntegrator({"max_depth": max_depth, "rr_depth": rr_depth}); prb.mode = mode
+        prb.counters(cbox32, reset=True)
+        films[mode] = (prb.render(cbox32, seed=1, spp=spp, develop=False), prb.counters(cbox32, reset=True))
+    for mode in (mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):
+        assert torch_cuda.allclose(films[mode][0], films[mi.abi.MODE_STATIC][0], rtol=1e-4, atol=1e-4)
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert films[mode][1][k] == films[mi.abi.MODE_STATIC][1][k], k
 
 
 @pytest.mark.parametrize("rfilter", [{"type": "box"}, {"type": "tent"}, {"type": "gaussian", "stddev": 0.4}])
