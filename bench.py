@@ -98,7 +98,7 @@ def main():
     my_tiles = [t for t in range(n_tiles) if t % world == rank]
     my_shard = mi.shard_tiles(W, H, rank, world, rows=TILE_ROWS)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    img = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    img = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def step(seed):
@@ -109,8 +109,9 @@ def main():
         else:
             p = integ._params(scene, seed, args.spp, shard=my_shard)      # all of this rank's tiles in ONE launch
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
-            dist.all_reduce(film, op=dist.ReduceOp.SUM)
-        mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)                   # the frame is assembled (and developed) on rank 0
+        if rank == 0:
+            mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
 
     def barrier():
         if dist is not None:
@@ -148,8 +149,22 @@ def main():
             traffic = json.load(f)[KERNEL_NAME]["bytes_per_launch"] if (world == 1 and args.res == 512 and args.spp == 256) else None
     except Exception:
         traffic = None
+    # next to the nominal 8 TB/s, the device-to-device copy rate measured on THIS box (read + write bytes / time)
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)     # 1 GiB each
+        src.fill_(1.0); dst.copy_(src); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize(dev)
+        copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "peak_measured_copy": None if copy_gbs is None else round(copy_gbs, 1),
+                "frac_of_measured_copy": None if copy_gbs is None else round(achieved / copy_gbs, 4),
                 "kernel": KERNEL_NAME, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg),
                 "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}
@@ -249,7 +264,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
-                          "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film all-reduce" if world > 1 else "none"},
+                          "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film reduce to rank 0" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4
