@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 2u
+#define MI355_ABI_VERSION 3u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -126,9 +126,11 @@ typedef struct mi355_sensor_desc {
     uint32_t rfilter;                   /* MI355_RFILTER_* */
     float    rfilter_param;             /* gaussian: stddev (default 0.5); tent: radius */
     /* realistic lens (src/sensors/realisticlens.cpp): interface table ordered from the film towards the world,
-       AFTER the constructor's fine focus (:899-905).  lens_count x 8 floats, metres:
-       type (0 sphere :345-424, 1 plane :427-493, 2 aperture stop :495-550), signed curvature radius, element radius,
-       z intercept, IOR on the film side, IOR on the world side (both at 589.3 nm, :169-179), 0, 0 */
+       AFTER the constructor's fine focus (:899-905).  lens_count x 16 floats, metres:
+       [0] type (0 sphere :345-424, 1 plane :427-493, 2 aperture stop :495-550, 3 asphere :553-821), [1] signed curvature
+       radius (sphere), [2] element radius, [3] z intercept, [4] IOR on the film side, [5] IOR on the world side (both at
+       589.3 nm, :169-179); asphere only: [6] conic constant kappa, [7] unitless curvature c = r_scale / R with
+       r_scale = 1000 * element radius, [8..14] a_i * r_scale^(2i+3), i = 0..6 (ctor :559-572); [15] 0 */
     uint32_t lens_count;
     const float *lens_data;
     float    film_diagonal;             /* physical film diagonal [m] (film.cpp:46-48, film.h:193-198) */

@@ -915,10 +915,72 @@ MI_DEV Ray sample_primary_ray(const DScene &sc, float pos_x, float pos_y) {
 // PlanoLens::intersect :444-468, ApertureStop::compute_interaction :505-517.
 // The interface table is indexed by a wave-uniform loop counter (scalar loads); every lane refracts its own ray.
 // -------------------------------------------------------------------------------------------
+// AsphericalLens (realisticlens.cpp:553-821), per-ray semantics (the reference's JIT variants branch on dr::none / dr::any over
+// the whole wavefront there).  Row: L[6] = kappa, L[7] = c (unitless), L[8..14] = a_i * r_scale^(2i+3).
+#define MI_LENS_ROW 16
+MI_DEV float asph_conic(const float *L, float r2_) {
+    float c = L[7], K = L[6];
+    float sqr_term = 1.f - (1.f + K) * (c * c) * r2_;
+    return c * r2_ * (1.f / (1.f + sqrtf(sqr_term)));
+}
+MI_DEV float asph_eval(const float *L, float r2) {
+    float er = L[2], r2_ = r2 * (1.f / (er * er)), z_ = 0.f;
+#pragma unroll
+    for (int i = 6; i >= 0; --i) z_ = fmaf(z_, r2_, L[8 + i]);
+    z_ *= r2_ * r2_;
+    z_ += asph_conic(L, r2_);
+    return -z_ * er + L[3];
+}
+MI_DEV float asph_grad_(const float *L, float r2_) {
+    float r_ = sqrtf(r2_), z_ = 0.f;
+#pragma unroll
+    for (int i = 6; i >= 0; --i) z_ = fmaf(z_, r2_, (2.f * (float) i + 4.f) * L[8 + i]);
+    z_ *= r2_ * r_;
+    float cr = L[7] * r_, sqr_term = 1.f - (1.f + L[6]) * (cr * cr);
+    z_ += cr * (1.f / sqrtf(sqr_term));
+    return -z_;
+}
+MI_DEV v3 asph_normal(const float *L, v3 p) {
+    float inv = 1.f / L[2], rx = p.x * inv, ry = p.y * inv, r2_ = rx * rx + ry * ry;
+    if (r2_ >= 4.f * MI_EPS) { float s = 1.f / sqrtf(r2_); rx *= s; ry *= s; } else { rx = 0.f; ry = 0.f; }
+    float zg = asph_grad_(L, r2_);
+    return normalize3(V3(zg * rx, zg * ry, -1.f));
+}
+MI_DEV bool asph_conic_hit(const float *L, v3 o, v3 d, float &t_out) {
+    float R = L[2], c = L[7], K = L[6], z0 = L[3];
+    v3 on = (o - V3(0.f, 0.f, z0)) * (1.f / R);
+    float A = c * (1.f + K * (d.z * d.z)), B = 2.f * (c * (dot3(on, d) + K * on.z * d.z) - d.z), C = c * (dot3(on, on) + K * (on.z * on.z)) - 2.f * on.z;
+    float t0, t1; if (!solve_quadratic(A, B, C, t0, t1)) return false;
+    t0 *= R; t1 *= R;
+    float z0t = c * (o.z + t0 * d.z - z0), z1t = c * (o.z + t1 * d.z - z0), lim = K > -1.f ? R * (1.f / (1.f + K)) : MI_INF;
+    bool v0 = z0t > 0.f && z0t <= lim, v1 = z1t > 0.f && z1t <= lim;
+    if (!(v0 || v1)) return false;
+    t_out = (v0 && v1) ? (t0 > 0.f ? t0 : t1) : (v0 ? t0 : t1);
+    return true;
+}
+MI_DEV bool asph_intersect(const float *L, v3 o, v3 d, float &t, v3 &p, v3 &n) {
+    const float TOL = MI_EPS * 10.f;
+    if (!asph_conic_hit(L, o, d, t)) t = (L[3] - o.z) * (1.f / d.z);
+    p = fma3s(d, t, o); float r2 = p.x * p.x + p.y * p.y, err = MI_INF;
+    for (int itr = 0; itr < 10; ++itr) {
+        float z_asph = asph_eval(L, r2);
+        v3 plane_p = V3(p.x, p.y, z_asph);
+        err = fabsf(p.z - z_asph);
+        v3 pn = asph_normal(L, p);
+        t = dot3(pn, plane_p - o) / dot3(pn, d);
+        p = fma3s(d, t, o); r2 = p.x * p.x + p.y * p.y;
+        if (!(err > TOL)) break;
+    }
+    if (!(err < TOL)) return false;
+    n = asph_normal(L, p);
+    return t == t && fabsf(t) != MI_INF;
+}
 MI_DEV bool lens_interact(const float *L, v3 &o, v3 &d) {
     uint32_t kind = (uint32_t) L[0]; float R = L[1], er = L[2], z = L[3], n_left = L[4], n_right = L[5];
     v3 p, n; float t;
-    if (kind == 0) {
+    if (kind == 3) {
+        if (!asph_intersect(L, o, d, t, p, n)) return false;
+    } else if (kind == 0) {
         v3 center = V3(0.f, 0.f, z + R);
         v3 pc = center - o;
         float center_proj = dot3(pc, d);
@@ -961,7 +1023,7 @@ MI_DEV float sample_lens_ray(const DScene &sc, float pos_x, float pos_y, float a
     v3 aperture_p = V3(sc.lens[2] * dkx, sc.lens[2] * dky, sc.lens[3]);
     v3 o = film_p, d = normalize3(aperture_p - film_p);
     bool active = true;
-    for (uint32_t i = 0; i < sc.lens_count; ++i) { v3 o2 = o, d2 = d; bool ok = lens_interact(sc.lens + 8 * i, o2, d2); if (active && ok) { o = o2; d = d2; } active = active && ok; }
+    for (uint32_t i = 0; i < sc.lens_count; ++i) { v3 o2 = o, d2 = d; bool ok = lens_interact(sc.lens + MI_LENS_ROW * i, o2, d2); if (active && ok) { o = o2; d = d2; } active = active && ok; }
     const float *tw = sc.cam_to_world;
     ray.o = xf_point(tw, o); ray.d = xf_vector(tw, d);
     float inv_z = rcp_(d.z), near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;

@@ -994,8 +994,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         if (!se.lens_count || !se.lens_data || se.lens_count > 64) return fail(MI355_ERR_INVALID, "realisticlens needs 1..64 interfaces");
         if (!(se.film_diagonal > 0.f)) return fail(MI355_ERR_INVALID, "realisticlens needs the physical film diagonal");
         for (uint32_t i = 0; i < se.lens_count; ++i) {
-            const float *L = se.lens_data + 8 * i;
-            if (!(L[0] == 0.f || L[0] == 1.f || L[0] == 2.f) || !(L[2] > 0.f) || !(L[4] > 0.f) || !(L[5] > 0.f) || (L[0] == 0.f && L[1] == 0.f))
+            const float *L = se.lens_data + MI_LENS_ROW * i;
+            if (!(L[0] == 0.f || L[0] == 1.f || L[0] == 2.f || L[0] == 3.f) || !(L[2] > 0.f) || !(L[4] > 0.f) || !(L[5] > 0.f) || (L[0] == 0.f && L[1] == 0.f))
                 return fail(MI355_ERR_INVALID, "malformed lens interface row");
         }
     }
@@ -1134,7 +1134,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if (se.type == MI355_SENSOR_PERSPECTIVE)
         host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
     else {
-        s->lens.assign(se.lens_data, se.lens_data + 8 * (size_t) se.lens_count);
+        s->lens.assign(se.lens_data, se.lens_data + MI_LENS_ROW * (size_t) se.lens_count);
         float aspect = (float) se.film_height / (float) se.film_width;       // Film::get_physical_size, film.h:193-198
         float x = sqrtf(se.film_diagonal * se.film_diagonal / (1.f + aspect * aspect));
         ds.film_px = x / 2; ds.film_py = aspect * x / 2; ds.lens_count = se.lens_count;

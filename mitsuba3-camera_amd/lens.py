@@ -3,15 +3,16 @@ dispersive glass models, and the thick-lens autofocus the reference runs in its 
 (film point -> rear element -> sequential refraction through the interfaces) runs on the device; this module only
 produces the flat interface table handed over through the C ABI (mi355_sensor_desc.lens_data).
 
-Interface table row (8 floats, metres): type (0 sphere, 1 plane, 2 aperture stop), curvature radius (signed, sphere only),
-element radius, z intercept on the optical axis, IOR on the film side ("left"), IOR on the world side ("right"), 0, 0.
+Interface table row (16 floats, metres): type (0 sphere, 1 plane, 2 aperture stop, 3 asphere), curvature radius (signed, sphere
+only), element radius, z intercept on the optical axis, IOR on the film side ("left"), IOR on the world side ("right"); for an
+asphere additionally kappa, the unitless curvature c and the seven scaled polynomial coefficients (include/mi355.h).
 In RGB variants every glass is evaluated at the nominal wavelength 589.3 nm (realisticlens.cpp:169-179).
 """
 import math
 
 import numpy as np
 
-SPHERE, PLANE, APERTURE = 0, 1, 2
+SPHERE, PLANE, APERTURE, ASPHERE = 0, 1, 2, 3
 NOMINAL_WAVELENGTH_UM = 0.5893
 
 
@@ -41,16 +42,84 @@ AIR = DispersiveMaterial("Air", cauchy=(1.000277, 0.0))
 
 
 class Interface:
-    def __init__(self, kind, element_radius, z, left, right, curvature_radius=0.0):
+    def __init__(self, kind, element_radius, z, left, right, curvature_radius=0.0, kappa=0.0, ai=None):
         self.kind = kind
         self.curvature_radius = float(curvature_radius)
         self.element_radius = float(element_radius)
         self.z = float(z)
         self.left, self.right = left, right      # materials on the film side / world side
+        # AsphericalLens ctor (realisticlens.cpp:559-572): curvature radius and a_i arrive in millimetres
+        self.kappa = float(kappa)
+        self.c = 0.0
+        self.ai = [0.0] * 7
+        if kind == ASPHERE:
+            r_scale = 1000.0 * self.element_radius
+            self.c = r_scale / self.curvature_radius
+            self.ai = [r_scale ** (2 * i + 3) * float(a) for i, a in enumerate(list(ai) + [0.0] * (7 - len(ai)))]
 
     def row(self):
         return [float(self.kind), self.curvature_radius, self.element_radius, self.z,
-                float(self.left.compute_ior()), float(self.right.compute_ior()), 0.0, 0.0]
+                float(self.left.compute_ior()), float(self.right.compute_ior()), self.kappa, self.c] + [float(a) for a in self.ai] + [0.0]
+
+    # ---- asphere geometry in float64 (realisticlens.cpp:574-731), used by the constructor-time autofocus
+    def asph_eval(self, r2):
+        r2_ = r2 / self.element_radius ** 2
+        z_ = 0.0
+        for a in reversed(self.ai):
+            z_ = z_ * r2_ + a
+        z_ *= r2_ * r2_
+        z_ += self.c * r2_ / (1 + math.sqrt(1 - (1 + self.kappa) * self.c ** 2 * r2_))
+        return -z_ * self.element_radius + self.z
+
+    def asph_normal(self, p):
+        rx, ry = p[0] / self.element_radius, p[1] / self.element_radius
+        r2_ = rx * rx + ry * ry
+        if r2_ >= 4 * 5.96e-8:
+            s = 1 / math.sqrt(r2_); rx *= s; ry *= s
+        else:
+            rx = ry = 0.0
+        r_ = math.sqrt(r2_)
+        z_ = 0.0
+        for i in range(6, -1, -1):
+            z_ = z_ * r2_ + (2.0 * i + 4.0) * self.ai[i]
+        z_ *= r2_ * r_
+        cr = self.c * r_
+        z_ += cr / math.sqrt(1 - (1 + self.kappa) * cr * cr)
+        n = np.array([-z_ * rx, -z_ * ry, -1.0])
+        return n / np.linalg.norm(n)
+
+    def asph_intersect(self, o, d):
+        R, c, K, z0 = self.element_radius, self.c, self.kappa, self.z
+        on = (o - np.array([0.0, 0.0, z0])) / R
+        A = c * (1 + K * d[2] ** 2); B = 2 * (c * (float(on @ d) + K * on[2] * d[2]) - d[2]); C = c * (float(on @ on) + K * on[2] ** 2) - 2 * on[2]
+        t = None
+        disc = B * B - 4 * A * C
+        if A == 0 and B != 0:
+            roots = (-C / B, -C / B)
+        elif A != 0 and disc >= 0:
+            q = -0.5 * (B + math.copysign(math.sqrt(disc), B)); r0, r1 = q / A, C / q; roots = (min(r0, r1), max(r0, r1))
+        else:
+            roots = None
+        if roots is not None:
+            t0, t1 = roots[0] * R, roots[1] * R
+            lim = R / (1 + K) if K > -1 else math.inf
+            v0 = 0 < c * (o[2] + t0 * d[2] - z0) <= lim; v1 = 0 < c * (o[2] + t1 * d[2] - z0) <= lim
+            if v0 or v1:
+                t = (t0 if t0 > 0 else t1) if (v0 and v1) else (t0 if v0 else t1)
+        if t is None:
+            t = (z0 - o[2]) / d[2]
+        p = o + t * d; err = math.inf
+        for _ in range(10):
+            z_asph = self.asph_eval(p[0] ** 2 + p[1] ** 2)
+            err = abs(p[2] - z_asph)
+            pn = self.asph_normal(p)
+            t = float(pn @ (np.array([p[0], p[1], z_asph]) - o)) / float(pn @ d)
+            p = o + t * d
+            if not err > 5.96e-7:
+                break
+        if not err < 5.96e-7 or not math.isfinite(t):
+            return None
+        return p, self.asph_normal(p)
 
 
 # ---- scalar double-precision trace used only by the constructor-time autofocus ---------------------------------
@@ -71,7 +140,12 @@ def _fresnel(cos_theta_i, eta):
 
 def _interact(itf, o, d):
     """LensInterface::compute_interaction (realisticlens.cpp:269-297) in float64.  Returns (o, d) or None."""
-    if itf.kind == SPHERE:
+    if itf.kind == ASPHERE:
+        r = itf.asph_intersect(o, d)
+        if r is None:
+            return None
+        p, n = r
+    elif itf.kind == SPHERE:
         R = itf.curvature_radius
         c = np.array([0.0, 0.0, itf.z + R])
         pc = c - o
@@ -178,7 +252,7 @@ def build_doublet(object_distance, R, lens_radius):
             Interface(SPHERE, lens_radius, z + 2 * thickness, g1, AIR, -R), Interface(APERTURE, lens_radius, z + 3 * thickness, AIR, AIR)]
 
 
-def build_from_data(kinds, thicknesses, curv_radii, elem_radii, mats, stop_ratio=1.0, scale=1.0):
+def build_from_data(kinds, thicknesses, curv_radii, elem_radii, mats, stop_ratio=1.0, scale=1.0, kappas=None, ai_list=None):
     """build_lens_from_data, realisticlens.cpp:1568-1652: tables are listed from the world side, in millimetres."""
     out = []
     z_pos = 0.0
@@ -189,6 +263,9 @@ def build_from_data(kinds, thicknesses, curv_radii, elem_radii, mats, stop_ratio
             out.append(Interface(APERTURE, er * stop_ratio, z, mats[i + 1], mats[i + 1]))
         elif kinds[i] == PLANE:
             out.append(Interface(PLANE, er, z, mats[i + 1], mats[i]))
+        elif kinds[i] == ASPHERE:                                   # :1607-1626: R and a_i rescaled with the design scale
+            ai = [a / scale ** (2 * j + 3) for j, a in enumerate(ai_list[i])]
+            out.append(Interface(ASPHERE, er, z, mats[i + 1], mats[i], curvature_radius=scale * curv_radii[i], kappa=kappas[i], ai=ai))
         else:
             out.append(Interface(SPHERE, er, z, mats[i + 1], mats[i], -0.001 * scale * curv_radii[i]))
     return out
@@ -260,10 +337,39 @@ def build_double_gauss(stop_ratio=1.0):
                            [AIR, ga, AIR, ga, gb, AIR, AIR, gc, gd, AIR, ge, AIR], stop_ratio)
 
 
+def build_exp2_nikon(mode):
+    """realisticlens.cpp:1452-1566: 22-surface Nikon design of notebooks' experiment 2 (mode 0 = as published, 1 = aspheres
+    zeroed, 2 = re-optimised aspheres); design scale 35 / 1.57, aperture stopped down to 0.5."""
+    g = [_cauchy("glass_%s" % n, a, b) for n, a, b in (
+        ("A", 1.5046464980225065, 0.004220601200948007), ("B", 1.8645930283464647, 0.013233579146425922), ("C", 1.5725988459469284, 0.007952986594191858),
+        ("D", 1.6639243971469755, 0.012180862092226684), ("E", 1.8718384392978837, 0.013530356122431513), ("F", 1.5797734345478602, 0.0045237938738434446),
+        ("G", 1.689190440676433, 0.010873011246216379), ("H", 1.5673889795706786, 0.008789871710972213), ("I", 1.6738434507974307, 0.006826218099482183),
+        ("J", 1.4770641526601842, 0.00362410356265244))]
+    gA, gB, gC, gD, gE, gF, gG, gH, gI, gJ = g
+    kinds = [S] * 11 + [A] + [S] * 4 + [ASPHERE, ASPHERE] + [S, S, PLANE, PLANE]
+    curv = [5.2674, 0.9607, 1.442, 10.2799, 1.2154, -1.0987, 2.9183, -1.6693, 1.6429, -1.4116, -2.5725, 1e8, -0.973, -24.0801, 2.3756, -1.3055,
+            -7.3169, -2.2, -1.5449, -7.2572, 1e8, 1e8]
+    thick = [0.102, 0.309, 0.246, 0.083, 0.411, 0.088, 0.258, 0.009, 0.379, 0.069, 0.118, 0.604, 0.051, 0.009, 0.282, 0.239, 0.122, 0.154, 0.083, 0.75,
+             0.074, 0.0425]
+    radii = [0.847, 0.696, 0.661, 0.625, 0.546, 0.524, 0.586, 0.601, 0.624, 0.613, 0.607, 0.555, 0.476, 0.49, 0.543, 0.569, 0.604, 0.627, 0.662, 0.712,
+             1.2, 1.2]
+    ai = [[0.0] * 7 for _ in range(22)]
+    if mode == 0:
+        ai[16] = [-0.24, -0.4268, 0.0, 0.0, 0.0, 0.0, 0.0]; ai[17] = [-0.05053, -0.3491, 0.1459, 0.07718, 0.0, 0.0, 0.0]
+    elif mode == 2:
+        ai[16] = [-0.09490284323692322, -0.10803833603858948, -0.08069773763418198, -0.01646527275443077, -0.007415791507810354,
+                  -0.503877580165863, -3.2629644870758057]
+        ai[17] = [0.07706142961978912, 0.06080370396375656, -0.015299857594072819, -0.16691075265407562, -0.38500601053237915,
+                  -0.5226516723632812, 0.1124117523431778]
+    mats = [AIR, gA, AIR, gB, gC, AIR, gD, gE, AIR, gF, gG, AIR, AIR, gH, AIR, gF, AIR, gI, AIR, gJ, AIR, gA, AIR]
+    return build_from_data(kinds, thick, curv, radii, mats, stop_ratio=0.5, scale=35.0 / 1.57, kappas=[0.0] * 22, ai_list=ai)
+
+
 TABLE_DESIGNS = {"tessar": build_tessar, "helios": build_helios, "jupiter": build_jupiter, "fisheye": build_fisheye, "gauss": build_double_gauss}
 EXP1 = {"exp1a": (1.5689525390422485, 0.0263051608728981), "exp1b": (1.507009332993809, 0.04781645616233479),
         "exp1c": (1.5030211256389316, 0.04920145883751409)}     # realisticlens.cpp:883-888
-UNSUPPORTED_DESIGNS = ("hypercentric", "asph", "exp2a", "exp2b", "exp2c")     # need aspherical interfaces / their own focusing
+EXP2 = {"exp2a": 0, "exp2b": 1, "exp2c": 2}
+UNSUPPORTED_DESIGNS = ("hypercentric", "asph")     # own film position / 13-asphere phone lens without fine focus: not carried
 
 
 def build_lens(props, film_half_width):
@@ -273,13 +379,23 @@ def build_lens(props, film_half_width):
     focal_length = float(props.get("lens_focal_length", 0.05))
     lens_diameter = float(props.get("lens_diameter", 0.01))
     stop_ratio = float(props.get("stop_ratio", 1.0))
+    if design == "custom":          # extension: an explicit interface list (film -> world), e.g. to exercise aspheres on their own
+        import copy
+        itf = [copy.copy(i) for i in props["lens_interfaces"]]
+        delta = focus_thick_lens(itf, film_half_width, object_distance) if props.get("fine_focus", True) else float("nan")
+        if not math.isnan(delta):
+            for i in itf:
+                i.z -= delta
+        return itf, delta
     if design in UNSUPPORTED_DESIGNS:
-        raise NotImplementedError('lens_design "%s": aspherical interfaces are not built (carried: singlet, doublet, tessar, helios, '
-                                  'jupiter, fisheye, gauss, exp1a/b/c)' % design)
+        raise NotImplementedError('lens_design "%s" is not carried by this build (carried: singlet, doublet, tessar, helios, jupiter, '
+                                  'fisheye, gauss, exp1a/b/c, exp2a/b/c)' % design)
     if design == "doublet":
         itf = build_doublet(object_distance, focal_length / 2, lens_diameter / 2)
     elif design in TABLE_DESIGNS:
         itf = TABLE_DESIGNS[design](stop_ratio=stop_ratio)
+    elif design in EXP2:
+        itf = build_exp2_nikon(EXP2[design])
     elif design in EXP1:
         itf = build_exp1_doublet(*EXP1[design], stop_ratio=stop_ratio)
     else:

@@ -344,7 +344,7 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
                            s->camera_to_sample, s->sample_to_camera);
     if (d->sensor.type == MI355_SENSOR_REALISTICLENS) {
         s->lens_count = d->sensor.lens_count;
-        s->lens = (float *) dupmem(d->sensor.lens_data, 32u * d->sensor.lens_count);
+        s->lens = (float *) dupmem(d->sensor.lens_data, 64u * d->sensor.lens_count);
         s->sensor.lens_data = s->lens;
         float aspect = (float) d->sensor.film_height / (float) d->sensor.film_width;      /* Film::get_physical_size, film.h:193-198 */
         float x = sqrtf(d->sensor.film_diagonal * d->sensor.film_diagonal / (1.f + aspect * aspect));
@@ -989,10 +989,72 @@ static Ray sample_primary_ray(const OScene *sc, v2 sample_pos) {
  * trace_ray_from_film :1654-1683, LensInterface::compute_interaction :269-297, SpheroidLens::intersect :359-397,
  * PlanoLens::intersect :444-468, ApertureStop::compute_interaction :505-517.  Returns the ray weight (cos^4, 0 if blocked).
  * ---------------------------------------------------------------------------------------- */
+/* AsphericalLens (realisticlens.cpp:553-821) with per-ray ("scalar variant") semantics: the reference's intersect_conic /
+ * intersect branch on dr::none / dr::any over the whole wavefront in JIT variants, which has no per-lane meaning.
+ * Row: L[6] = kappa, L[7] = c (unitless curvature r_scale / R_mm), L[8..14] = a_i * r_scale^(2i+3) (ctor :559-572). */
+#define ORC_LENS_ROW 16
+static float asph_conic(const float *L, float r2_) {                   /* _eval_conic :683-687 */
+    float c = L[7], K = L[6];
+    float sqr_term = 1.f - (1.f + K) * (c * c) * r2_;
+    return c * r2_ * (1.f / (1.f + sqrtf(sqr_term)));
+}
+static float asph_eval(const float *L, float r2) {                      /* eval_asph :698-707 */
+    float er = L[2], r2_ = r2 * (1.f / (er * er)), z_ = 0.f;
+    for (int i = 6; i >= 0; --i) z_ = fmaf(z_, r2_, L[8 + i]);
+    z_ *= r2_ * r2_;
+    z_ += asph_conic(L, r2_);
+    return -z_ * er + L[3];
+}
+static float asph_grad_(const float *L, float r2_) {                    /* _eval_asph_grad :722-731, _eval_conic_grad :690-695 */
+    float r_ = sqrtf(r2_), z_ = 0.f;
+    for (int i = 6; i >= 0; --i) z_ = fmaf(z_, r2_, (2.f * (float) i + 4.f) * L[8 + i]);
+    z_ *= r2_ * r_;
+    float cr = L[7] * r_, sqr_term = 1.f - (1.f + L[6]) * (cr * cr);
+    z_ += cr * (1.f / sqrtf(sqr_term));
+    return -z_;
+}
+static v3 asph_normal(const float *L, v3 p) {                           /* normal :646-655 */
+    float inv = 1.f / L[2], rx = p.x * inv, ry = p.y * inv, r2_ = rx * rx + ry * ry;
+    if (r2_ >= 4.f * ORC_EPS) { float s = 1.f / sqrtf(r2_); rx *= s; ry *= s; } else { rx = 0.f; ry = 0.f; }
+    float zg = asph_grad_(L, r2_);
+    return normalize3(V3(zg * rx, zg * ry, -1.f));
+}
+static int asph_conic_hit(const float *L, v3 o, v3 d, float *t_out) {   /* intersect_conic :770-819 */
+    float R = L[2], c = L[7], K = L[6], z0 = L[3];
+    v3 on = scale3(sub3(o, V3(0.f, 0.f, z0)), 1.f / R);
+    float A = c * (1.f + K * (d.z * d.z)), B = 2.f * (c * (dot3(on, d) + K * on.z * d.z) - d.z), C = c * (dot3(on, on) + K * (on.z * on.z)) - 2.f * on.z;
+    float t0, t1; if (!solve_quadratic(A, B, C, &t0, &t1)) return 0;
+    t0 *= R; t1 *= R;
+    float z0t = c * (o.z + t0 * d.z - z0), z1t = c * (o.z + t1 * d.z - z0), lim = K > -1.f ? R * (1.f / (1.f + K)) : INFINITY;
+    int v0 = z0t > 0.f && z0t <= lim, v1 = z1t > 0.f && z1t <= lim;
+    if (!(v0 || v1)) return 0;
+    *t_out = (v0 && v1) ? (t0 > 0.f ? t0 : t1) : (v0 ? t0 : t1);
+    return 1;
+}
+static int asph_intersect(const float *L, v3 o, v3 d, float *t_out, v3 *p_out, v3 *n_out) {   /* intersect :574-644 */
+    const float TOL = ORC_EPS * 10.f;
+    float t;
+    if (!asph_conic_hit(L, o, d, &t)) t = (L[3] - o.z) * (1.f / d.z);
+    v3 p = fma3s(d, t, o); float r2 = p.x * p.x + p.y * p.y, err = INFINITY;
+    for (int itr = 0; itr < 10; ++itr) {                                /* Newton on tangent planes */
+        float z_asph = asph_eval(L, r2);
+        v3 plane_p = V3(p.x, p.y, z_asph);
+        err = fabsf(p.z - z_asph);
+        v3 pn = asph_normal(L, p);
+        t = dot3(pn, sub3(plane_p, o)) / dot3(pn, d);
+        p = fma3s(d, t, o); r2 = p.x * p.x + p.y * p.y;
+        if (!(err > TOL)) break;
+    }
+    if (!(err < TOL)) return 0;
+    *t_out = t; *p_out = p; *n_out = asph_normal(L, p);
+    return isfinite(t);
+}
 static int lens_interact(const float *L, v3 *o, v3 *d) {
     uint32_t kind = (uint32_t) L[0]; float R = L[1], er = L[2], z = L[3], n_left = L[4], n_right = L[5];
     v3 p, n; float t;
-    if (kind == 0) {
+    if (kind == 3) {
+        if (!asph_intersect(L, *o, *d, &t, &p, &n)) return 0;
+    } else if (kind == 0) {
         v3 center = V3(0.f, 0.f, z + R);
         v3 pc = sub3(center, *o);
         float center_proj = dot3(pc, *d);
@@ -1037,7 +1099,7 @@ static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample
     v3 aperture_p = V3(L0[2] * dk.x, L0[2] * dk.y, L0[3]);              /* sample_rear_element, :1870-1878 */
     v3 o = film_p, d = normalize3(sub3(aperture_p, film_p));
     int active = 1;
-    for (uint32_t i = 0; i < sc->lens_count && active; ++i) active = lens_interact(sc->lens + 8 * i, &o, &d);
+    for (uint32_t i = 0; i < sc->lens_count && active; ++i) active = lens_interact(sc->lens + ORC_LENS_ROW * i, &o, &d);
     const float *tw = sc->sensor.to_world;
     ray_out->o = xf_point(tw, o); ray_out->d = xf_vector(tw, d);
     float inv_z = rcpf_(d.z), near_t = sc->sensor.near_clip * inv_z, far_t = sc->sensor.far_clip * inv_z;
