@@ -365,11 +365,57 @@ def build_exp2_nikon(mode):
     return build_from_data(kinds, thick, curv, radii, mats, stop_ratio=0.5, scale=35.0 / 1.57, kappas=[0.0] * 22, ai_list=ai)
 
 
+def build_asph(stop_ratio=1.0):
+    """realisticlens.cpp:1373-1449: 13-asphere phone-camera lens (no fine focus, :876-878)."""
+    gA, gB, gC = _cauchy("glass_A", 1.52923858553436, 0.00509603519451627), _cauchy("glass_B", 1.59833561885235, 0.0143836590443554), \
+        _cauchy("glass_C", 1.5205859418518, 0.00497611850070528)
+    nbk7 = _cauchy("NBK7", 1.50478491769513, 0.00421697320906858)
+    Q = ASPHERE
+    kinds = [Q, A, Q, Q, Q, Q, Q, Q, Q, Q, Q, Q, Q, PLANE, PLANE]
+    curv = [1.952, 1e8, 2.978, 2.003, 2.167, 4.143, -3.947, -0.969, -2.089, 3.867, -0.847, -16.711, 0.785, 1e8, 1e8]
+    thick = [0.118, 0.28, 0.069, 0.28, 0.205, 0.551, 0.211, 0.421, 0.03, 1.105, 0.03, 0.44, 0.7, 0.3, 0.235]
+    radii = [0.72391, 0.70781, 0.79221, 0.79661, 0.91103, 0.94416, 1.05504, 1.07363, 1.26654, 1.33913, 1.56417, 1.81331, 2.37438, 2.72353, 2.72353]
+    kappas = [-2.1201, 0.0, -20.0, -12.382, -3.006, 1.0, 0.0, -1.4213, -3.0569, -6.3368, -4.2091, -20.0, -5.1631, 0.0, 0.0]
+    ai = [[3.5988e-03, 3.7387e-01, -1.3929e+00, 1.4094e+00, 2.0282e+00, -3.6199e+00, 0.0], [0.0] * 7,
+          [-1.7492e-01, 9.8443e-02, 6.6244e-01, -1.7257e+00, 6.6955e-01, -3.4243e-01, 0.0],
+          [-2.6551e-01, 5.7642e-01, -1.1253e+00, 1.1555e+00, 1.4439e-02, -1.9141e+00, 0.0],
+          [-2.5306e-01, 3.1573e-01, -2.1258e-01, 9.4103e-02, -2.7001e-01, 1.1110e-01, 0.0],
+          [-1.4680e-01, -1.9199e-02, 1.1489e-01, -1.6910e-01, -1.1287e-01, 1.2615e-01, 0.0],
+          [-4.4328e-02, -1.6599e-01, 4.8223e-02, 9.4653e-03, 1.2137e-02, -8.1558e-03, 0.0],
+          [3.3847e-01, -8.7891e-01, 1.1445e+00, -9.1578e-01, 5.9482e-01, -2.0143e-01, 0.0],
+          [1.4102e-01, -2.7755e-01, 3.2138e-01, -2.4968e-01, 1.2901e-01, -2.7976e-02, 0.0],
+          [-1.6984e-01, 1.4944e-01, -9.9124e-02, 1.3353e-02, 1.6198e-03, 1.2524e-03, 0.0],
+          [-6.7672e-02, -3.0645e-02, 1.0444e-01, -8.3869e-02, 2.6536e-02, -2.7869e-03, 0.0],
+          [-1.3442e-01, 3.8933e-02, -6.2383e-03, 7.5356e-04, 2.2005e-04, -5.2957e-05, 0.0],
+          [-7.5325e-02, 2.4095e-02, -5.8920e-03, 1.0269e-03, -1.1564e-04, 5.9417e-06, 0.0], [0.0] * 7, [0.0] * 7]
+    mats = [AIR, gA, gA, AIR, gB, AIR, gA, AIR, gB, AIR, gC, AIR, gC, AIR, nbk7, AIR]
+    return build_from_data(kinds, thick, curv, radii, mats, stop_ratio=stop_ratio, kappas=kappas, ai_list=ai)
+
+
+def build_hypercentric(ap_radius=1.0, focal_lengths=2.0):
+    """realisticlens.cpp:1322-1370: one thick biconvex element behind a far aperture (hypercentric / telecentric optics).
+    Returns (interfaces, film_z_position): the film does not sit at z = 0 of the lens frame (:1366, :2263)."""
+    sf6 = _cauchy("SF6", 1.757435971209294, 0.016580283248837778)
+    target_img_size, lens_radius, focal_length, track_length, R, lens_thickness = 5.0, 120.0, 210.0, 450.0, 310.505660861, 50.0
+    z_ap_to_lens = focal_length * focal_lengths
+    z_film_to_ap = z_ap_to_lens * (target_img_size - ap_radius) / (lens_radius + ap_radius)
+    curv, thick, radii = [R, -R, math.inf], [lens_thickness, z_ap_to_lens - lens_thickness * 0.5, z_film_to_ap], [lens_radius, lens_radius, ap_radius]
+    mats = [AIR, sf6, AIR, AIR]
+    out, z_pos = [], 0.0
+    for i in (2, 1, 0):
+        z_pos += thick[i]
+        if i == 2:
+            out.append(Interface(APERTURE, 0.001 * radii[i], 0.001 * z_pos, AIR, AIR))
+        else:
+            out.append(Interface(SPHERE, 0.001 * radii[i], 0.001 * z_pos, mats[i + 1], mats[i], -0.001 * curv[i]))
+    return out, 0.001 * (track_length - sum(thick))
+
+
 TABLE_DESIGNS = {"tessar": build_tessar, "helios": build_helios, "jupiter": build_jupiter, "fisheye": build_fisheye, "gauss": build_double_gauss}
 EXP1 = {"exp1a": (1.5689525390422485, 0.0263051608728981), "exp1b": (1.507009332993809, 0.04781645616233479),
         "exp1c": (1.5030211256389316, 0.04920145883751409)}     # realisticlens.cpp:883-888
 EXP2 = {"exp2a": 0, "exp2b": 1, "exp2c": 2}
-UNSUPPORTED_DESIGNS = ("hypercentric", "asph")     # own film position / 13-asphere phone lens without fine focus: not carried
+UNSUPPORTED_DESIGNS = ()
 
 
 def build_lens(props, film_half_width):
@@ -396,6 +442,13 @@ def build_lens(props, film_half_width):
         itf = TABLE_DESIGNS[design](stop_ratio=stop_ratio)
     elif design in EXP2:
         itf = build_exp2_nikon(EXP2[design])
+    elif design == "asph":                  # no fine focus (:876-878)
+        return build_asph(stop_ratio=stop_ratio), float("nan")
+    elif design == "hypercentric":          # no fine focus either (:866-875); the caller shifts the camera frame by film_z_position
+        itf, film_z = build_hypercentric(float(props.get("ap_size", 1.0)), float(props.get("ap_offset", 2.0)))
+        for i in itf:
+            i.film_z_position = film_z
+        return itf, float("nan")
     elif design in EXP1:
         itf = build_exp1_doublet(*EXP1[design], stop_ratio=stop_ratio)
     else:

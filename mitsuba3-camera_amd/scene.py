@@ -360,6 +360,9 @@ class Sensor:
             except NotImplementedError as e:
                 raise PluginError(str(e))
             self.lens_table = _lens.lens_table(self.interfaces)
+            film_z = getattr(self.interfaces[0], "film_z_position", 0.0)
+            if film_z:              # ray.o.z += m_film_z_position before to_world (realisticlens.cpp:2263)
+                self.to_world = self.to_world.translate([0.0, 0.0, film_z])
             self.x_fov = 0.0
         else:
             self.x_fov = float(np.float32(parse_fov(props, self.film.width / float(self.film.height))))

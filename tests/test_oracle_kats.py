@@ -570,7 +570,31 @@ def test_lens_focus_and_trace(orc, mi, design):
     wide = o.lens_rays(np.tile(np.array([32.0, 32.0], dtype=np.float32), (256, 1)), rng.random((256, 2), dtype=np.float32))
     assert (wide[:, 7] >= 0).all() and (wide[:, 7] <= 1 + 1e-5).all()
     with pytest.raises(mi.PluginError):
-        _lens_scene(mi, "asph")
+        _lens_scene(mi, "singlet", sample_exit_pupil=True)
+
+
+@pytest.mark.parametrize("design", ["asph", "hypercentric"])
+def test_lens_designs_without_fine_focus(orc, mi, design):
+    """`asph` (13 aspheres, realisticlens.cpp:1373-1449) and `hypercentric` (:1322-1370, film not at z = 0) skip the fine focus:
+    check the tables load, paraxial rays get through with cos^4 weights, and the hypercentric camera frame is shifted by
+    film_z_position (:2263)."""
+    from mitsuba3_camera_amd import lens
+    sc = _lens_scene(mi, design, 32, diagonal=6.0 if design == "asph" else 10.0)
+    assert np.isnan(sc.sensor.focus_delta) and sc.sensor.lens_table.shape == ((15, 16) if design == "asph" else (3, 16))
+    o = orc.OracleScene(sc, mi.abi)
+    rng = np.random.default_rng(1)
+    zone = 0.01 if design == "asph" else 0.002          # (rear plates sit 0.2 mm / a few mm in front of the film)
+    ap = 0.5 + (rng.random((128, 2), dtype=np.float32) - 0.5) * zone
+    rays = o.lens_rays(np.tile(np.array([16.0, 16.0], dtype=np.float32), (128, 1)), ap)
+    ok = rays[:, 7] > 0
+    assert ok.mean() > 0.9
+    assert np.allclose(rays[ok, 7], (rays[ok, 3:6] @ np.array([0, 0, -1.0])) ** 4, rtol=1e-4)
+    if design == "hypercentric":
+        _, fz = lens.build_hypercentric()
+        assert abs(fz - 0.001 * (450.0 - (50.0 + 395.0 + 420.0 * 4.0 / 121.0))) < 1e-9
+        ref = mi.ScalarTransform4f.look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0])
+        shift = sc.sensor.to_world.transform_affine([0, 0, 0]) - ref.transform_affine([0, 0, 0])
+        assert np.allclose(shift, [0, 0, -fz], atol=1e-6)            # camera looks down -z: +film_z along its own axis
 
 
 def test_lens_render_oracle(orc, mi):
