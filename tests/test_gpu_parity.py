@@ -518,6 +518,43 @@ def test_one_pass_adjoint_equals_two_pass(mi, orc, torch_cuda, case):
             assert 2 * c1[k] == c2[k], k                                  # one walk instead of two
 
 
+def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
+    """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
+    pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the
+    C ABI asks the caller to)."""
+    torch = torch_cuda
+    T = mi.ScalarTransform4f
+    sensor = {"type": "perspective", "fov": 40, "to_world": T.look_at([0, 0, 4], [0, 0, 0], [0, 1, 0]),
+              "film": {"type": "hdrfilm", "width": 16, "height": 12, "rfilter": {"type": "gaussian"}}}
+    empty = mi.load_dict({"type": "scene", "sensor": dict(sensor)})
+    dark = mi.load_dict({"type": "scene", "sensor": dict(sensor), "wall": {"type": "rectangle", "bsdf": {"type": "diffuse"}}})
+    for scene in (empty, dark):
+        o = orc.OracleScene(scene, mi.abi)
+        for integ in (mi.PathIntegrator({"max_depth": 4}), mi.PRBIntegrator({"max_depth": 4})):
+            film = integ.render(scene, seed=1, spp=4, develop=False)
+            assert float(film[..., :3].abs().max()) == 0.0 and float(film[..., 3].min()) > 0.0          # weights are still splatted
+            ref, _ = o.render(o.params(integ, 1, 4), develop=False)
+            assert np.allclose(film.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+        prb = mi.PRBIntegrator({"max_depth": 4}); params = mi.traverse(scene)
+        g = prb.render_backward(scene, params, torch.ones((12, 16, 3), device="cuda"), seed=2, spp=4)
+        assert float(g.abs().max()) == 0.0
+    scene = mi.load_dict(small_cbox(mi, 16)); o = orc.OracleScene(scene, mi.abi)
+    for md, spp in ((0, 4), (1, 4), (6, 1)):
+        for integ in (mi.PathIntegrator({"max_depth": md}), mi.PRBIntegrator({"max_depth": md})):
+            img = integ.render(scene, seed=3, spp=spp).cpu().numpy()
+            ref, _ = o.render(o.params(integ, 3, spp))
+            assert np.abs(img - ref).max() <= 1e-3 * max(ref.max(), 1e-6), (md, spp)
+            if md == 0:
+                assert img.max() == 0.0
+    integ = mi.PathIntegrator({"max_depth": 3})
+    film = torch.zeros((16, 16, 4), device="cuda")
+    p = integ._params(scene, 0, 4, shard=(256, 0))                       # empty shard: nothing to do, not an error
+    mi.abi.check(mi.abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), None))
+    torch.cuda.synchronize(); assert float(film.abs().max()) == 0.0
+    with pytest.raises(mi.Mi355Error):
+        integ.render(scene, seed=0, spp=1 << 25)                          # 256 * 2^25 = 2^33 lanes
+
+
 def test_full_size_properties(mi, torch_cuda):
     """BASELINE configs[1] and [2] at their FULL sizes (512^2 x 256 spp forward, 512^2 x 64 spp PRB backward with the 256^2
     albedo texture) through properties that need no oracle run of that size:
