@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 3u
+#define MI355_ABI_VERSION 4u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -135,6 +135,11 @@ typedef struct mi355_sensor_desc {
     const float *lens_data;
     float    film_diagonal;             /* physical film diagonal [m] (film.cpp:46-48, film.h:193-198) */
     float    focus_distance;            /* unused by the engine (focus is already baked into the table) */
+    float    shutter_open_time;         /* Sensor::shutter_open_time (sensor.cpp: shutter_close - shutter_open).  > 0 costs every sample one
+                                           extra sampler draw for the time (integrator.cpp:442-444, common.py:293-295), any sensor type */
+    uint32_t sample_exit_pupil;         /* realisticlens `sample_exit_pupil` (:851): aim at the exit-pupil bounds of the film point's radius
+                                           (LUT of 64 x 2^20 traced rays, :1685-1806, built at scene creation) instead of the whole rear
+                                           element; ray weight = shutter_open_time * bounds_area / z_rear^2 (:2282-2285) */
 } mi355_sensor_desc;
 
 typedef struct mi355_scene_desc {
@@ -271,6 +276,10 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
    out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6] analytic spheres,
    out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres, 4: realisticlens sensor; any bit -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
+
+/* realisticlens with sample_exit_pupil: the 64 (min.x, min.y, max.x, max.y) exit-pupil bounds the scene was created with
+   (compute_exit_pupil_bounds, realisticlens.cpp:1772-1806).  out = 256 floats of host memory. */
+int mi355_lens_exit_pupil_bounds(const mi355_scene *scene, float *out);
 
 /* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):
    d_out = count x 4 (r,g,b,valid).  Used by the lane-exact parity tests

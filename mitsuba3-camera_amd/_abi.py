@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -62,7 +62,8 @@ class SensorDesc(C.Structure):
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("rfilter", C.c_uint32), ("rfilter_param", C.c_float),
                 ("lens_count", C.c_uint32), ("lens_data", f32p),
-                ("film_diagonal", C.c_float), ("focus_distance", C.c_float)]
+                ("film_diagonal", C.c_float), ("focus_distance", C.c_float),
+                ("shutter_open_time", C.c_float), ("sample_exit_pupil", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):
@@ -107,6 +108,7 @@ SYMBOLS = [
     ("mi355_render_backward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_get_counters", C.c_int, [C.c_void_p, C.POINTER(Counters), C.c_int]),
     ("mi355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("mi355_debug_lane_radiance", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_perspective_projection", None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

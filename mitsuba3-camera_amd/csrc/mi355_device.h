@@ -117,6 +117,8 @@ struct DScene {
     // realisticlens sensor: interface table (8 floats per interface, film -> world), physical half extents of the film
     uint32_t sensor_type, lens_count; const float *lens; float film_px, film_py;
     uint32_t film_w, film_h;
+    float shutter_open_time;      // > 0: one extra sampler draw per sample for the time (integrator.cpp:442-444)
+    uint32_t sample_exit_pupil; float film_diagonal; const float *pupil;   // exit-pupil bounds, 64 x (min.x, min.y, max.x, max.y)
 };
 
 // -------------------------------------------------------------------------------------------
@@ -1020,7 +1022,20 @@ MI_DEV float sample_lens_ray(const DScene &sc, float pos_x, float pos_y, float a
     float rox = (float) sc.crop_x / (float) sc.film_w, roy = (float) sc.crop_y / (float) sc.film_h;
     v3 film_p = V3(sc.film_px * (2.f * fmaf(ax, rsx, rox) - 1.f), sc.film_py * (2.f * fmaf(ay, rsy, roy) - 1.f), 0.f);
     float dkx, dky; disk_concentric(ap_x, ap_y, dkx, dky);
-    v3 aperture_p = V3(sc.lens[2] * dkx, sc.lens[2] * dky, sc.lens[3]);
+    float bounds_area = 0.f;
+    v3 pupil_p = V3(0.f, 0.f, 0.f);
+    if (sc.sample_exit_pupil) {                                             // sample_exit_pupil, realisticlens.cpp:1808-1836
+        float r_film = sqrtf(film_p.x * film_p.x + film_p.y * film_p.y);
+        uint32_t r_idx = (uint32_t) (int32_t) floorf(r_film / sc.film_diagonal * 64.f);
+        if (r_idx > 63u) r_idx = 63u;
+        const float *b = sc.pupil + 4 * r_idx;
+        float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        bounds_area = (b2 - b0) * (b3 - b1);
+        float ppx = fmaf(b2, ap_x, fmaf(-b0, ap_x, b0)), ppy = fmaf(b3, ap_y, fmaf(-b1, ap_y, b1));      // dr::lerp
+        float sin_t = r_film > 0.f ? film_p.y * (1.f / r_film) : 0.f, cos_t = r_film > 0.f ? film_p.x * (1.f / r_film) : 1.f;
+        pupil_p = V3(cos_t * ppx - sin_t * ppy, sin_t * ppx + cos_t * ppy, sc.lens[3]);
+    }
+    v3 aperture_p = sc.sample_exit_pupil ? pupil_p : V3(sc.lens[2] * dkx, sc.lens[2] * dky, sc.lens[3]);   // sample_rear_element, :1870-1878
     v3 o = film_p, d = normalize3(aperture_p - film_p);
     bool active = true;
     for (uint32_t i = 0; i < sc.lens_count; ++i) { v3 o2 = o, d2 = d; bool ok = lens_interact(sc.lens + MI_LENS_ROW * i, o2, d2); if (active && ok) { o = o2; d = d2; } active = active && ok; }
@@ -1029,7 +1044,20 @@ MI_DEV float sample_lens_ray(const DScene &sc, float pos_x, float pos_y, float a
     float inv_z = rcp_(d.z), near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;
     ray.o = ray.o + ray.d * near_t; ray.maxt = far_t - near_t;
     float c2 = d.z * d.z;
+    if (sc.sample_exit_pupil)                                               // :2282-2285
+        return active ? sc.shutter_open_time * bounds_area * (1.f / (sc.lens[3] * sc.lens[3])) : 0.f;
     return active ? c2 * c2 : 0.f;
+}
+// RadicalInverse::eval (include/mitsuba/core/qmc.h:67-92), recip = 1.f / base (qmc.cpp:50)
+MI_DEV float radical_inverse(uint32_t base, uint32_t index) {
+    uint32_t value = 0; float factor = 1.f, recip = 1.f / (float) base;
+    while (index != 0u) {
+        uint32_t next = index / base;
+        factor = factor * recip;
+        value = (value - next) * base + index;
+        index = next;
+    }
+    return fminf(0.99999994f, (float) value * factor);
 }
 // render_sample head (integrator.cpp:433-455): pixel jitter, aperture sample when the sensor needs one, ray + ray weight
 template <bool FULL>
@@ -1037,8 +1065,10 @@ MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, fl
     pos_x = (float) px + next_1d(rng); pos_y = (float) py + next_1d(rng);                  // integrator.cpp:435
     if (FULL && sc.sensor_type == MI355_SENSOR_REALISTICLENS) {
         float ap_x = next_1d(rng), ap_y = next_1d(rng);                                    // needs_aperture_sample, :438-440
+        if (sc.shutter_open_time > 0.f) (void) next_1d(rng);                               // time sample, :442-444
         return sample_lens_ray(sc, pos_x, pos_y, ap_x, ap_y, ray);
     }
+    if (sc.shutter_open_time > 0.f) (void) next_1d(rng);                                   // time sample, :442-444
     ray = sample_primary_ray(sc, pos_x, pos_y); return 1.f;
 }
 

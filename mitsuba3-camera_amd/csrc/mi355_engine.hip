@@ -662,6 +662,39 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     flush_counters(s_cnt, cnt, g_counters);
 }
 
+// bound_exit_pupil / compute_exit_pupil_bounds (realisticlens.cpp:1685-1806): 64 rings of film radii x 2^20 rays each towards a
+// (1.5 x rear radius)^2 square on the rear plane, sampled with radical inverses in bases 2 and 3; the bound of a ring is the
+// bounding box of the rays that make it through the lens.  min/max of floats through order-preserving unsigned keys.
+MI_DEV uint32_t float_key(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static inline float key_float(uint32_t k) { uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; }
+#define PUPIL_SEGMENTS 64
+#define PUPIL_RAYS (1u << 20)
+__global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t lens_count, float film_diagonal, uint32_t *keys /* [64][5] */) {
+    __shared__ uint32_t s_k[5];
+    if (threadIdx.x < 5) s_k[threadIdx.x] = threadIdx.x < 2 ? 0xffffffffu : 0u;
+    __syncthreads();
+    const uint32_t blocks_per_seg = PUPIL_RAYS / 256u, seg = blockIdx.x / blocks_per_seg, i = (blockIdx.x % blocks_per_seg) * 256u + threadIdx.x;
+    const float rear_radius = lens[2] * 1.5f, rear_z = lens[3];
+    const float r0 = (float) seg * film_diagonal / (float) PUPIL_SEGMENTS, r1 = (float) (seg + 1u) * film_diagonal / (float) PUPIL_SEGMENTS;
+    const float tf = ((float) i + 0.5f) / (float) PUPIL_RAYS;
+    v3 p_film = V3(fmaf(r1, tf, fmaf(-r0, tf, r0)), 0.f, 0.f);
+    const float u = radical_inverse(2u, i), v = radical_inverse(3u, i);
+    v3 p_rear = V3(fmaf(rear_radius, u, fmaf(rear_radius, u, -rear_radius)), fmaf(rear_radius, v, fmaf(rear_radius, v, -rear_radius)), rear_z);
+    v3 o = p_film, d = normalize3(p_rear - p_film);
+    bool active = true;
+    for (uint32_t k = 0; k < lens_count && active; ++k) active = lens_interact(lens + MI_LENS_ROW * k, o, d);
+    if (active) {
+        atomicMin(&s_k[0], float_key(p_rear.x)); atomicMin(&s_k[1], float_key(p_rear.y));
+        atomicMax(&s_k[2], float_key(p_rear.x)); atomicMax(&s_k[3], float_key(p_rear.y));
+        atomicAdd(&s_k[4], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && s_k[4] != 0u) {
+        uint32_t *g = keys + 5u * seg + threadIdx.x;
+        if (threadIdx.x < 2) atomicMin(g, s_k[threadIdx.x]); else if (threadIdx.x < 4) atomicMax(g, s_k[threadIdx.x]); else atomicAdd(g, s_k[4]);
+    }
+}
+
 // HDRFilm::develop, hdrfilm.cpp:304-409
 __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,14 +807,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_pupil = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
@@ -1170,6 +1203,27 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
     if ((rc = upload(&s->d_lens, s->lens))) return rc;
     ds.lens = s->d_lens;
+    ds.shutter_open_time = se.shutter_open_time; ds.film_diagonal = se.film_diagonal;
+    ds.sample_exit_pupil = (se.type == MI355_SENSOR_REALISTICLENS && se.sample_exit_pupil) ? 1u : 0u;
+    if (ds.sample_exit_pupil) {                                             // compute_exit_pupil_bounds, realisticlens.cpp:1772-1806
+        uint32_t *d_keys = nullptr, h_keys[PUPIL_SEGMENTS * 5];
+        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) { h_keys[5 * i] = h_keys[5 * i + 1] = 0xffffffffu; h_keys[5 * i + 2] = h_keys[5 * i + 3] = h_keys[5 * i + 4] = 0u; }
+        HIP_TRY(hipMalloc((void **) &d_keys, sizeof(h_keys)));
+        HIP_TRY(hipMemcpy(d_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_exit_pupil, dim3(PUPIL_SEGMENTS * (PUPIL_RAYS / 256u)), dim3(256), 0, 0, s->d_lens, se.lens_count, se.film_diagonal, d_keys);
+        hipError_t le = hipGetLastError(); if (le == hipSuccess) le = hipMemcpy(h_keys, d_keys, sizeof(h_keys), hipMemcpyDeviceToHost);
+        (void) hipFree(d_keys);
+        HIP_TRY(le);
+        const float rear_radius = s->lens[2] * 1.5f, spacing = 4.f * rear_radius * sqrtf(2.f / (float) PUPIL_RAYS);
+        s->pupil.assign(PUPIL_SEGMENTS * 4, 0.f);
+        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) {
+            float mnx = -rear_radius, mny = -rear_radius, mxx = rear_radius, mxy = rear_radius;      // nothing transmitted: the whole square
+            if (h_keys[5 * i + 4] != 0u) { mnx = key_float(h_keys[5 * i]); mny = key_float(h_keys[5 * i + 1]); mxx = key_float(h_keys[5 * i + 2]); mxy = key_float(h_keys[5 * i + 3]); }
+            s->pupil[4 * i] = mnx - spacing; s->pupil[4 * i + 1] = mny - spacing; s->pupil[4 * i + 2] = mxx + spacing; s->pupil[4 * i + 3] = mxy + spacing;
+        }
+        if ((rc = upload(&s->d_pupil, s->pupil))) return rc;
+        ds.pupil = s->d_pupil;
+    }
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
@@ -1204,7 +1258,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -1432,6 +1486,12 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
       if (reset) { memset(pr, 0, sizeof(pr)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), pr, sizeof(pr))); } }
 #endif
     if (reset) { HIP_TRY(hipMemset(s->d_counters, 0, sizeof(h))); s->n_gen = s->n_splat = 0; s->ms_accum = 0.f; s->launches_accum = 0; }
+    return MI355_OK;
+}
+extern "C" int mi355_lens_exit_pupil_bounds(const mi355_scene *s, float *out) {
+    if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
+    if (s->pupil.empty()) return fail(MI355_ERR_INVALID, "the scene's sensor does not sample an exit pupil");
+    memcpy(out, s->pupil.data(), s->pupil.size() * sizeof(float));
     return MI355_OK;
 }
 extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {

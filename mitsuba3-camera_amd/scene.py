@@ -350,11 +350,14 @@ class Sensor:
         if self.to_world.has_scale():
             raise PluginError("Scale factors in the camera-to-world transformation are not allowed!")
         self.near_clip = float(props.get("near_clip", 1e-2)); self.far_clip = float(props.get("far_clip", 1e4))
-        self.lens_table = None; self.interfaces = None
+        self.lens_table = None; self.interfaces = None; self.sample_exit_pupil = False
+        # Sensor::Sensor (sensor.cpp): shutter_open / shutter_close, open time = close - open
+        self.shutter_open = float(props.get("shutter_open", 0.0)); self.shutter_open_time = float(props.get("shutter_close", 0.0)) - self.shutter_open
+        if self.shutter_open_time < 0:
+            raise PluginError("Shutter opening time must be less than or equal to the shutter closing time!")
         if self.type == abi.SENSOR_REALISTICLENS:       # realisticlens.cpp:832-907
             from . import lens as _lens
-            if props.get("sample_exit_pupil", False):
-                raise PluginError("realisticlens: sample_exit_pupil=true (exit-pupil LUT) is not carried by this build")
+            self.sample_exit_pupil = bool(props.get("sample_exit_pupil", False))       # realisticlens.cpp:851
             try:
                 self.interfaces, self.focus_delta = _lens.build_lens(props, self.film.physical_size()[0])
             except NotImplementedError as e:
@@ -435,6 +438,7 @@ class Scene:
             d.sensor.lens_data = se.lens_table.ctypes.data_as(abi.f32p); keep.append(se.lens_table)
         d.sensor.film_diagonal = f.diagonal
         d.sensor.to_world[:] = se.to_world.affine12().tolist()
+        d.sensor.shutter_open_time = se.shutter_open_time; d.sensor.sample_exit_pupil = 1 if se.sample_exit_pupil else 0
         d.sensor.x_fov, d.sensor.near_clip, d.sensor.far_clip = se.x_fov, se.near_clip, se.far_clip
         d.sensor.film_width, d.sensor.film_height = f.width, f.height
         d.sensor.crop_offset_x, d.sensor.crop_offset_y = f.crop_offset_x, f.crop_offset_y

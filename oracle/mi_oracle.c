@@ -284,11 +284,13 @@ typedef struct {
     float sample_to_camera[16], camera_to_sample[16];
     float filter_coeff[10]; float filter_radius;
     float *lens; uint32_t lens_count; float film_px, film_py;   /* realisticlens: interface table, physical half extents */
+    float pupil[64 * 4];                                          /* exit-pupil bounds (min.x, min.y, max.x, max.y) per film-radius segment */
     uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
 } OScene;
 
 static void *dupmem(const void *p, size_t n) { if (!p || !n) return NULL; void *q = malloc(n); memcpy(q, p, n); return q; }
 
+static void exit_pupil_bounds(OScene *sc, float film_diagonal);
 ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
     if (!d || d->abi_version != MI355_ABI_VERSION) return NULL;
     OScene *s = (OScene *) calloc(1, sizeof(OScene));
@@ -349,6 +351,7 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
         float aspect = (float) d->sensor.film_height / (float) d->sensor.film_width;      /* Film::get_physical_size, film.h:193-198 */
         float x = sqrtf(d->sensor.film_diagonal * d->sensor.film_diagonal / (1.f + aspect * aspect));
         s->film_px = x / 2; s->film_py = aspect * x / 2;
+        if (d->sensor.sample_exit_pupil) exit_pupil_bounds(s, d->sensor.film_diagonal);
     }
     if (d->sensor.rfilter == MI355_RFILTER_GAUSSIAN) {
         orc_gaussian_coeffs(d->sensor.rfilter_param, s->filter_coeff); s->filter_radius = 4.f * d->sensor.rfilter_param;
@@ -1087,6 +1090,46 @@ static int lens_interact(const float *L, v3 *o, v3 *d) {
     *o = p;
     return 1;
 }
+/* RadicalInverse::eval (include/mitsuba/core/qmc.h:67-92), prime bases 2 and 3, recip = 1.f / base (qmc.cpp:50) */
+static float radical_inverse(uint32_t base, uint64_t index) {
+    uint64_t value = 0; float factor = 1.f, recip = 1.f / (float) base;
+    while (index != 0) {
+        uint64_t next = index / base;
+        factor = factor * recip;
+        value = (value - next) * base + index;
+        index = next;
+    }
+    return fminf(0.99999994f, (float) value * factor);
+}
+static float lerp_(float a, float b, float t) { return fmaf(b, t, fmaf(-a, t, a)); }   /* dr::lerp = fmadd(b, t, fnmadd(a, t, a)) */
+/* bound_exit_pupil + compute_exit_pupil_bounds (realisticlens.cpp:1685-1806): for 64 rings of film radii, the bounding box on
+ * the rear plane of the rays that make it through the lens.  (The reference skips samples that already lie inside the box;
+ * that only saves work.) */
+static void exit_pupil_bounds(OScene *sc, float film_diagonal) {
+    const uint32_t NSEG = 64, N = 1u << 20;
+    const float rear_radius = sc->lens[2] * 1.5f, rear_z = sc->lens[3];
+    for (uint32_t seg = 0; seg < NSEG; ++seg) {
+        float r0 = (float) seg * film_diagonal / (float) NSEG, r1 = (float) (seg + 1) * film_diagonal / (float) NSEG;
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY; uint64_t transmitted = 0;
+        #pragma omp parallel for reduction(min:mnx, mny) reduction(max:mxx, mxy) reduction(+:transmitted) schedule(static)
+        for (int64_t i = 0; i < (int64_t) N; ++i) {
+            v3 p_film = V3(lerp_(r0, r1, ((float) i + 0.5f) / (float) N), 0.f, 0.f);
+            v3 p_rear = V3(lerp_(-rear_radius, rear_radius, radical_inverse(2, (uint64_t) i)),
+                           lerp_(-rear_radius, rear_radius, radical_inverse(3, (uint64_t) i)), rear_z);
+            v3 o = p_film, d = normalize3(sub3(p_rear, p_film));
+            int active = 1;
+            for (uint32_t k = 0; k < sc->lens_count && active; ++k) active = lens_interact(sc->lens + ORC_LENS_ROW * k, &o, &d);
+            if (active) {
+                mnx = fminf(mnx, p_rear.x); mny = fminf(mny, p_rear.y); mxx = fmaxf(mxx, p_rear.x); mxy = fmaxf(mxy, p_rear.y);
+                transmitted++;
+            }
+        }
+        if (transmitted == 0) { mnx = mny = -rear_radius; mxx = mxy = rear_radius; }
+        float spacing = 4.f * rear_radius * sqrtf(2.f / (float) N);
+        float *b = sc->pupil + 4 * seg;
+        b[0] = mnx - spacing; b[1] = mny - spacing; b[2] = mxx + spacing; b[3] = mxy + spacing;
+    }
+}
 static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample, Ray *ray_out) {
     float sx = 1.f / (float) sc->sensor.crop_width, sy = 1.f / (float) sc->sensor.crop_height;
     float ax = fmaf(sample_pos.x, sx, -(float) sc->sensor.crop_offset_x * sx), ay = fmaf(sample_pos.y, sy, -(float) sc->sensor.crop_offset_y * sy);
@@ -1095,8 +1138,20 @@ static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample
     float rox = (float) sc->sensor.crop_offset_x / (float) sc->sensor.film_width, roy = (float) sc->sensor.crop_offset_y / (float) sc->sensor.film_height;
     v3 film_p = V3(sc->film_px * (2.f * fmaf(ax, rsx, rox) - 1.f), sc->film_py * (2.f * fmaf(ay, rsy, roy) - 1.f), 0.f);
     const float *L0 = sc->lens;
-    v2 dk = square_to_uniform_disk_concentric(aperture_sample);
-    v3 aperture_p = V3(L0[2] * dk.x, L0[2] * dk.y, L0[3]);              /* sample_rear_element, :1870-1878 */
+    v3 aperture_p; float bounds_area = 0.f;
+    if (sc->sensor.sample_exit_pupil) {                                 /* sample_exit_pupil, :1808-1836 */
+        float r_film = sqrtf(film_p.x * film_p.x + film_p.y * film_p.y);
+        uint32_t r_idx = (uint32_t) (int32_t) floorf(r_film / sc->sensor.film_diagonal * 64.f);
+        if (r_idx > 63u) r_idx = 63u;
+        const float *b = sc->pupil + 4 * r_idx;
+        bounds_area = (b[2] - b[0]) * (b[3] - b[1]);
+        float px = lerp_(b[0], b[2], aperture_sample.x), py = lerp_(b[1], b[3], aperture_sample.y);
+        float sin_t = r_film > 0.f ? film_p.y * (1.f / r_film) : 0.f, cos_t = r_film > 0.f ? film_p.x * (1.f / r_film) : 1.f;
+        aperture_p = V3(cos_t * px - sin_t * py, sin_t * px + cos_t * py, L0[3]);
+    } else {
+        v2 dk = square_to_uniform_disk_concentric(aperture_sample);
+        aperture_p = V3(L0[2] * dk.x, L0[2] * dk.y, L0[3]);             /* sample_rear_element, :1870-1878 */
+    }
     v3 o = film_p, d = normalize3(sub3(aperture_p, film_p));
     int active = 1;
     for (uint32_t i = 0; i < sc->lens_count && active; ++i) active = lens_interact(sc->lens + ORC_LENS_ROW * i, &o, &d);
@@ -1105,6 +1160,8 @@ static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample
     float inv_z = rcpf_(d.z), near_t = sc->sensor.near_clip * inv_z, far_t = sc->sensor.far_clip * inv_z;
     ray_out->o = add3(ray_out->o, scale3(ray_out->d, near_t)); ray_out->maxt = far_t - near_t;
     float ct = d.z, c2 = ct * ct;
+    if (sc->sensor.sample_exit_pupil)                                   /* :2282-2285 */
+        return active ? sc->sensor.shutter_open_time * bounds_area * (1.f / (L0[3] * L0[3])) : 0.f;
     return active ? c2 * c2 : 0.f;
 }
 
@@ -1325,6 +1382,8 @@ ORC_API void orc_film_develop(const OScene *sc, const float *film_rgbw, float *i
     }
 }
 /* test hook for ImageBlock::put KATs */
+ORC_API void orc_exit_pupil_bounds(const OScene *sc, float *out) { memcpy(out, sc->pupil, sizeof(sc->pupil)); }
+ORC_API float orc_radical_inverse(uint32_t base, uint64_t index) { return radical_inverse(base, index); }
 ORC_API void orc_film_put(const OScene *sc, float *film_rgbw, const float *pos2, const float *values4, int n) {
     for (int i = 0; i < n; ++i) { v2 p = { pos2[2*i], pos2[2*i+1] }; film_put(sc, film_rgbw, 4, p, values4 + 4*i); }
 }
@@ -1347,8 +1406,10 @@ static float camera_ray(const OScene *sc, pcg32 *rng, uint32_t lane, uint32_t sp
     sp->x = (float) px + pcg32_float(rng); sp->y = (float) py + pcg32_float(rng);          /* integrator.cpp:435 */
     if (sc->sensor.type == MI355_SENSOR_REALISTICLENS) {
         v2 ap; ap.x = pcg32_float(rng); ap.y = pcg32_float(rng);                         /* needs_aperture_sample, :438-440 */
+        if (sc->sensor.shutter_open_time > 0.f) (void) pcg32_float(rng);                 /* time sample, :442-444 */
         return sample_lens_ray(sc, *sp, ap, ray);
     }
+    if (sc->sensor.shutter_open_time > 0.f) (void) pcg32_float(rng);                     /* time sample, :442-444 */
     *ray = sample_primary_ray(sc, *sp); return 1.f;
 }
 static void trace_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane, v3 *rgb, int *valid, v2 *pos, Cnt *cnt) {

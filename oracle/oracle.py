@@ -70,6 +70,9 @@ def lib(abi):
     l.orc_texture_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
     l.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     l.orc_num_threads.restype = C.c_int
+    l.orc_exit_pupil_bounds.argtypes = [C.c_void_p, C.c_void_p]
+    l.orc_radical_inverse.restype = C.c_float
+    l.orc_radical_inverse.argtypes = [C.c_uint32, C.c_uint64]
     _lib = l
     return l
 
@@ -165,6 +168,11 @@ class OracleScene:
         rays = np.empty((sp.shape[0], 8), dtype=np.float32)
         self.l.orc_lens_rays(self.h, _p(sp), _p(ap), sp.shape[0], _p(rays))
         return rays
+
+    def exit_pupil_bounds(self):
+        out = np.empty((64, 4), dtype=np.float32)
+        self.l.orc_exit_pupil_bounds(self.h, _p(out))
+        return out
 
     def surface_area(self, shape):
         return float(self.l.orc_shape_surface_area(self.h, shape))

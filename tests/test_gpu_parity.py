@@ -375,12 +375,11 @@ def _asph_singlet(mi):
             lens.Interface(lens.ASPHERE, 0.01, base[1].z, glass, lens.AIR, curvature_radius=50.0, kappa=0.4, ai=[-1e-5, 2e-7, 0, 0, 0, 0, 0])]
 
 
-def _lens_cbox(mi, design, res=32):
+def _lens_cbox(mi, design, res=32, **extra):
     T = mi.ScalarTransform4f
     d = mi.cornell_box()
-    extra = {}
     if design == "asph_singlet":
-        design, extra = "custom", {"lens_interfaces": _asph_singlet(mi)}
+        design, extra = "custom", dict(extra, lens_interfaces=_asph_singlet(mi))
     d["sensor"] = {"type": "realisticlens", "lens_design": design, **extra, "object_distance": 3.9, "lens_focal_length": 0.05, "lens_diameter": 0.02,
                    "near_clip": 0.001, "far_clip": 100.0, "to_world": T.look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0]),
                    "sampler": {"type": "independent", "sample_count": 16},
@@ -516,6 +515,35 @@ def test_one_pass_adjoint_equals_two_pass(mi, orc, torch_cuda, case):
         assert c1["n_redo_groups"] == 0, c1["n_redo_groups"]
         for k in ("n_isect", "n_shade", "n_shadow"):
             assert 2 * c1[k] == c2[k], k                                  # one walk instead of two
+
+
+@pytest.mark.parametrize("design", ["singlet", "doublet", "exp2a"])
+def test_exit_pupil_sampling_matches_oracle(mi, orc, torch_cuda, design):
+    """realisticlens `sample_exit_pupil` (realisticlens.cpp:1685-1836, :2282-2285): the 64 x 2^20-ray exit-pupil LUT the engine
+    traces at scene creation equals the oracle's (min / max of the same rays: order-independent; a ray whose transmission
+    flips between v_rsq and libm can move a bound by one sample spacing), lanes agree, shutter_open_time > 0 costs one
+    sampler draw per sample -- and with the LUT the 22-surface Nikon design (exp2a) finally transmits most of its rays."""
+    import ctypes
+    scene = _lens_cbox(mi, design, sample_exit_pupil=True, shutter_open=0.0, shutter_close=1.0)
+    got = np.empty((64, 4), dtype=np.float32)
+    mi.abi.check(mi.abi.lib().mi355_lens_exit_pupil_bounds(scene.handle(), got.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 3})
+    spp, seed, n = 8, 5, 32 * 32 * 8
+    lanes = integ.lane_radiance(scene, seed, spp, 0, n).cpu().numpy()
+    assert np.isfinite(lanes).all()
+    if design == "exp2a":
+        assert (lanes[:, :3].max(axis=1) > 0).mean() > 0.05             # lit lanes; without the LUT: none of 8192 (test_realisticlens_matches_oracle)
+        assert got[0, 2] - got[0, 0] < 0.1 * 2 * 1.5 * scene.sensor.interfaces[0].element_radius   # (outer rings nothing gets through: whole square)
+        return                                                          # (the oracle's LUT for 22 surfaces takes a minute on 8 cores)
+    o = orc.OracleScene(scene, mi.abi)
+    ref_b = o.exit_pupil_bounds()
+    spacing = 2 * 1.5 * scene.sensor.interfaces[0].element_radius / 1024
+    assert np.abs(got - ref_b).max() <= spacing and (got == ref_b).mean() > 0.9
+    ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
+    close = np.isclose(lanes[:, :3], ref[:, :3], rtol=2e-4, atol=1e-5).all(axis=1) & (lanes[:, 3] == ref[:, 3])
+    assert close.mean() > (0.998 if (got == ref_b).all() else 0.97), "diverged lanes: %g" % (1 - close.mean())
+    off = _lens_cbox(mi, design, sample_exit_pupil=True)                 # shutter closed: the reference's weight is 0 (:2284)
+    assert float(integ.render(off, seed=1, spp=4).abs().max()) == 0.0
 
 
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):

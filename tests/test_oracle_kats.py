@@ -569,8 +569,53 @@ def test_lens_focus_and_trace(orc, mi, design):
             assert abs(hit[:, 0].mean()) > 1e-3
     wide = o.lens_rays(np.tile(np.array([32.0, 32.0], dtype=np.float32), (256, 1)), rng.random((256, 2), dtype=np.float32))
     assert (wide[:, 7] >= 0).all() and (wide[:, 7] <= 1 + 1e-5).all()
+    if design == "singlet":                                                     # unknown names fall back to the singlet (:896-898)
+        assert np.array_equal(_lens_scene(mi, "no-such-design", 64).sensor.lens_table, sc.sensor.lens_table)
+
+
+def test_radical_inverse_and_time_sample(orc, mi):
+    """RadicalInverse::eval (qmc.h:67-92) in bases 2 and 3 -- van der Corput values are exact binary fractions, base 3 follows
+    the float recurrence -- and the extra sampler draw a sensor with shutter_open_time > 0 costs (integrator.cpp:442-444)."""
+    l = orc.lib(mi.abi)
+    assert [l.orc_radical_inverse(2, i) for i in range(8)] == [0.0, 0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875]
+    third = np.float32(1) / np.float32(3)
+    assert l.orc_radical_inverse(3, 1) == float(third) and l.orc_radical_inverse(3, 2) == float(np.float32(2) * third)
+    assert abs(l.orc_radical_inverse(3, 5) - (2 / 3 + 1 / 9)) < 1e-7 and l.orc_radical_inverse(2, (1 << 20) - 1) < 1.0
+    d = small_cbox_for(mi, 8)
+    a = orc.OracleScene(mi.load_dict(d), mi.abi)
+    d["sensor"]["shutter_open"] = 0.25; d["sensor"]["shutter_close"] = 0.75
+    sc_b = mi.load_dict(d); b = orc.OracleScene(sc_b, mi.abi)
+    assert sc_b.sensor.shutter_open_time == 0.5
+    integ = mi.PathIntegrator({"max_depth": 3})
+    la, lb = a.lane_radiance(a.params(integ, 1, 4), 0, 256), b.lane_radiance(b.params(integ, 1, 4), 0, 256)
+    assert not np.allclose(la, lb)                                   # the light paths use a shifted sample stream ...
+    wa, wb = a.splat_weights(a.params(integ, 1, 4)), b.splat_weights(b.params(integ, 1, 4))
+    assert np.array_equal(wa, wb)                                    # ... the film positions (drawn first) do not move
     with pytest.raises(mi.PluginError):
-        _lens_scene(mi, "singlet", sample_exit_pupil=True)
+        d["sensor"]["shutter_close"] = 0.1; mi.load_dict(d)
+
+
+def test_exit_pupil_bounds(orc, mi):
+    """compute_exit_pupil_bounds (realisticlens.cpp:1685-1806) on the singlet: the bounds are symmetric about the meridional
+    plane (p_film sits on the +x axis), contain the axis for the central ring, stay inside the sampled (1.5 x rear radius)^2
+    square plus its padding, and every ray the sensor then samples starts inside its ring's bounds; the ray weight is
+    shutter_open_time * bounds_area / z_rear^2 (:2282-2285)."""
+    sc = _lens_scene(mi, "singlet", 32, sample_exit_pupil=True, shutter_close=2.0)
+    o = orc.OracleScene(sc, mi.abi)
+    b = o.exit_pupil_bounds()
+    rr = 1.5 * sc.sensor.interfaces[0].element_radius; pad = 4 * rr * np.sqrt(2 / (1 << 20))
+    assert b.shape == (64, 4) and np.allclose(b[:, 1], -b[:, 3], atol=2e-5) and (b[:, 0] >= -rr - pad - 1e-7).all() and (b[:, 2] <= rr + pad + 1e-7).all()
+    assert b[0, 0] < 0 < b[0, 2] and (b[:, 2] > b[:, 0]).all()
+    assert b[40, 2] - b[40, 0] <= b[0, 2] - b[0, 0] + 1e-6               # vignetting narrows the pupil off-axis
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(0, 32, (256, 2)).astype(np.float32)
+    rays = o.lens_rays(pos, rng.random((256, 2), dtype=np.float32))
+    ok = rays[:, 7] > 0
+    assert ok.mean() > 0.4                                               # the box over-covers the round pupil, but not by much
+    z = sc.sensor.interfaces[0].z
+    areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    got = np.unique(np.round(rays[ok, 7] * z * z / 2.0, 10))
+    assert all(np.isclose(areas, g, rtol=1e-4).any() for g in got)
 
 
 @pytest.mark.parametrize("design", ["asph", "hypercentric"])
