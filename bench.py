@@ -97,23 +97,37 @@ def main():
     n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
     my_tiles = [t for t in range(n_tiles) if t % world == rank]
     my_shard = mi.shard_tiles(W, H, rank, world, rows=TILE_ROWS)
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    # N > 1: two film accumulators, so that the reduce of frame k (RCCL runs it on its own stream) overlaps the kernel of
+    # frame k + 1; a frame is complete when its accumulator has been reduced to rank 0 and developed there.
+    films = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    pending = [None] * len(films)
     img = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    frame_no = [0]
+
+    def finish(b):
+        if pending[b] is not None:
+            pending[b].wait(); pending[b] = None                          # the compute stream waits for the collective (no host sync)
+            if rank == 0:
+                mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(films[b].data_ptr()), C.c_void_p(img.data_ptr()), stream))
 
     def step(seed):
+        b = frame_no[0] % len(films); frame_no[0] += 1
+        finish(b)
+        film = films[b]
         film.zero_()
         if world == 1:
             p = integ._params(scene, seed, args.spp)
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
+            mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
         else:
             p = integ._params(scene, seed, args.spp, shard=my_shard)      # all of this rank's tiles in ONE launch
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)                   # the frame is assembled (and developed) on rank 0
-        if rank == 0:
-            mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
+            pending[b] = dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, async_op=True)   # the frame is assembled (and developed) on rank 0
 
     def barrier():
+        for b in range(len(films)):                                       # every frame of the timed region is finished inside it
+            finish(b)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -264,7 +278,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
-                          "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film reduce to rank 0" if world > 1 else "none"},
+                          "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film reduce to rank 0 overlapped with the next frame" if world > 1 else "none"},
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4
