@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--prb-plain", action="store_true", help="A/B: PRB leg without the albedo texture (constant reflectances only)")
     ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
     ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
     ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
@@ -191,7 +192,7 @@ def main():
         rng = np.random.default_rng(12345)
         d3["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
                                                          "data": rng.uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
-        if not os.environ.get("MI355_BENCH_PLAIN"):                 # experiment switch: constant albedos only
+        if not args.prb_plain:
             d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
         scene3 = mi.load_dict(d3)
         prb_i = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb_i.timing = True
@@ -210,7 +211,7 @@ def main():
         c3 = prb_i.counters(scene3, reset=True)
         if dist is not None:
             tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
-        g = params.grad("tex.reflectance.data") if not os.environ.get("MI355_BENCH_PLAIN") else params.grad_buffer(dev)
+        g = params.grad("tex.reflectance.data") if not args.prb_plain else params.grad_buffer(dev)
         prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
                "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),

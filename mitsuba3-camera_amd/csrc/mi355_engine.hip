@@ -1,12 +1,20 @@
 // mi355_engine.hip -- kernels and host side of the C ABI declared in include/mi355.h.
 //
-// Kernels (all gfx950, 256-thread workgroups = 4 waves of 64):
-//   k_render<INTEGRATOR, OUT>   one lane per camera path: TEA/PCG32 seed -> pixel jitter -> primary ray
-//                               -> PathIntegrator::sample / PRBIntegrator.sample (primal) in registers
-//                               -> per-pixel pre-reduced film splat through LDS (one atomic per tap+channel
-//                               per wave instead of 100 per lane)
+// Kernels (all gfx950, 256-thread workgroups = 4 waves of 64; FULL = scene has non-diffuse BSDFs / spheres / a lens sensor):
+//   k_render_compact<INTEGRATOR, FULL>  DEFAULT forward kernel.  One lane per camera path: TEA/PCG32 seed -> pixel jitter ->
+//                               primary ray -> PathIntegrator::sample / PRBIntegrator.sample (primal) with the state in
+//                               registers; the workgroup re-packs its live paths (wave ballot + mbcnt prefix, SoA state
+//                               through LDS) whenever that empties a wave; per-pixel pre-reduced film splat through LDS
+//                               (one atomic per tap+channel per wave instead of 100 per lane)
+//   k_render<INTEGRATOR, OUT, FULL>     same without re-packing (MI355_MODE_STATIC), and the per-lane debug output
+//   k_render_regen<FULL>        opt-in path regeneration variant (MI355_FLAG_REGEN)
 //   k_splat_weights             W[p] = sum of filter weights (PRB step 1a)
-//   k_prb_backward              dL gather -> primal replay -> adjoint replay; parameter gradients reduced in LDS
+//   k_prepare_grad              grad_in / W
+//   k_prb_backward_1p<FULL, BVH>  DEFAULT adjoint: dL gather -> ONE walk; gradient records wait in an LDS queue for the
+//                               lane's L_total, resolved per workgroup (LDS accumulators, per-texel hash, float atomics)
+//   k_prb_backward<FULL>        prb.py's two walks (primal replay + adjoint replay): MI355_FLAG_TWO_PASS, and the redo pass
+//                               for workgroups whose one-pass queue overflowed
+//   k_exit_pupil                realisticlens exit-pupil LUT (64 rings x 2^20 rays) at scene creation
 //   k_develop                   HDRFilm::develop
 //   k_debug_intersect           Scene::ray_intersect_preliminary / ray_test on caller rays
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
