@@ -840,6 +840,8 @@ static void roughconductor_sample(const mi355_bsdf_desc *b, v3 wi, v2 s2, int ac
     if (active) *weight = mul3(F, scale3(sr, w));
 }
 /* SmoothDielectric::sample, dielectric.cpp:246-371 (unpolarized, radiance transport); eval/pdf are zero (delta lobes) */
+static int g_importance_mode = 0;   /* TransportMode::Importance for the particle tracer (set per thread region; the oracle's drivers never mix modes) */
+#pragma omp threadprivate(g_importance_mode)
 static void dielectric_sample(const mi355_bsdf_desc *b, v3 wi, float s1, int active, BSample *bs, v3 *weight) {
     float eta = b->int_ior / b->ext_ior;
     float r_i, cos_theta_t, eta_it, eta_ti; fresnel_(wi.z, eta, &r_i, &cos_theta_t, &eta_it, &eta_ti);
@@ -849,7 +851,7 @@ static void dielectric_sample(const mi355_bsdf_desc *b, v3 wi, float s1, int act
     bs->wo = selected_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);
     bs->eta = selected_r ? 1.f : eta_it; bs->delta = 1;
     v3 w = selected_r ? V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]) : V3(b->transmittance[0], b->transmittance[1], b->transmittance[2]);
-    if (!selected_r) w = scale3(w, eta_ti * eta_ti);                    /* radiance scaling, dielectric.cpp:361-366 */
+    if (!selected_r && !g_importance_mode) w = scale3(w, eta_ti * eta_ti);   /* radiance scaling (TransportMode::Radiance only), dielectric.cpp:361-366 */
     *weight = active ? w : V3(0, 0, 0);
 }
 static void bsdf_eval_pdf(const mi355_bsdf_desc *b, v3 refl, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
@@ -1386,6 +1388,207 @@ ORC_API void orc_exit_pupil_bounds(const OScene *sc, float *out) { memcpy(out, s
 ORC_API float orc_radical_inverse(uint32_t base, uint64_t index) { return radical_inverse(base, index); }
 ORC_API void orc_film_put(const OScene *sc, float *film_rgbw, const float *pos2, const float *values4, int n) {
     for (int i = 0; i < n; ++i) { v2 p = { pos2[2*i], pos2[2*i+1] }; film_put(sc, film_rgbw, 4, p, values4 + 4*i); }
+}
+
+/* ----------------------------------------------------------------------------------------
+ * Particle tracer: src/integrators/ptracer.cpp:77-371 driven by AdjointIntegrator::render (integrator.cpp:545-745, JIT
+ * branch: one lane per sample, lanes = film_size * spp, sampler seeded like the path tracer's).  RGB, perspective sensor.
+ * ---------------------------------------------------------------------------------------- */
+/* ImageBlock::put with normalize = true (imageblock.cpp:460-474): the sample's filter weights are divided by their sum, the
+   weight channel is not touched (ptracer.cpp:366-368) */
+static void film_put_normalized(const OScene *sc, float *film_rgbw, v2 pos, v3 rgb) {
+    int32_t x0, y0; float wx[16], wy[16];
+    int count = splat_weights(sc, pos, &x0, &y0, wx, wy);
+    float sx = 0.f, sy = 0.f;
+    for (int i = 0; i < count; ++i) { sx += wx[i]; sy += wy[i]; }
+    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+    for (int i = 0; i < count; ++i) wx[i] *= factor;
+    int32_t W = (int32_t) sc->sensor.crop_width, H = (int32_t) sc->sensor.crop_height;
+    for (int ys = 0; ys < count; ++ys) for (int xs = 0; xs < count; ++xs) {
+        int32_t x = x0 + xs, y = y0 + ys;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        float w = wy[ys] * wx[xs];
+        float *px = film_rgbw + ((size_t) y * W + x) * 4;
+        px[0] += rgb.x * w; px[1] += rgb.y * w; px[2] += rgb.z * w;
+    }
+}
+static v3 xf_point_proj(const float *m, v3 p) {                        /* Transform4f * Point3f with the homogeneous divide */
+    float r[4];
+    for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], p.x, v); v = fmaf(m[i*4+1], p.y, v); v = fmaf(m[i*4+2], p.z, v); r[i] = v; }
+    float iw = 1.f / r[3];
+    return V3(r[0] * iw, r[1] * iw, r[2] * iw);
+}
+/* PerspectiveCamera::sample_direction + importance (perspective.cpp:282-386); image_rect / normalization :190-199.
+   Returns 0 when the point is not seen; else uv (pixels, crop-relative), the sensor position, direction, weight. */
+static int sensor_sample_direction(const OScene *sc, v3 p, v2 *uv, v3 *ds_p, v3 *ds_d, float *weight) {
+    const float *tw = sc->sensor.to_world;
+    /* inverse of the rigid camera frame (no scale: perspective.cpp:144-145) */
+    v3 rel = sub3(p, V3(tw[3], tw[7], tw[11]));
+    v3 ref_p = V3(tw[0] * rel.x + tw[4] * rel.y + tw[8] * rel.z, tw[1] * rel.x + tw[5] * rel.y + tw[9] * rel.z, tw[2] * rel.x + tw[6] * rel.y + tw[10] * rel.z);
+    if (!(ref_p.z >= sc->sensor.near_clip && ref_p.z <= sc->sensor.far_clip)) return 0;
+    v3 screen = xf_point_proj(sc->camera_to_sample, ref_p);
+    if (!(screen.x >= 0.f && screen.x <= 1.f && screen.y >= 0.f && screen.y <= 1.f)) return 0;
+    uv->x = screen.x * (float) sc->sensor.crop_width; uv->y = screen.y * (float) sc->sensor.crop_height;
+    float dist = norm3(ref_p), inv_dist = 1.f / dist;
+    v3 local_d = scale3(ref_p, inv_dist);
+    *ds_p = V3(tw[3], tw[7], tw[11]);
+    *ds_d = scale3(sub3(*ds_p, p), inv_dist);
+    v3 pmin = xf_point_proj(sc->sample_to_camera, V3(0.f, 0.f, 0.f)), pmax = xf_point_proj(sc->sample_to_camera, V3(1.f, 1.f, 0.f));
+    float ax = pmin.x / pmin.z, ay = pmin.y / pmin.z, bx = pmax.x / pmax.z, by = pmax.y / pmax.z;
+    float lox = fminf(ax, bx), hix = fmaxf(ax, bx), loy = fminf(ay, by), hiy = fmaxf(ay, by);
+    float normalization = 1.f / ((hix - lox) * (hiy - loy));
+    float ct = local_d.z, inv_ct = 1.f / ct, qx = local_d.x * inv_ct, qy = local_d.y * inv_ct;
+    int valid = ct > 0.f && qx >= lox && qx <= hix && qy >= loy && qy <= hiy;
+    float importance = valid ? normalization * inv_ct * inv_ct * inv_ct : 0.f;
+    *weight = importance * inv_dist * inv_dist;
+    return 1;
+}
+/* Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229 */
+static void shape_sample_position(const OShape *sh, v2 sample, v3 *p, v3 *n, float *pdf) {
+    if (sh->type == MI355_SHAPE_RECTANGLE) {
+        *p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f)); *n = sh->frame_n; *pdf = sh->inv_area;
+    } else {
+        float z = fmaf(-2.f, sample.y, 1.f), r = safe_sqrt_(fmaf(-z, z, 1.f)), ph = 2.f * ORC_PI * sample.x;   /* square_to_uniform_sphere, warp.h:250-255 */
+        v3 local = V3(r * cosf(ph), r * sinf(ph), z);
+        *p = fma3s(local, sh->radius, sh->center); *n = sh->flip_normals ? neg3(local) : local; *pdf = sh->inv_area;
+    }
+}
+/* a SurfaceInteraction built from a PositionSample: frame from the normal (interaction.h: SurfaceInteraction(ps, wavelengths)) */
+static SI si_from_position(v3 p, v3 n, int32_t shape) {
+    SI si; memset(&si, 0, sizeof(si));
+    si.p = p; si.n = n; si.sh_n = n; coordinate_system(n, &si.sh_s, &si.sh_t); si.shape = shape; si.t = 0.f;
+    return si;
+}
+/* connect_sensor, ptracer.cpp:286-371.  bsdf = NULL for a point on an emitter. */
+static void connect_sensor(OScene *sc, const SI *si, const mi355_bsdf_desc *bsdf, int have_sensor, v2 uv, v3 ds_p, v3 weight,
+                           float sample_scale, float *film_rgbw, Cnt *cnt) {
+    if (!have_sensor || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) return;
+    Ray sensor_ray = spawn_ray_to(si->p, si->n, ds_p);
+    cnt->shadow++;
+    if (scene_ray_test(sc, &sensor_ray)) return;
+    v3 local_d = si_to_local(si, sensor_ray.d);
+    v3 surface_weight = V3(1.f, 1.f, 1.f);
+    if (bsdf == NULL) surface_weight = scale3(surface_weight, fmaxf(0.f, local_d.z));                  /* foreshortening of the emitter */
+    else {
+        float wi_dot_geo_n = dot3(si->n, si_to_world(si, si->wi)), wo_dot_geo_n = dot3(si->n, sensor_ray.d);
+        int valid = wi_dot_geo_n * si->wi.z > 0.f && wo_dot_geo_n * local_d.z > 0.f;
+        float correction = valid ? fabsf((si->wi.z * wo_dot_geo_n) / (local_d.z * wi_dot_geo_n)) : 0.f;
+        v3 refl = bsdf_reflectance(sc, bsdf, si), val; float pdf;
+        bsdf_eval_pdf(bsdf, refl, si->wi, local_d, 1, &val, &pdf);
+        surface_weight = scale3(val, correction);
+    }
+    v3 result = scale3(mul3(weight, surface_weight), sample_scale);
+    v2 pos = { uv.x + (float) sc->sensor.crop_offset_x, uv.y + (float) sc->sensor.crop_offset_y };
+    film_put_normalized(sc, film_rgbw, pos, result);
+}
+static uint32_t pick_emitter(const OScene *sc, float *sample, float *weight) {                     /* Scene::sample_emitter, scene.cpp:227-250 */
+    *weight = 1.f;
+    if (sc->n_emitters < 2) return 0;
+    float cf = (float) sc->n_emitters, scaled = *sample * cf;
+    uint32_t index = (uint32_t) scaled; if (index > sc->n_emitters - 1) index = sc->n_emitters - 1;
+    *weight = cf; *sample = scaled - (float) index;
+    return index;
+}
+static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane, float sample_scale, float *film_rgbw, Cnt *cnt) {
+    pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+    const int timed = sc->sensor.shutter_open_time > 0.f;
+    const int32_t max_depth = rp->max_depth;
+    /* ---- sample_visible_emitters, ptracer.cpp:99-171 */
+    if (max_depth != 0 && !(rp->flags & MI355_FLAG_HIDE_EMITTERS)) {
+        if (timed) (void) pcg32_float(&rng);
+        float es = pcg32_float(&rng), idx_weight; uint32_t ei = pick_emitter(sc, &es, &idx_weight);
+        const mi355_emitter_desc *em = &sc->emitters[ei]; const OShape *sh = &sc->shapes[em->shape];
+        v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
+        v3 p, n; float pdf; shape_sample_position(sh, s2, &p, &n, &pdf);
+        float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
+        SI si = si_from_position(p, n, (int32_t) em->shape);
+        (void) pcg32_float(&rng); (void) pcg32_float(&rng);                                        /* sensor->sample_direction's (unused) 2D sample */
+        v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
+        int seen = sensor_sample_direction(sc, si.p, &uv, &ds_p, &ds_d, &sensor_weight);
+        si.wi = ds_d;
+        (void) pcg32_float(&rng);                                                                  /* sample_wavelengths: radiance in RGB mode */
+        v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
+        v3 weight = scale3(rad, idx_weight * pos_weight * sensor_weight);
+        connect_sensor(sc, &si, NULL, seen, uv, ds_p, weight, sample_scale, film_rgbw, cnt);
+    }
+    /* ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115) */
+    if (timed) (void) pcg32_float(&rng);
+    float wav = pcg32_float(&rng), idx_weight; uint32_t ei = pick_emitter(sc, &wav, &idx_weight);
+    v2 sa, sb; sa.x = pcg32_float(&rng); sa.y = pcg32_float(&rng); sb.x = pcg32_float(&rng); sb.y = pcg32_float(&rng);
+    const mi355_emitter_desc *em = &sc->emitters[ei]; const OShape *esh = &sc->shapes[em->shape];
+    v3 ep, en; float epdf; shape_sample_position(esh, sa, &ep, &en, &epdf);
+    SI esi = si_from_position(ep, en, (int32_t) em->shape);
+    v3 local = square_to_cosine_hemisphere(sb);
+    Ray ray = spawn_ray(esi.p, esi.n, si_to_world(&esi, local));
+    v3 throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (epdf > 0.f ? 1.f / epdf : 0.f) * ORC_PI * idx_weight);
+    int active = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) != 0.f;
+    /* ---- trace_light_ray, ptracer.cpp:200-284 */
+    float eta = 1.f; int32_t depth = 1;
+    PI pi; SI si;
+    if (active) { pi = scene_intersect(sc, &ray); cnt->isect++; si = compute_si(sc, &ray, &pi); active = si.shape >= 0; }
+    if (max_depth >= 0) active = active && depth < max_depth;
+    while (active) {
+        cnt->shade++;
+        const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
+        (void) pcg32_float(&rng); (void) pcg32_float(&rng);
+        v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
+        int seen = sensor_sample_direction(sc, si.p, &uv, &ds_p, &ds_d, &sensor_weight);
+        connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt);
+        float s1 = pcg32_float(&rng); v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
+        v3 refl = bsdf_reflectance(sc, bsdf, &si); BSample bs; v3 bsdf_val;
+        bsdf_sample(bsdf, refl, si.wi, s1, s2, 1, &bs, &bsdf_val);
+        v3 wo_world = si_to_world(&si, bs.wo);
+        float wi_dot_geo_n = dot3(si.n, neg3(ray.d)), wo_dot_geo_n = dot3(si.n, wo_world);
+        active = active && wi_dot_geo_n * si.wi.z > 0.f && wo_dot_geo_n * bs.wo.z > 0.f;
+        float correction = fabsf((si.wi.z * wo_dot_geo_n) / (bs.wo.z * wi_dot_geo_n));
+        throughput = mul3(throughput, scale3(bsdf_val, correction));
+        eta *= bs.eta;
+        active = active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
+        if (!active) break;
+        ray = spawn_ray(si.p, si.n, wo_world);
+        pi = scene_intersect(sc, &ray); cnt->isect++; si = compute_si(sc, &ray, &pi);
+        depth++;
+        if (max_depth >= 0) active = active && depth < max_depth;
+        active = active && si.shape >= 0;
+        if (depth > rp->rr_depth) {                                                                  /* :271-277 */
+            float q = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * (eta * eta), 0.95f);
+            active = active && pcg32_float(&rng) < q;       /* next_1d(active): dead lanes still advance their stream -- irrelevant, they are done */
+            throughput = scale3(throughput, 1.f / q);
+        }
+    }
+}
+/* AdjointIntegrator::render: lanes = FILM size * spp (not crop), sample_scale = prod(crop) / (spp * prod(film)).  The
+   accumulator is RGBW with W untouched = 0, so orc_film_develop divides by 1 (hdrfilm.cpp:396-400). */
+ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
+    size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
+    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * rp->spp;
+    if (sc->n_emitters == 0) return 0;                                                              /* integrator.cpp:590-600 */
+    float sample_scale = (float) (sc->sensor.crop_width * sc->sensor.crop_height) / (float) ((uint64_t) rp->spp * sc->sensor.film_width * sc->sensor.film_height);
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    float *films = (float *) calloc(fsz * (size_t) n_threads, sizeof(float));
+    uint64_t ci = 0, cs = 0, csh = 0;
+    #pragma omp parallel num_threads(n_threads) reduction(+:ci, cs, csh)
+    {
+#ifdef _OPENMP
+        float *film = films + fsz * (size_t) omp_get_thread_num();
+#else
+        float *film = films;
+#endif
+        Cnt cnt = { 0, 0, 0 };
+        g_importance_mode = 1;
+        #pragma omp for schedule(dynamic, 4096)
+        for (int64_t lane = 0; lane < (int64_t) lanes; ++lane) ptracer_lane(sc, rp, (uint32_t) lane, sample_scale, film, &cnt);
+        g_importance_mode = 0;
+        ci += cnt.isect; cs += cnt.shade; csh += cnt.shadow;
+    }
+    for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
+    free(films);
+    sc->c_isect += ci; sc->c_shade += cs; sc->c_shadow += csh;
+    return lanes;
 }
 
 /* ----------------------------------------------------------------------------------------

@@ -71,6 +71,8 @@ def lib(abi):
     l.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     l.orc_num_threads.restype = C.c_int
     l.orc_exit_pupil_bounds.argtypes = [C.c_void_p, C.c_void_p]
+    l.orc_ptracer_accumulate.restype = C.c_uint64
+    l.orc_ptracer_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int]
     l.orc_radical_inverse.restype = C.c_float
     l.orc_radical_inverse.argtypes = [C.c_uint32, C.c_uint64]
     _lib = l
@@ -118,6 +120,12 @@ class OracleScene:
         img = np.empty((self.H, self.W, 3), dtype=np.float32)
         self.l.orc_film_develop(self.h, _p(film), _p(img))
         return img, n
+
+    def ptracer_render(self, p, threads=0, develop=True):
+        """AdjointIntegrator::render with the particle tracer (ptracer.cpp): RGBW accumulator whose W stays 0."""
+        film = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        n = self.l.orc_ptracer_accumulate(self.h, C.byref(p), _p(film), threads)
+        return (self.develop(film) if develop else film), n
 
     def develop(self, film):
         film = np.ascontiguousarray(film, dtype=np.float32)

@@ -180,3 +180,32 @@ def test_texture_lookup(mi, orc):
     assert np.allclose(mid, (tex[0, 0] + tex[0, 1]) / 200, atol=1e-6)
     wrap = o.texture_eval(0, np.array([[0.0, 0.25]], dtype=np.float32))[0]      # repeat: between texel 3 and texel 0
     assert np.allclose(wrap, (tex[0, 3] + tex[0, 0]) / 200, atol=1e-6)
+
+
+def test_particle_tracer_agrees_with_path_tracer(mi, orc):
+    """Scope row (f)-3, forward part: the oracle's light tracer (ptracer.cpp:77-371 under AdjointIntegrator::render,
+    integrator.cpp:545-745) and its path tracer estimate the same image -- same maximum path length for the same max_depth
+    (visible emitters = length 1, a connection at light-path depth k = length k + 1).  Reference methodology: the two
+    integrators are compared statistically (test_renders.py); here: image means within 1.5 %, block means within 6 %."""
+    d = small_cbox(mi, 24); d["sensor"]["film"]["rfilter"] = {"type": "box"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    for md in (1, 2, 5):
+        integ = mi.PathIntegrator({"max_depth": md, "rr_depth": 3})
+        a, _ = o.render(o.params(integ, 0, 1024))
+        b, lanes = o.ptracer_render(o.params(integ, 0, 1024))
+        assert lanes == 24 * 24 * 1024 and np.isfinite(b).all()
+        assert abs(b.mean() / a.mean() - 1) < 0.015, (md, b.mean() / a.mean())
+        if md == 5:
+            ab = a.reshape(4, 6, 4, 6, 3).mean(axis=(1, 3)); bb = b.reshape(4, 6, 4, 6, 3).mean(axis=(1, 3))
+            assert (np.abs(bb - ab) < 0.06 * ab + 1e-3).mean() > 0.95
+    integ = mi.PathIntegrator({"max_depth": 4})
+    f1, _ = o.ptracer_render(o.params(integ, 7, 16), develop=False)
+    f2, _ = o.ptracer_render(o.params(integ, 7, 16), threads=3, develop=False)
+    assert np.allclose(f1, f2, rtol=1e-4, atol=1e-6) and (f1[..., 3] == 0).all()          # lanes are functions of (seed, lane); W unused
+    z, _ = o.ptracer_render(o.params(mi.PathIntegrator({"max_depth": 0}), 0, 4))
+    assert z.max() == 0.0
+    integ.hide_emitters = True
+    h, _ = o.ptracer_render(o.params(integ, 0, 256)); integ.hide_emitters = False
+    v, _ = o.ptracer_render(o.params(integ, 0, 256))
+    light = v - h                                                                           # the directly visible emitter only
+    assert light.max() > 5 * np.median(v) and (light >= -0.05 * v.max()).all()
