@@ -169,7 +169,10 @@ enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path sta
        MI355_MODE_STATIC = 2 };        /* never re-pack: a lane keeps its path until the longest path of its wave ends */
 
 enum { MI355_INTEGRATOR_PATH = 0,      /* src/integrators/path.cpp */
-       MI355_INTEGRATOR_PRB  = 1 };    /* src/python/python/ad/integrators/prb.py (primal estimator differs in RR timing) */
+       MI355_INTEGRATOR_PRB  = 1,      /* src/python/python/ad/integrators/prb.py (primal estimator differs in RR timing) */
+       MI355_INTEGRATOR_PTRACER = 2 }; /* src/integrators/ptracer.cpp under AdjointIntegrator::render (integrator.cpp:545-745): light paths
+                                          connected to a perspective sensor.  mi355_render_accumulate only; lanes = FILM pixels x spp (the
+                                          shard fields count film pixels, not crop pixels), normalised splats into RGB, W stays 0 */
 
 typedef struct mi355_render_params {
     uint32_t seed;                      /* the `seed` argument of Integrator::render */

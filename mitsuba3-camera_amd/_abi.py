@@ -22,7 +22,7 @@ FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS = 1, 2, 4, 8
 MODE_FUSED, MODE_WAVEFRONT, MODE_STATIC = 0, 1, 2
-INTEGRATOR_PATH, INTEGRATOR_PRB = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_PRB, INTEGRATOR_PTRACER = 0, 1, 2
 PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE = 0, 1, 2
 
 f32p = C.POINTER(C.c_float)

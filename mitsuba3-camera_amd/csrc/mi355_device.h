@@ -117,6 +117,8 @@ struct DScene {
     // realisticlens sensor: interface table (8 floats per interface, film -> world), physical half extents of the film
     uint32_t sensor_type, lens_count; const float *lens; float film_px, film_py;
     uint32_t film_w, film_h;
+    float camera_to_sample[16];   // perspective sensor, particle tracer: sample_direction (perspective.cpp:282-340)
+    float image_rect[4], normalization;   // lo.x, lo.y, hi.x, hi.y of the image plane at z = 1 and 1 / its area (perspective.cpp:190-199)
     float shutter_open_time;      // > 0: one extra sampler draw per sample for the time (integrator.cpp:442-444)
     uint32_t sample_exit_pupil; float film_diagonal; const float *pupil;   // exit-pupil bounds, 64 x (min.x, min.y, max.x, max.y)
 };
@@ -793,13 +795,14 @@ MI_DEV void roughconductor_sample(const DBsdf &b, v3 wi, float sx, float sy, boo
     v3 F = V3(fresnel_conductor_(ct, b.eta[0], b.k[0]), fresnel_conductor_(ct, b.eta[1], b.k[1]), fresnel_conductor_(ct, b.eta[2], b.k[2]));
     if (active) weight = F * (ld3(b.reflectance) * w);
 }
-MI_DEV void dielectric_sample(const DBsdf &b, v3 wi, float s1, bool active, BSample &bs, v3 &weight) {   // dielectric.cpp:246-371
+// `importance` = TransportMode::Importance (particle tracer): no radiance scaling of the transmitted lobe (dielectric.cpp:361-366)
+MI_DEV void dielectric_sample(const DBsdf &b, v3 wi, float s1, bool active, BSample &bs, v3 &weight, bool importance = false) {   // dielectric.cpp:246-371
     float r_i, cos_theta_t, eta_it, eta_ti; fresnel_(wi.z, b.rel_eta, r_i, cos_theta_t, eta_it, eta_ti);
     bool selected_r = s1 <= r_i && active;
     bs.pdf = selected_r ? r_i : 1.f - r_i;
     bs.wo = selected_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);
     bs.eta = selected_r ? 1.f : eta_it; bs.delta = true;
-    v3 w = selected_r ? ld3(b.reflectance) : ld3(b.transmittance) * (eta_ti * eta_ti);
+    v3 w = selected_r ? ld3(b.reflectance) : (importance ? ld3(b.transmittance) : ld3(b.transmittance) * (eta_ti * eta_ti));
     weight = active ? w : V3(0.f, 0.f, 0.f);
 }
 template <bool FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
@@ -807,10 +810,11 @@ template <bool FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
     else { val = V3(0.f, 0.f, 0.f); pdf = 0.f; }
 }
-template <bool FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, float s1, float s2x, float s2y, bool active, BSample &bs, v3 &weight) {
+template <bool FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, float s1, float s2x, float s2y, bool active, BSample &bs, v3 &weight,
+                                             bool importance = false) {
     if (!FULL || b.type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2x, s2y, active, bs.wo, bs.pdf, weight); bs.eta = 1.f; bs.delta = false; }
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2x, s2y, active, bs, weight);
-    else dielectric_sample(b, wi, s1, active, bs, weight);
+    else dielectric_sample(b, wi, s1, active, bs, weight, importance);
 }
 
 struct DS { v3 p, n; float pdf; v3 d; float dist; int32_t emitter; };     // DirectionSample, records.h:93-195
@@ -1586,3 +1590,178 @@ MI_DEV Splat splat_weights(const DScene &sc, float pos_x, float pos_y) {
     }
     return s;
 }
+
+// -------------------------------------------------------------------------------------------
+// Particle tracer: src/integrators/ptracer.cpp:77-371 (one lane per light sample; AdjointIntegrator::render drives it)
+// -------------------------------------------------------------------------------------------
+MI_DEV v3 xf_point_proj(const float *m, v3 p) {                             // Transform4f * Point3f with the homogeneous divide
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmaf(m[i * 4 + 2], p.z, fmaf(m[i * 4 + 1], p.y, fmaf(m[i * 4 + 0], p.x, m[i * 4 + 3])));
+    float iw = 1.f / r[3];
+    return V3(r[0] * iw, r[1] * iw, r[2] * iw);
+}
+// PerspectiveCamera::sample_direction + importance, perspective.cpp:282-386
+MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, v2 &uv, v3 &ds_p, float &weight) {
+    const float *tw = sc.cam_to_world;
+    v3 rel = p - V3(tw[3], tw[7], tw[11]);                                  // inverse of the rigid camera frame
+    v3 ref_p = V3(tw[0] * rel.x + tw[4] * rel.y + tw[8] * rel.z, tw[1] * rel.x + tw[5] * rel.y + tw[9] * rel.z, tw[2] * rel.x + tw[6] * rel.y + tw[10] * rel.z);
+    if (!(ref_p.z >= sc.near_clip && ref_p.z <= sc.far_clip)) return false;
+    v3 screen = xf_point_proj(sc.camera_to_sample, ref_p);
+    if (!(screen.x >= 0.f && screen.x <= 1.f && screen.y >= 0.f && screen.y <= 1.f)) return false;
+    uv.x = screen.x * (float) sc.crop_w; uv.y = screen.y * (float) sc.crop_h;
+    float dist = norm3(ref_p), inv_dist = 1.f / dist;
+    v3 local_d = ref_p * inv_dist;
+    ds_p = V3(tw[3], tw[7], tw[11]);
+    float ct = local_d.z, inv_ct = 1.f / ct, qx = local_d.x * inv_ct, qy = local_d.y * inv_ct;
+    bool valid = ct > 0.f && qx >= sc.image_rect[0] && qx <= sc.image_rect[2] && qy >= sc.image_rect[1] && qy <= sc.image_rect[3];
+    float importance = valid ? sc.normalization * inv_ct * inv_ct * inv_ct : 0.f;
+    weight = importance * inv_dist * inv_dist;
+    return true;
+}
+// Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229
+template <bool FULL>
+MI_DEV void shape_sample_position(const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
+    if (!FULL || sh.type == MI355_SHAPE_RECTANGLE) {
+        p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f)); n = ld3(sh.frame_n); pdf = sh.inv_area;
+    } else {
+        v3 center = ld3(sh.frame_s); float radius = sh.frame_t[0];
+        float z = fmaf(-2.f, sy, 1.f), r = safe_sqrt_(fmaf(-z, z, 1.f)), ph = 2.f * MI_PI * sx;      // square_to_uniform_sphere, warp.h:250-255
+        v3 local = V3(r * cosf(ph), r * sinf(ph), z);
+        p = fma3s(local, radius, center); n = (sh.flags & DSHAPE_FLIP) ? -local : local; pdf = sh.inv_area;
+    }
+}
+// ImageBlock::put with normalize = true (imageblock.cpp:460-474): per-sample weights divided by their sum; RGB only, the weight
+// channel is never touched (ptracer.cpp:366-368).  Splat positions are scattered over the film: plain float atomics.
+MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, float pos_y, v3 rgb) {
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI_MAX_TAPS; ++i) { sx += i < sp.count ? sp.wx[i] : 0.f; sy += i < sp.count ? sp.wy[i] : 0.f; }
+    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+#pragma unroll
+    for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+            int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+            if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+            float w = sp.wy[ty] * (sp.wx[tx] * factor);
+            float *px = film + ((size_t) y * W + x) * 4;
+            atomicAdd(px, rgb.x * w); atomicAdd(px + 1, rgb.y * w); atomicAdd(px + 2, rgb.z * w);
+        }
+}
+// connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
+template <bool FULL>
+MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bool seen, v2 uv, v3 ds_p, v3 weight, float sample_scale,
+                           float *film, uint32_t *stk) {
+    bool want = seen && (weight.x != 0.f || weight.y != 0.f || weight.z != 0.f);
+    Ray sensor_ray = spawn_ray_to(si.p, si.n, ds_p);
+    if (!want) { sensor_ray.o = sensor_ray.d = V3(0.f, 0.f, 1.f); sensor_ray.maxt = 0.f; }
+    bool occluded = scene_ray_test<FULL>(sc, sensor_ray, want, stk);
+    if (want && !occluded) {
+        v3 local_d = si_to_local(si, sensor_ray.d);
+        v3 surface_weight;
+        if (bsdf == nullptr) { float c = fmaxf(0.f, local_d.z); surface_weight = V3(c, c, c); }       // foreshortening of the emitter
+        else {
+            float wi_dot_geo_n = dot3(si.n, si_to_world(si, si.wi)), wo_dot_geo_n = dot3(si.n, sensor_ray.d);
+            bool valid = wi_dot_geo_n * si.wi.z > 0.f && wo_dot_geo_n * local_d.z > 0.f;
+            float correction = valid ? fabsf((si.wi.z * wo_dot_geo_n) / (local_d.z * wi_dot_geo_n)) : 0.f;
+            v3 refl = bsdf->texture >= 0 ? texture_eval(sc, sc.textures[bsdf->texture], si.uv, nullptr) : ld3(bsdf->reflectance);
+            v3 val; float pdf; bsdf_eval_pdf<FULL>(*bsdf, refl, si.wi, local_d, true, val, pdf);
+            surface_weight = val * correction;
+        }
+        v3 result = (weight * surface_weight) * sample_scale;
+        film_put_normalized(sc, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result);
+    }
+    return want;
+}
+MI_DEV uint32_t pick_emitter(const DScene &sc, float &sample, float &weight) {                      // Scene::sample_emitter, scene.cpp:227-250
+    weight = 1.f;
+    if (sc.n_emitters < 2u) return 0u;
+    float cf = (float) sc.n_emitters, scaled = sample * cf;
+    uint32_t index = min((uint32_t) scaled, sc.n_emitters - 1u);
+    weight = cf; sample = scaled - (float) index;
+    return index;
+}
+MI_DEV SI si_from_position(v3 p, v3 n, int32_t shape) {                     // SurfaceInteraction(PositionSample): frame from the normal
+    SI si; si.t = 0.f; si.p = p; si.n = n; si.sh_n = n; coordinate_system(n, si.sh_s, si.sh_t); si.uv.x = si.uv.y = 0.f;
+    si.wi = V3(0.f, 0.f, 1.f); si.prim = 0; si.shape = shape;
+    return si;
+}
+template <bool FULL>
+MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
+                           float sample_scale, float *film, uint32_t *stk, Counters3 &cnt) {
+    const bool timed = sc.shutter_open_time > 0.f;
+    // ---- sample_visible_emitters, ptracer.cpp:99-171 (wave-uniform condition)
+    if (max_depth != 0 && !hide_emitters) {
+        if (timed) (void) next_1d(rng);
+        float es = next_1d(rng), idx_weight; uint32_t ei = pick_emitter(sc, es, idx_weight);
+        const DEmitter &em = sc.emitters[ei]; const DShape &sh = sc.shapes[em.shape];
+        float sx = next_1d(rng), sy = next_1d(rng);
+        v3 p, n; float pdf; shape_sample_position<FULL>(sh, sx, sy, p, n, pdf);
+        float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
+        SI si = si_from_position(p, n, (int32_t) em.shape);
+        (void) next_1d(rng); (void) next_1d(rng);                           // sensor->sample_direction's (unused) 2D sample
+        v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
+        bool seen = lane_on && sensor_sample_direction(sc, si.p, uv, ds_p, sensor_weight);
+        (void) next_1d(rng);                                                // sample_wavelengths: the radiance itself in RGB mode
+        v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
+        bool cast = connect_sensor<FULL>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk);
+        cnt.shadow += wave_count(cast);
+    }
+    // ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115)
+    if (timed) (void) next_1d(rng);
+    float wav = next_1d(rng), idx_weight; uint32_t ei = pick_emitter(sc, wav, idx_weight);
+    float ax = next_1d(rng), ay = next_1d(rng), bx = next_1d(rng), by = next_1d(rng);
+    const DEmitter &em = sc.emitters[ei]; const DShape &esh = sc.shapes[em.shape];
+    v3 ep, en; float epdf; shape_sample_position<FULL>(esh, ax, ay, ep, en, epdf);
+    SI esi = si_from_position(ep, en, (int32_t) em.shape);
+    Ray ray = spawn_ray(esi.p, esi.n, si_to_world(esi, square_to_cosine_hemisphere(bx, by)));
+    v3 throughput = ld3(em.radiance) * ((epdf > 0.f ? 1.f / epdf : 0.f) * MI_PI * idx_weight);
+    bool active = lane_on && max3(throughput) != 0.f;
+    // ---- trace_light_ray, ptracer.cpp:200-284
+    float eta = 1.f; int32_t depth = 1;
+    Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
+    cnt.isect += wave_count(active);
+    active = active && hit.t != MI_INF;
+    if (max_depth >= 0) active = active && depth < max_depth;
+    while (__any(active)) {
+        cnt.shade += wave_count(active);
+        bool cast = false, next_active = false;
+        Ray next_ray = ray;
+        if (active) {
+            SI si = compute_si<FULL>(sc, ray, hit);
+            const DBsdf &bsdf = sc.bsdfs[sc.shapes[hit.shape].bsdf];
+            (void) next_1d(rng); (void) next_1d(rng);
+            v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
+            bool seen = sensor_sample_direction(sc, si.p, uv, ds_p, sensor_weight);
+            cast = connect_sensor<FULL>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk);
+            float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
+            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
+            BSample bs; v3 bsdf_val; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bs, bsdf_val, true);
+            v3 wo_world = si_to_world(si, bs.wo);
+            float wi_dot_geo_n = dot3(si.n, -ray.d), wo_dot_geo_n = dot3(si.n, wo_world);
+            next_active = wi_dot_geo_n * si.wi.z > 0.f && wo_dot_geo_n * bs.wo.z > 0.f;
+            float correction = fabsf((si.wi.z * wo_dot_geo_n) / (bs.wo.z * wi_dot_geo_n));
+            throughput = throughput * (bsdf_val * correction);
+            eta *= bs.eta;
+            next_active = next_active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
+            next_ray = spawn_ray(si.p, si.n, wo_world);
+        }
+        cnt.shadow += wave_count(cast);
+        active = next_active; ray = next_ray;
+        hit = scene_intersect<FULL>(sc, ray, active, stk);
+        cnt.isect += wave_count(active);
+        depth++;
+        if (max_depth >= 0) active = active && depth < max_depth;
+        active = active && hit.t != MI_INF;
+        if (depth > rr_depth) {                                             // :271-277 (depth is wave-uniform)
+            float q = fminf(max3(throughput) * (eta * eta), 0.95f);
+            bool survive = next_1d(rng) < q;
+            active = active && survive;
+            throughput = throughput * (1.f / q);
+        }
+    }
+}
+

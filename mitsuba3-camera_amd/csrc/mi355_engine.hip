@@ -703,6 +703,28 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
     }
 }
 
+// Particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per light sample; a.n_local lanes of the shard, global
+// lane id = pixel * spp + s over the FILM grid.  Every connection splats normalised filter weights with plain float atomics --
+// the positions are scattered over the film, there is nothing to pre-reduce per wave.
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, unsigned long long *g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool on = i < a.n_local;
+    const uint32_t ii = on ? i : 0u;
+    const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
+    Pcg32 rng; sampler_seed(rng, a.seed, lane);
+    Counters3 cnt = {};
+    ptracer_sample<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt);
+    __syncthreads();
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
 // HDRFilm::develop, hdrfilm.cpp:304-409
 __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1172,8 +1194,18 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
             coff[2] = { (int32_t) se.crop_offset_x, (int32_t) se.crop_offset_y };
     float c2s[16];
-    if (se.type == MI355_SENSOR_PERSPECTIVE)
+    if (se.type == MI355_SENSOR_PERSPECTIVE) {
         host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
+        memcpy(ds.camera_to_sample, c2s, sizeof(ds.camera_to_sample));
+        // m_image_rect / m_normalization, perspective.cpp:190-199: the corners of the sample square on the plane z = 1
+        auto proj = [&](float x, float y, float *o) {
+            float r[4]; for (int i = 0; i < 4; ++i) r[i] = fmaf(ds.sample_to_camera[i * 4 + 1], y, fmaf(ds.sample_to_camera[i * 4 + 0], x, ds.sample_to_camera[i * 4 + 3]));
+            float iw = 1.f / r[3]; o[0] = r[0] * iw; o[1] = r[1] * iw; o[2] = r[2] * iw; };
+        float pmin[3], pmax[3]; proj(0.f, 0.f, pmin); proj(1.f, 1.f, pmax);
+        float ax = pmin[0] / pmin[2], ay = pmin[1] / pmin[2], bx = pmax[0] / pmax[2], by = pmax[1] / pmax[2];
+        ds.image_rect[0] = std::min(ax, bx); ds.image_rect[1] = std::min(ay, by); ds.image_rect[2] = std::max(ax, bx); ds.image_rect[3] = std::max(ay, by);
+        ds.normalization = 1.f / ((ds.image_rect[2] - ds.image_rect[0]) * (ds.image_rect[3] - ds.image_rect[1]));
+    }
     else {
         s->lens.assign(se.lens_data, se.lens_data + MI_LENS_ROW * (size_t) se.lens_count);
         float aspect = (float) se.film_height / (float) se.film_width;       // Film::get_physical_size, film.h:193-198
@@ -1315,7 +1347,8 @@ extern "C" int mi355_scene_param_layout(const mi355_scene *s, mi355_param_info *
 
 static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderArgs *a) {
     if (!s || !p) return fail(MI355_ERR_INVALID, "null argument");
-    uint32_t npix = s->ds.crop_w * s->ds.crop_h;
+    // lanes cover the crop window, except for the particle tracer: the whole film (integrator.cpp:575-577)
+    uint32_t npix = p->integrator == MI355_INTEGRATOR_PTRACER ? s->ds.film_w * s->ds.film_h : s->ds.crop_w * s->ds.crop_h;
     if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
     if ((uint64_t) npix * p->spp > 0xffffffffull)
         return fail(MI355_ERR_INVALID, "W*H*spp exceeds 2^32 lanes; split into passes (integrator.cpp:247-265)");
@@ -1376,6 +1409,17 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
     float *nof = nullptr;
+    if (p->integrator == MI355_INTEGRATOR_PTRACER) {
+        if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "the particle tracer needs a perspective sensor (sample_direction)");
+        if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
+        const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
+        if (full) hipLaunchKernelGGL(k_ptracer<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, s->d_counters);
+        else hipLaunchKernelGGL(k_ptracer<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, s->d_counters);
+        HIP_TRY(hipGetLastError());
+        if ((rc = tm.end())) return rc;
+        s->n_gen += a.n_local;
+        return MI355_OK;
+    }
     // path integrator: re-pack the workgroup's live paths from bounce 2 on, whenever that empties a wave (MODE_FUSED);
     // after every bounce unconditionally (MODE_WAVEFRONT); never (MODE_STATIC)
     // (bit 31 stands for every bounce >= 31 and must stay set: the count exchange is also the loop's exit test when max_depth = -1)

@@ -64,9 +64,9 @@ def shard_tiles(width, height, rank, world, rows=SHARD_TILE_ROWS):
     return (min(rank * tile, npix), count, tile, world * tile)
 
 
-def shard_of(film, rank, world):
+def shard_of(film, rank, world, grid=None):
     """The shard a rank renders: interleaved 16-row tiles when every rank gets at least one, else contiguous bands."""
-    w, h = film.crop_width, film.crop_height
+    w, h = grid if grid is not None else (film.crop_width, film.crop_height)
     if world > 1 and (h + SHARD_TILE_ROWS - 1) // SHARD_TILE_ROWS >= world:
         return shard_tiles(w, h, rank, world)
     return shard_pixels(w * h, rank, world)
@@ -126,6 +126,10 @@ class Integrator:
     def aov_names(self):
         return []
 
+    def lane_grid(self, film):
+        """Pixel grid the lanes are laid over: lane = pixel * spp + s (crop window for sampling integrators)."""
+        return film.crop_width, film.crop_height
+
     # ---- parameter block for the C ABI -----------------------------------------------------------
     def _params(self, scene, seed, spp, shard=None, spp_shard=None):
         f = scene.sensor.film
@@ -135,7 +139,7 @@ class Integrator:
         p.max_depth = self.max_depth; p.rr_depth = self.rr_depth
         p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0) | (abi.FLAG_REGEN if getattr(self, "regen", False) else 0) | (abi.FLAG_TWO_PASS if getattr(self, "two_pass", False) else 0)
         p.mode = self.mode; p.integrator = self.integrator_id
-        npix = f.crop_width * f.crop_height
+        gw, gh = self.lane_grid(f); npix = gw * gh
         if shard is not None:
             p.pixel_begin, p.pixel_count = shard[0], shard[1]
             if len(shard) == 4:
@@ -163,7 +167,7 @@ class Integrator:
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
         band = None
         if shard is not None:
-            band = shard_of(f, shard[0], shard[1])
+            band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f))
         p = self._params(scene, seed, spp, shard=band)
         if band is None or band[1] > 0:
             be.accumulate(scene, p, film)
@@ -242,13 +246,41 @@ class PRBIntegrator(Integrator):
     default_max_depth = 6
 
 
+class ParticleTracerIntegrator(Integrator):
+    """src/integrators/ptracer.cpp under AdjointIntegrator::render (integrator.cpp:545-745): light paths connected to the
+    (perspective) sensor.  Lanes cover the whole FILM (not the crop window); rr_depth default 5, max_depth -1."""
+    integrator_id = abi.INTEGRATOR_PTRACER
+    name = "ptracer"
+    default_max_depth = -1
+
+    def __init__(self, props=None):
+        super().__init__(props)
+        self.samples_per_pass = int((props or {}).get("samples_per_pass", -1))
+
+    def lane_grid(self, film):
+        return film.width, film.height
+
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
+        if scene.sensor.type != abi.SENSOR_PERSPECTIVE:
+            raise PluginError("ptracer: only the perspective sensor implements sample_direction here")
+        spp_res = self._resolve_spp(scene, spp)
+        if self.samples_per_pass not in (-1, 0) and spp_res % min(self.samples_per_pass, spp_res) != 0:
+            raise PluginError("sample_count (%d) must be a multiple of samples_per_pass (%d)." % (spp_res, self.samples_per_pass))
+        return super().render(scene, sensor, seed, spp, develop, evaluate, shard, group)
+
+    def render_backward(self, *a, **k):
+        raise PluginError("ptracer: render_backward (AD through mesh vertices / IORs) is not built")
+
+
 def make_integrator(props):
     t = props.get("type")
     if t == "path":
         return PathIntegrator(props)
     if t == "prb":
         return PRBIntegrator(props)
-    raise PluginError('integrator plugin "%s" is outside the path (path, prb)' % t)
+    if t == "ptracer":
+        return ParticleTracerIntegrator(props)
+    raise PluginError('integrator plugin "%s" is outside the path (path, prb, ptracer)' % t)
 
 
 # ------------------------------------------------------------------------------------------------

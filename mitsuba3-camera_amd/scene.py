@@ -571,7 +571,7 @@ def load_dict(d):
         if key == "type" or not isinstance(v, dict):
             continue
         vt = v.get("type")
-        if vt in ("path", "prb"):
+        if vt in ("path", "prb", "ptracer"):
             scene.integrator_props = dict(v)
         elif vt in ("perspective", "realisticlens"):
             scene.sensor = Sensor(v)
@@ -579,7 +579,7 @@ def load_dict(d):
             named[key] = _make_bsdf(scene, v, key)
         elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere"):
             pending_shapes.append((key, v))
-        elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "ptracer", "aov",
+        elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "aov",
                     "disk", "cylinder", "serialized", "constant", "point", "envmap", "directional",
                     "conductor", "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)

@@ -546,6 +546,57 @@ def test_exit_pupil_sampling_matches_oracle(mi, orc, torch_cuda, design):
     assert float(integ.render(off, seed=1, spp=4).abs().max()) == 0.0
 
 
+# ---- scope row (f)-3, forward part: the particle tracer ----------------------------------------------------------
+@pytest.mark.parametrize("case", ["cbox-box", "cbox-gaussian-crop", "veach", "hide"])
+def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
+    """k_ptracer against the oracle's restatement of ptracer.cpp / AdjointIntegrator::render: same seeds, same lanes (the film
+    is a sum over lanes, so it agrees up to the order of the float atomics), same event counts; shards over the FILM grid add up;
+    the image agrees statistically with the path tracer's (the reference's own methodology for this integrator)."""
+    torch = torch_cuda
+    if case == "veach":
+        scene = mi.load_dict(mi.veach_mis_scene(32)); props = {"max_depth": 5, "rr_depth": 2}; spp = 16
+    else:
+        film = {"rfilter": {"type": "box"}} if case != "cbox-gaussian-crop" else {"crop_offset_x": 5, "crop_offset_y": 3, "crop_width": 20, "crop_height": 24}
+        scene = mi.load_dict(small_cbox(mi, 32, **film)); props = {"max_depth": 6, "rr_depth": 3}; spp = 16
+    integ = mi.ParticleTracerIntegrator(props); integ.hide_emitters = case == "hide"
+    o = orc.OracleScene(scene, mi.abi)
+    integ.counters(scene, reset=True); o.counters(reset=True)
+    film = integ.render(scene, seed=4, spp=spp, develop=False)
+    c = integ.counters(scene, reset=True)
+    ref, lanes = o.ptracer_render(o.params(integ, 4, spp), develop=False)
+    r = o.counters()
+    f = film.cpu().numpy()
+    assert np.isfinite(f).all() and (f[..., 3] == 0).all() and ref[..., :3].max() > 0
+    scale = np.percentile(ref[..., :3], 99)
+    err = np.abs(f - ref)
+    if case == "veach":        # glossy lobes amplify ulp differences (see test_veach_lane_radiance): robust comparison
+        assert np.percentile(err, 99) < 5e-3 * scale and abs(f.sum() - ref.sum()) < 5e-3 * ref.sum()
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert abs(int(c[k]) - r[k]) <= 2e-3 * r[k] + 2, (k, c[k], r[k])
+    else:
+        assert err.max() < 1e-3 * scale + 1e-5, err.max() / scale
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert int(c[k]) == r[k], (k, c[k], r[k])
+    img = integ.render(scene, seed=4, spp=spp).cpu().numpy()
+    assert np.allclose(img, f[..., :3], rtol=1e-4, atol=1e-6)                # W = 0: develop divides by 1 (hdrfilm.cpp:396-400)
+    # shards of the film grid (bands, tiles, spp slices) add up to the whole accumulator
+    h = scene.handle(); lib = mi.abi.lib()
+    fw, fh = scene.sensor.film.width, scene.sensor.film.height
+    for shards in ([mi.shard_pixels(fw * fh, k, 3) for k in range(3)], [mi.shard_tiles(fw, fh, k, 2, rows=4) for k in range(2)]):
+        acc = torch.zeros_like(film)
+        for sh in shards:
+            p = integ._params(scene, 4, spp, shard=sh)
+            mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert torch.allclose(acc, film, rtol=1e-3, atol=1e-3 * float(scale) + 1e-5)
+    if case == "cbox-box":     # light tracing and path tracing estimate the same image
+        path = mi.PathIntegrator(props).render(scene, seed=1, spp=1024).cpu().numpy()
+        pt = integ.render(scene, seed=1, spp=1024).cpu().numpy()
+        assert abs(pt.mean() / path.mean() - 1) < 0.015
+        with pytest.raises(mi.PluginError):
+            integ.render_backward(scene, None, None)
+
+
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
     pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the
