@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--prb-plain", action="store_true", help="A/B: PRB leg without the albedo texture (constant reflectances only)")
+    ap.add_argument("--ptracer", action="store_true", help="extra leg: particle tracer (ptracer) on the Cornell box, 512^2 @ 64 spp, box and gaussian filter")
     ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
     ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
     ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
@@ -254,6 +255,28 @@ def main():
               "finite": bool(torch.isfinite(film4).all().item())}
         sc4.release()
 
+    # ---- optional: particle tracer (forward part) -----------------------------------------------------
+    pt = None
+    if args.ptracer:
+        pt = {}
+        for rf in ("box", "gaussian"):
+            dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
+            dp["sensor"]["film"]["rfilter"] = {"type": rf}
+            scp = mi.load_dict(dp)
+            ip = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 5}); ip.timing = True
+            shard = (rank, world) if world > 1 else None
+            ip.render(scp, seed=0, spp=args.prb_spp, shard=shard); barrier(); ip.counters(scp, reset=True)
+            n_pt = max(2, args.steps // 3)
+            t0 = time.perf_counter()
+            for i in range(n_pt):
+                imgp = ip.render(scp, seed=i, spp=args.prb_spp, shard=shard, evaluate=False)
+            barrier(); dtp = time.perf_counter() - t0
+            kp = ip.counters(scp, reset=True)
+            pt[rf] = {"value": round(npix * args.prb_spp * n_pt / dtp / 1e6, 2), "unit": "Msamples/s (light paths)", "ms_per_step": round(dtp / n_pt * 1e3, 3),
+                      "kernel_ms": round(kp["kernel_ms"] / max(kp["kernel_launches"], 1), 3),
+                      "connections_per_lane": round(kp["n_shadow"] / max(kp["n_gen"], 1), 3), "finite": bool(torch.isfinite(imgp).all().item())}
+            scp.release()
+
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -283,6 +306,8 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4
+        if pt is not None:
+            out["ptracer"] = pt
         print(json.dumps(out), flush=True)
     scene.release()
     if dist is not None:

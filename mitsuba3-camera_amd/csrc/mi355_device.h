@@ -1647,6 +1647,7 @@ MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, floa
             int32_t x = sp.x0 + tx, y = sp.y0 + ty;
             if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
             float w = sp.wy[ty] * (sp.wx[tx] * factor);
+            if (w == 0.f) continue;                                         // (adding 0 changes nothing: skip the memory-side atomics)
             float *px = film + ((size_t) y * W + x) * 4;
             atomicAdd(px, rgb.x * w); atomicAdd(px + 1, rgb.y * w); atomicAdd(px + 2, rgb.z * w);
         }
@@ -1672,7 +1673,8 @@ MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bo
             surface_weight = val * correction;
         }
         v3 result = (weight * surface_weight) * sample_scale;
-        film_put_normalized(sc, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result);
+        if (result.x != 0.f || result.y != 0.f || result.z != 0.f)          // (a black splat changes nothing)
+            film_put_normalized(sc, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result);
     }
     return want;
 }
