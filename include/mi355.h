@@ -57,7 +57,8 @@ enum { MI355_SHAPE_RECTANGLE = 0,   /* src/shapes/rectangle.cpp */
 
 enum { MI355_BSDF_DIFFUSE        = 0,   /* src/bsdfs/diffuse.cpp */
        MI355_BSDF_ROUGHCONDUCTOR = 1,   /* src/bsdfs/roughconductor.cpp */
-       MI355_BSDF_DIELECTRIC     = 2 }; /* src/bsdfs/dielectric.cpp */
+       MI355_BSDF_DIELECTRIC     = 2,   /* src/bsdfs/dielectric.cpp */
+       MI355_BSDF_CONDUCTOR      = 3 }; /* src/bsdfs/conductor.cpp: delta reflection, reflectance * fresnel_conductor(eta, k) */
 
 enum { MI355_EMITTER_AREA = 0 };        /* src/emitters/area.cpp */
 

@@ -41,7 +41,8 @@ struct DShape {                      // 176 B, read through the scalar cache
     uint32_t vtx_offset;             // into positions/normals/texcoords
     int32_t  bvh_root;               // -1: scan the triangles linearly
     float bbox_min[3], bbox_max[3];
-    uint32_t pad[2];
+    uint32_t cdf_offset;             // mesh: into DScene::area_cdf (inclusive prefix sums of the face areas, ORIGINAL face order)
+    uint32_t pad[1];
 };
 struct DTri { float p0[3], e1[3], e2[3]; };               // mesh.h:438: e1 = p1-p0, e2 = p2-p0 precomputed (same arithmetic)
 // Flat, wave-uniform primitive: a parallelogram frame P0 + s*Es + t*Et, stored as the affine map world -> (s, t, h)
@@ -94,6 +95,7 @@ struct DScene {
     const float    *positions;    // 3 per vertex (all meshes concatenated)
     const float    *normals;      // 3 per vertex (zeros when the mesh has none)
     const float    *texcoords;    // 2 per vertex
+    const float    *area_cdf;     // meshes: Mesh::build_pmf table (mesh.cpp:430-470), one float per face
     const DBvhNode *bvh;
     const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
     const DPrimFin *fins;
@@ -805,6 +807,13 @@ MI_DEV void dielectric_sample(const DBsdf &b, v3 wi, float s1, bool active, BSam
     v3 w = selected_r ? ld3(b.reflectance) : (importance ? ld3(b.transmittance) : ld3(b.transmittance) * (eta_ti * eta_ti));
     weight = active ? w : V3(0.f, 0.f, 0.f);
 }
+// SmoothConductor::sample, conductor.cpp:248-307 (unpolarized); eval / pdf are zero (delta lobe)
+MI_DEV void conductor_sample(const DBsdf &b, v3 wi, bool active, BSample &bs, v3 &weight) {
+    active = active && wi.z > 0.f;
+    bs.wo = active ? V3(-wi.x, -wi.y, wi.z) : V3(0.f, 0.f, 0.f); bs.eta = active ? 1.f : 0.f; bs.pdf = active ? 1.f : 0.f; bs.delta = active;
+    v3 F = V3(fresnel_conductor_(wi.z, b.eta[0], b.k[0]), fresnel_conductor_(wi.z, b.eta[1], b.k[1]), fresnel_conductor_(wi.z, b.eta[2], b.k[2]));
+    weight = active ? ld3(b.reflectance) * F : V3(0.f, 0.f, 0.f);
+}
 template <bool FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
     if (!FULL || b.type == MI355_BSDF_DIFFUSE) diffuse_eval_pdf(refl, wi, wo, active, val, pdf);
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
@@ -814,6 +823,7 @@ template <bool FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, flo
                                              bool importance = false) {
     if (!FULL || b.type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2x, s2y, active, bs.wo, bs.pdf, weight); bs.eta = 1.f; bs.delta = false; }
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2x, s2y, active, bs, weight);
+    else if (b.type == MI355_BSDF_CONDUCTOR) conductor_sample(b, wi, active, bs, weight);
     else dielectric_sample(b, wi, s1, active, bs, weight, importance);
 }
 
@@ -822,6 +832,27 @@ struct DS { v3 p, n; float pdf; v3 d; float dist; int32_t emitter; };     // Dir
 // Scene::sample_emitter_direction (scene.cpp:299-353) -> AreaLight::sample_direction (area.cpp:117-168)
 // -> Shape::sample_direction (shape.cpp:358-375) -> Rectangle::sample_position (rectangle.cpp:166-180).
 // The shadow ray is returned to the caller so that fused and wavefront modes can trace it their own way.
+// Mesh::sample_position (mesh.cpp:749-803): face by area (DiscreteDistribution::sample_reuse, distr_1d.h:104-182), then
+// square_to_uniform_triangle (warp.h:153-156)
+MI_DEV void mesh_sample_position(const DScene &sc, const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
+    const float *cdf = sc.area_cdf + sh.cdf_offset;
+    const float sum = cdf[sh.tri_count - 1u], norm = 1.f / sum, target = sy * sum;
+    uint32_t lo = 0, hi = sh.tri_count - 1u;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < target) lo = mid + 1u; else hi = mid; }
+    const uint32_t f = lo;
+    const float c_prev = f > 0u ? cdf[f - 1u] : 0.f;
+    sy = (sy - c_prev * norm) / ((cdf[f] - c_prev) * norm);
+    const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + f);
+    uint32_t i0 = sh.vtx_offset + fi[0], i1 = sh.vtx_offset + fi[1], i2 = sh.vtx_offset + fi[2];
+    v3 p0 = ld3(sc.positions + 3 * (size_t) i0), p1 = ld3(sc.positions + 3 * (size_t) i1), p2 = ld3(sc.positions + 3 * (size_t) i2);
+    v3 e0 = p1 - p0, e1 = p2 - p0;
+    float t = safe_sqrt_(1.f - sx), bx = 1.f - t, by = t * sy;
+    p = fma3s(e0, bx, fma3s(e1, by, p0));
+    v3 n0 = ld3(sc.normals + 3 * (size_t) i0), n1 = ld3(sc.normals + 3 * (size_t) i1), n2 = ld3(sc.normals + 3 * (size_t) i2);
+    v3 nn = (sh.flags & DSHAPE_HAS_NRM) ? fma3s(n0, 1.f - bx - by, fma3s(n1, bx, n2 * by)) : cross3(e0, e1);
+    nn = normalize3(nn);
+    n = (sh.flags & DSHAPE_FLIP) ? -nn : nn; pdf = norm;
+}
 template <bool FULL>
 MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, float sy, bool active, DS &ds, v3 &spec, Ray &shadow) {
     ds.p = ds.n = ds.d = V3(0.f, 0.f, 0.f); ds.pdf = 0.f; ds.dist = 0.f; ds.emitter = -1; spec = V3(0.f, 0.f, 0.f);
@@ -835,9 +866,9 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     const DEmitter &em = sc.emitters[index];
     const DShape &sh = sc.shapes[em.shape];
     ds.emitter = (int32_t) index;
-    if (sh.type == MI355_SHAPE_RECTANGLE) {
-        ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
-        ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
+    if (sh.type == MI355_SHAPE_RECTANGLE || sh.type == MI355_SHAPE_MESH) {   // Shape::sample_direction, shape.cpp:358-375
+        if (sh.type == MI355_SHAPE_MESH) mesh_sample_position(sc, sh, sx, sy, ds.p, ds.n, ds.pdf);
+        else { ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f)); ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area; }
         ds.d = ds.p - si.p;
         float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2);
         ds.d = ds.d * rcp_(ds.dist);
@@ -1138,7 +1169,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
             // ---- emitter sampling (path.cpp:186-208)
             float ex = next_1d(st.rng), ey = next_1d(st.rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;        // BSDFFlags::Smooth, path.cpp:187
+            bool smooth = !FULL || (bsdf.type != MI355_BSDF_DIELECTRIC && bsdf.type != MI355_BSDF_CONDUCTOR);        // BSDFFlags::Smooth, path.cpp:187
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             PROF(cnt, 2);
             // ---- BSDF eval + sample (path.cpp:212-216, bsdf.cpp:22-33)
@@ -1245,7 +1276,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
             // ---- emitter sampling (prb.py:142-162)
             float ex = next_1d(rng), ey = next_1d(rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+            bool smooth = !FULL || (bsdf.type != MI355_BSDF_DIELECTRIC && bsdf.type != MI355_BSDF_CONDUCTOR);
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
             shadow_req = need_shadow;
@@ -1372,7 +1403,7 @@ MI_DEV bool prb_primal_step(const DScene &sc, PathState &st, uint32_t it, uint32
             // ---- emitter sampling (prb.py:142-162)
             float ex = next_1d(st.rng), ey = next_1d(st.rng);
             DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-            bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+            bool smooth = !FULL || (bsdf.type != MI355_BSDF_DIELECTRIC && bsdf.type != MI355_BSDF_CONDUCTOR);
             bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
             bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
             shadow_req = need_shadow;
@@ -1474,7 +1505,7 @@ MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max
         // ---- emitter sampling (prb.py:142-162)
         float ex = next_1d(st.rng), ey = next_1d(st.rng);
         DS ds; v3 em_weight; Ray shadow; shadow.o = shadow.d = V3(0.f, 0.f, 1.f); shadow.maxt = 0.f;
-        bool smooth = !FULL || bsdf.type != MI355_BSDF_DIELECTRIC;
+        bool smooth = !FULL || (bsdf.type != MI355_BSDF_DIELECTRIC && bsdf.type != MI355_BSDF_CONDUCTOR);
         bool need_shadow = sample_emitter_direction<FULL>(sc, si, ex, ey, active_next && smooth, ds, em_weight, shadow);
         bool occluded = scene_ray_test<FULL>(sc, shadow, need_shadow, stk);
         shadow_req = need_shadow;
@@ -1621,7 +1652,8 @@ MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, v2 &uv, v3 &ds_p, fl
 }
 // Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229
 template <bool FULL>
-MI_DEV void shape_sample_position(const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
+MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
+    if (sh.type == MI355_SHAPE_MESH) { mesh_sample_position(sc, sh, sx, sy, p, n, pdf); return; }
     if (!FULL || sh.type == MI355_SHAPE_RECTANGLE) {
         p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f)); n = ld3(sh.frame_n); pdf = sh.inv_area;
     } else {
@@ -1701,7 +1733,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         float es = next_1d(rng), idx_weight; uint32_t ei = pick_emitter(sc, es, idx_weight);
         const DEmitter &em = sc.emitters[ei]; const DShape &sh = sc.shapes[em.shape];
         float sx = next_1d(rng), sy = next_1d(rng);
-        v3 p, n; float pdf; shape_sample_position<FULL>(sh, sx, sy, p, n, pdf);
+        v3 p, n; float pdf; shape_sample_position<FULL>(sc, sh, sx, sy, p, n, pdf);
         float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
         SI si = si_from_position(p, n, (int32_t) em.shape);
         (void) next_1d(rng); (void) next_1d(rng);                           // sensor->sample_direction's (unused) 2D sample
@@ -1717,7 +1749,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
     float wav = next_1d(rng), idx_weight; uint32_t ei = pick_emitter(sc, wav, idx_weight);
     float ax = next_1d(rng), ay = next_1d(rng), bx = next_1d(rng), by = next_1d(rng);
     const DEmitter &em = sc.emitters[ei]; const DShape &esh = sc.shapes[em.shape];
-    v3 ep, en; float epdf; shape_sample_position<FULL>(esh, ax, ay, ep, en, epdf);
+    v3 ep, en; float epdf; shape_sample_position<FULL>(sc, esh, ax, ay, ep, en, epdf);
     SI esi = si_from_position(ep, en, (int32_t) em.shape);
     Ray ray = spawn_ray(esi.p, esi.n, si_to_world(esi, square_to_cosine_hemisphere(bx, by)));
     v3 throughput = ld3(em.radiance) * ((epdf > 0.f ? 1.f / epdf : 0.f) * MI_PI * idx_weight);

@@ -837,14 +837,14 @@ struct mi355_scene {
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil, area_cdf;
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_pupil = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_pupil = nullptr; float *d_area_cdf = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
@@ -1077,7 +1077,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     }
     for (uint32_t i = 0; i < d->n_bsdfs; ++i) {
         const mi355_bsdf_desc &b = d->bsdfs[i];
-        if (b.type != MI355_BSDF_DIFFUSE && b.type != MI355_BSDF_ROUGHCONDUCTOR && b.type != MI355_BSDF_DIELECTRIC)
+        if (b.type != MI355_BSDF_DIFFUSE && b.type != MI355_BSDF_ROUGHCONDUCTOR && b.type != MI355_BSDF_DIELECTRIC && b.type != MI355_BSDF_CONDUCTOR)
             return fail(MI355_ERR_UNSUPPORTED, "bsdf type not supported by this build (diffuse, roughconductor, dielectric)");
         if (b.reflectance_texture >= (int32_t) d->n_textures) return fail(MI355_ERR_INVALID, "bsdf references a missing texture");
         if (b.type != MI355_BSDF_DIFFUSE && b.reflectance_texture >= 0) return fail(MI355_ERR_UNSUPPORTED, "textured specular reflectance is not supported");
@@ -1093,7 +1093,6 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         const mi355_emitter_desc &e = d->emitters[i];
         if (e.type != MI355_EMITTER_AREA) return fail(MI355_ERR_UNSUPPORTED, "emitter type not supported (area only)");
         if (e.shape >= d->n_shapes) return fail(MI355_ERR_INVALID, "emitter references a missing shape");
-        if (d->shapes[e.shape].type == MI355_SHAPE_MESH) return fail(MI355_ERR_UNSUPPORTED, "area emitters must sit on rectangles or spheres in this build");
         DEmitter o; memset(&o, 0, sizeof(o)); o.type = e.type; memcpy(o.radiance, e.radiance, 12); o.shape = e.shape; o.grad_slot = -1;
         s->emitters.push_back(o);
     }
@@ -1125,7 +1124,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             else s->texcoords.insert(s->texcoords.end(), 2 * (size_t) sd.vertex_count, 0.f);
             std::vector<BuildTri> bt(sd.face_count);
             for (int k = 0; k < 3; ++k) { o.bbox_min[k] = INFINITY; o.bbox_max[k] = -INFINITY; }
-            double area = 0;
+            float area = 0.f;                                               // Mesh::build_pmf: float prefix sums, surface area = the last one
+            o.cdf_offset = (uint32_t) s->area_cdf.size();
             for (uint32_t f = 0; f < sd.face_count; ++f) {
                 const uint32_t *fi = sd.faces + 3 * (size_t) f;
                 for (int k = 0; k < 3; ++k) if (fi[k] >= sd.vertex_count) return fail(MI355_ERR_INVALID, "face index out of range");
@@ -1137,10 +1137,11 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
                 }
                 bt[f].face = f;
                 h3 cr = hcross(hsub(H3(b[0], b[1], b[2]), H3(a[0], a[1], a[2])), hsub(H3(c[0], c[1], c[2]), H3(a[0], a[1], a[2])));
-                area += 0.5 * (double) sqrtf(hdot(cr, cr));
+                area += 0.5f * sqrtf(hdot(cr, cr));
+                s->area_cdf.push_back(area);
                 s->faces.push_back(fi[0]); s->faces.push_back(fi[1]); s->faces.push_back(fi[2]);
             }
-            o.inv_area = (float) (1.0 / area);
+            o.inv_area = 1.f / area;
             size_t fins_before = s->fins.size();
             if (try_make_box(s, i, sd)) { }
             else if (sd.face_count <= MI_FLAT_MAX) { s->fins.resize(fins_before); flatten_mesh(s, i, sd); }
@@ -1243,6 +1244,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
     if ((rc = upload(&s->d_lens, s->lens))) return rc;
     ds.lens = s->d_lens;
+    if ((rc = upload(&s->d_area_cdf, s->area_cdf))) return rc;
+    ds.area_cdf = s->d_area_cdf;
     ds.shutter_open_time = se.shutter_open_time; ds.film_diagonal = se.film_diagonal;
     ds.sample_exit_pupil = (se.type == MI355_SENSOR_REALISTICLENS && se.sample_exit_pupil) ? 1u : 0u;
     if (ds.sample_exit_pupil) {                                             // compute_exit_pupil_bounds, realisticlens.cpp:1772-1806
@@ -1298,7 +1301,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;

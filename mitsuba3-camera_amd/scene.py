@@ -119,7 +119,7 @@ class BSDF:
         self.transmittance = np.ones(3, dtype=np.float32)
 
     def flags_smooth(self):
-        return self.type != abi.BSDF_DIELECTRIC
+        return self.type not in (abi.BSDF_DIELECTRIC, abi.BSDF_CONDUCTOR)
 
 
 class Emitter:
@@ -528,6 +528,15 @@ def _make_bsdf(scene, props, id):
         b.eta = _rgb(props.get("eta", 0.0), "roughconductor.eta", False); b.k = _rgb(props.get("k", 1.0), "roughconductor.k", False)
         scene.bsdfs.append(b)
         return b
+    if t == "conductor":                                        # conductor.cpp:222-241
+        if "eta" not in props and props.get("material", "none") != "none":
+            raise PluginError("conductor: named materials need the reference's IOR data files (absent); give eta / k")
+        if "eta" in props and props.get("material", "none") != "none":
+            raise PluginError("Should specify either (eta, k) or material, not both.")
+        b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "conductor.specular_reflectance", True), type=abi.BSDF_CONDUCTOR)
+        b.eta = _rgb(props.get("eta", 0.0), "conductor.eta", False); b.k = _rgb(props.get("k", 1.0), "conductor.k", False)
+        scene.bsdfs.append(b)
+        return b
     if t == "dielectric":
         b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "dielectric.specular_reflectance", True), type=abi.BSDF_DIELECTRIC)
         b.transmittance = _rgb(props.get("specular_transmittance", 1.0), "dielectric.specular_transmittance", True)
@@ -537,7 +546,7 @@ def _make_bsdf(scene, props, id):
         scene.bsdfs.append(b)
         return b
     if t != "diffuse":
-        raise PluginError('bsdf plugin "%s" is outside the path in this build (diffuse, roughconductor, dielectric)' % t)
+        raise PluginError('bsdf plugin "%s" is outside the path in this build (diffuse, roughconductor, conductor, dielectric)' % t)
     refl = props.get("reflectance", 0.5)
     if isinstance(refl, dict) and refl.get("type") == "bitmap":
         if "data" not in refl:
@@ -575,13 +584,13 @@ def load_dict(d):
             scene.integrator_props = dict(v)
         elif vt in ("perspective", "realisticlens"):
             scene.sensor = Sensor(v)
-        elif vt in ("diffuse", "roughconductor", "dielectric"):
+        elif vt in ("diffuse", "roughconductor", "conductor", "dielectric"):
             named[key] = _make_bsdf(scene, v, key)
         elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere"):
             pending_shapes.append((key, v))
         elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "aov",
                     "disk", "cylinder", "serialized", "constant", "point", "envmap", "directional",
-                    "conductor", "plastic", "twosided"):
+                    "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)
         else:
             raise PluginError('Plugin "%s" not found!' % vt)
@@ -631,8 +640,6 @@ def load_dict(d):
         if ep is not None:
             if ep.get("type") != "area":
                 raise PluginError('emitter plugin "%s" is outside the path (area)' % ep.get("type"))
-            if kind == abi.SHAPE_MESH:
-                raise PluginError("area emitters on meshes are outside this build's path (rectangle and sphere emitters)")
             e = Emitter(_rgb(ep.get("radiance", 1.0), "area.radiance", False))
             e.shape = shape; shape.emitter = e
             scene.emitters.append(e)

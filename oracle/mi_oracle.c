@@ -275,6 +275,7 @@ typedef struct {
     v3 center; float radius;                              /* sphere.cpp:158-159 */
     uint32_t vertex_count, face_count;
     float *pos, *nrm, *uv; uint32_t *faces;
+    float *area_cdf;                                      /* Mesh::build_pmf (mesh.cpp:430-470): inclusive float prefix sums of the face areas */
 } OShape;
 typedef struct { uint32_t w, h, c, filter, wrap; float to_uv[6]; float *data; } OTexture;
 typedef struct {
@@ -321,16 +322,18 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
             o->nrm = (float *) dupmem(sd->vertex_normals, 12u * sd->vertex_count);
             o->uv = (float *) dupmem(sd->vertex_texcoords, 8u * sd->vertex_count);
             o->faces = (uint32_t *) dupmem(sd->faces, 12u * sd->face_count);
-            /* Mesh::surface_area: sum of triangle areas (mesh.cpp) */
-            double area = 0;
+            /* Mesh::build_pmf + DiscreteDistribution::compute_cdf (mesh.cpp:430-470, distr_1d.h:218-231): surface area = last CDF entry */
+            o->area_cdf = (float *) malloc(4u * (o->face_count ? o->face_count : 1u));
+            float area = 0.f;
             for (uint32_t f = 0; f < o->face_count; ++f) {
                 const uint32_t *fi = o->faces + 3 * f;
                 v3 p0 = V3(o->pos[3*fi[0]], o->pos[3*fi[0]+1], o->pos[3*fi[0]+2]);
                 v3 p1 = V3(o->pos[3*fi[1]], o->pos[3*fi[1]+1], o->pos[3*fi[1]+2]);
                 v3 p2 = V3(o->pos[3*fi[2]], o->pos[3*fi[2]+1], o->pos[3*fi[2]+2]);
-                area += 0.5 * (double) norm3(cross3(sub3(p1, p0), sub3(p2, p0)));
+                area += 0.5f * norm3(cross3(sub3(p1, p0), sub3(p2, p0)));
+                o->area_cdf[f] = area;
             }
-            o->inv_area = (float) (1.0 / area);
+            o->inv_area = 1.f / area;
         } else if (sd->type == MI355_SHAPE_SPHERE) {
             /* Sphere::update, sphere.cpp:150-172 (uniform positive scale assumed) */
             o->center = xf_point(o->to_world, V3(0.f, 0.f, 0.f));
@@ -805,7 +808,7 @@ ORC_API void orc_microfacet(uint32_t type, float au, float av, int sample_visibl
 
 /* ---- generic BSDF interface: BSDF::eval_pdf / sample (bsdf.h:371-470) dispatched on the plugin type ---- */
 typedef struct { v3 wo; float pdf, eta; int delta; } BSample;
-static int bsdf_is_smooth(const mi355_bsdf_desc *b) { return b->type != MI355_BSDF_DIELECTRIC; }   /* BSDFFlags::Smooth, bsdf.h:96 */
+static int bsdf_is_smooth(const mi355_bsdf_desc *b) { return b->type != MI355_BSDF_DIELECTRIC && b->type != MI355_BSDF_CONDUCTOR; }   /* BSDFFlags::Smooth, bsdf.h:96 */
 /* RoughConductor::eval_pdf, roughconductor.cpp:428-517 */
 static void roughconductor_eval_pdf(const mi355_bsdf_desc *b, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
     *val = V3(0, 0, 0); *pdf = 0.f;
@@ -854,6 +857,15 @@ static void dielectric_sample(const mi355_bsdf_desc *b, v3 wi, float s1, int act
     if (!selected_r && !g_importance_mode) w = scale3(w, eta_ti * eta_ti);   /* radiance scaling (TransportMode::Radiance only), dielectric.cpp:361-366 */
     *weight = active ? w : V3(0, 0, 0);
 }
+/* SmoothConductor::sample, conductor.cpp:248-307 (unpolarized); eval / pdf are zero (delta lobe) */
+static void conductor_sample(const mi355_bsdf_desc *b, v3 wi, int active, BSample *bs, v3 *weight) {
+    active = active && wi.z > 0.f;
+    bs->wo = V3(-wi.x, -wi.y, wi.z); bs->eta = 1.f; bs->pdf = 1.f; bs->delta = 1;         /* reflect(wi), fresnel.h:275-278 */
+    v3 F = V3(fresnel_conductor_(wi.z, b->eta[0], b->k[0]), fresnel_conductor_(wi.z, b->eta[1], b->k[1]), fresnel_conductor_(wi.z, b->eta[2], b->k[2]));
+    v3 sr = V3(b->reflectance[0], b->reflectance[1], b->reflectance[2]);
+    *weight = active ? mul3(sr, F) : V3(0, 0, 0);
+    if (!active) { memset(bs, 0, sizeof(*bs)); }
+}
 static void bsdf_eval_pdf(const mi355_bsdf_desc *b, v3 refl, v3 wi, v3 wo, int active, v3 *val, float *pdf) {
     if (b->type == MI355_BSDF_DIFFUSE) diffuse_eval_pdf(refl, wi, wo, active, val, pdf);
     else if (b->type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
@@ -862,6 +874,7 @@ static void bsdf_eval_pdf(const mi355_bsdf_desc *b, v3 refl, v3 wi, v3 wo, int a
 static void bsdf_sample(const mi355_bsdf_desc *b, v3 refl, v3 wi, float s1, v2 s2, int active, BSample *bs, v3 *weight) {
     if (b->type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2, active, &bs->wo, &bs->pdf, weight); bs->eta = 1.f; bs->delta = 0; }
     else if (b->type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2, active, bs, weight);
+    else if (b->type == MI355_BSDF_CONDUCTOR) conductor_sample(b, wi, active, bs, weight);
     else dielectric_sample(b, wi, s1, active, bs, weight);
 }
 ORC_API void orc_bsdf_eval_pdf(const mi355_bsdf_desc *b, const float *wi, const float *wo, float *val3, float *pdf) {
@@ -873,6 +886,31 @@ ORC_API void orc_bsdf_sample(const mi355_bsdf_desc *b, const float *wi, float s1
     bsdf_sample(b, refl, V3(wi[0], wi[1], wi[2]), s1, q, 1, &bs, &w);
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; pdf_eta_delta3[0] = bs.pdf; pdf_eta_delta3[1] = bs.eta; pdf_eta_delta3[2] = (float) bs.delta;
     w3[0] = w.x; w3[1] = w.y; w3[2] = w.z;
+}
+
+/* Mesh::sample_position (mesh.cpp:749-803): face by area (DiscreteDistribution::sample_reuse, distr_1d.h:104-182: first CDF
+   entry >= sample * sum; the sample is re-stretched over that face), then square_to_uniform_triangle (warp.h:153-156) */
+static void mesh_sample_position(const OShape *sh, v2 sample, v3 *p, v3 *n, float *pdf) {
+    const float sum = sh->area_cdf[sh->face_count - 1], norm = 1.f / sum, target = sample.y * sum;
+    uint32_t lo = 0, hi = sh->face_count - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (sh->area_cdf[mid] < target) lo = mid + 1; else hi = mid; }
+    const uint32_t f = lo;
+    float cdf_prev = f > 0 ? sh->area_cdf[f - 1] * norm : 0.f, pmf = (sh->area_cdf[f] - (f > 0 ? sh->area_cdf[f - 1] : 0.f)) * norm;
+    sample.y = (sample.y - cdf_prev) / pmf;
+    const uint32_t *fi = sh->faces + 3 * f;
+    v3 p0 = V3(sh->pos[3*fi[0]], sh->pos[3*fi[0]+1], sh->pos[3*fi[0]+2]), p1 = V3(sh->pos[3*fi[1]], sh->pos[3*fi[1]+1], sh->pos[3*fi[1]+2]),
+       p2 = V3(sh->pos[3*fi[2]], sh->pos[3*fi[2]+1], sh->pos[3*fi[2]+2]);
+    v3 e0 = sub3(p1, p0), e1 = sub3(p2, p0);
+    float t = safe_sqrt_(1.f - sample.x), bx = 1.f - t, by = t * sample.y;
+    *p = fma3s(e0, bx, fma3s(e1, by, p0));
+    v3 nn;
+    if (sh->nrm) {
+        v3 n0 = V3(sh->nrm[3*fi[0]], sh->nrm[3*fi[0]+1], sh->nrm[3*fi[0]+2]), n1 = V3(sh->nrm[3*fi[1]], sh->nrm[3*fi[1]+1], sh->nrm[3*fi[1]+2]),
+           n2 = V3(sh->nrm[3*fi[2]], sh->nrm[3*fi[2]+1], sh->nrm[3*fi[2]+2]);
+        nn = fma3s(n0, 1.f - bx - by, fma3s(n1, bx, scale3(n2, by)));
+    } else nn = cross3(e0, e1);
+    nn = normalize3(nn);
+    *n = sh->flip_normals ? neg3(nn) : nn; *pdf = norm;
 }
 
 /* PathIntegrator::mis_weight: src/integrators/path.cpp:300-305 */
@@ -895,9 +933,10 @@ static void sample_emitter_direction(OScene *sc, const SI *si, v2 sample, int ac
     const mi355_emitter_desc *em = &sc->emitters[index];
     const OShape *sh = &sc->shapes[em->shape];
     ds->emitter = (int32_t) index;
-    if (sh->type == MI355_SHAPE_RECTANGLE) {
-        ds->p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
-        ds->n = sh->frame_n; ds->pdf = sh->inv_area; ds->uv = sample;
+    if (sh->type == MI355_SHAPE_RECTANGLE || sh->type == MI355_SHAPE_MESH) {          /* Shape::sample_direction, shape.cpp:358-375 */
+        if (sh->type == MI355_SHAPE_MESH) mesh_sample_position(sh, sample, &ds->p, &ds->n, &ds->pdf);
+        else { ds->p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f)); ds->n = sh->frame_n; ds->pdf = sh->inv_area; }
+        ds->uv = sample;
         ds->d = sub3(ds->p, si->p);
         float dist2 = sqnorm3(ds->d); ds->dist = sqrtf(dist2);
         ds->d = scale3(ds->d, rcpf_(ds->dist));
@@ -1443,8 +1482,9 @@ static int sensor_sample_direction(const OScene *sc, v3 p, v2 *uv, v3 *ds_p, v3 
     *weight = importance * inv_dist * inv_dist;
     return 1;
 }
-/* Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229 */
+/* Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229, mesh.cpp:749-803 */
 static void shape_sample_position(const OShape *sh, v2 sample, v3 *p, v3 *n, float *pdf) {
+    if (sh->type == MI355_SHAPE_MESH) { mesh_sample_position(sh, sample, p, n, pdf); return; }
     if (sh->type == MI355_SHAPE_RECTANGLE) {
         *p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f)); *n = sh->frame_n; *pdf = sh->inv_area;
     } else {

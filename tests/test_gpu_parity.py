@@ -546,6 +546,52 @@ def test_exit_pupil_sampling_matches_oracle(mi, orc, torch_cuda, design):
     assert float(integ.render(off, seed=1, spp=4).abs().max()) == 0.0
 
 
+def _fixture_like_cbox(mi, res=32):
+    """The ingredients of the reference's notebooks/scenes/cboxes/cbox_path.xml: mesh luminaire (cbox_luminaire.obj is a
+    quad = 2 triangles carrying the area emitter), mirror sphere (`conductor`, material none), glass sphere (`dielectric`)."""
+    T = mi.ScalarTransform4f
+    d = small_cbox(mi, res)
+    del d["large-box"], d["small-box"]
+    quad = np.array([[0.25, 0.99, -0.25], [0.25, 0.99, 0.25], [-0.25, 0.99, 0.25], [-0.25, 0.99, -0.25]], dtype=np.float32)
+    d["light"] = {"type": "mesh", "vertex_positions": quad, "faces": np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32),
+                  "bsdf": {"type": "ref", "id": "white"}, "emitter": d["light"]["emitter"]}
+    d["mirror"] = {"type": "conductor"}; d["glass"] = {"type": "dielectric"}
+    d["mirrorsphere"] = {"type": "sphere", "to_world": T.translate([-0.3, -0.5, 0.2]).scale(0.5), "bsdf": {"type": "ref", "id": "mirror"}}
+    d["glasssphere"] = {"type": "sphere", "to_world": T.translate([0.5, -0.75, -0.2]).scale(0.25), "bsdf": {"type": "ref", "id": "glass"}}
+    return d
+
+
+@pytest.mark.parametrize("integrator_name", ["path", "prb", "ptracer"])
+def test_mesh_emitter_and_smooth_conductor(mi, orc, torch_cuda, integrator_name):
+    """Mesh::sample_position (mesh.cpp:749-803, area-proportional face choice with sample reuse) as the NEE / light-tracing
+    source, SmoothConductor::sample (conductor.cpp:248-307): lanes (path, prb), film (ptracer) and gradients against the oracle."""
+    torch = torch_cuda
+    scene = mi.load_dict(_fixture_like_cbox(mi))
+    assert scene.info()["features"] & 3 == 3
+    o = orc.OracleScene(scene, mi.abi)
+    integ = mi.make_integrator({"type": integrator_name, "max_depth": 6, "rr_depth": 3})
+    if integrator_name == "ptracer":
+        f = integ.render(scene, seed=2, spp=16, develop=False).cpu().numpy()
+        ref, _ = o.ptracer_render(o.params(integ, 2, 16), develop=False)
+        scale = np.percentile(ref[..., :3], 99)
+        assert np.percentile(np.abs(f - ref), 99.5) < 2e-3 * scale and abs(f.sum() / ref.sum() - 1) < 2e-3
+        return
+    spp, seed, n = 8, 3, 32 * 32 * 8
+    ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
+    got = integ.lane_radiance(scene, seed, spp, 0, n).cpu().numpy()
+    close = np.isclose(got[:, :3], ref[:, :3], rtol=5e-4, atol=1e-5).all(axis=1) & (got[:, 3] == ref[:, 3])
+    assert close.mean() > 0.995, "diverged lanes: %g" % (1 - close.mean())
+    img = integ.render(scene, seed=5, spp=16).cpu().numpy()
+    img_ref, _ = o.render(o.params(integ, 5, 16))
+    err = np.abs(img - img_ref)
+    assert np.percentile(err, 99.5) < 1e-3 * img_ref.max() and abs(img.mean() / img_ref.mean() - 1) < 2e-3
+    params = mi.traverse(scene)
+    gin = np.random.default_rng(4).normal(size=(32, 32, 3)).astype(np.float32)
+    g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
+    g_ref = o.render_backward(o.params(integ, 7, 16), gin)
+    assert np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+
+
 # ---- scope row (f)-3, forward part: the particle tracer ----------------------------------------------------------
 @pytest.mark.parametrize("case", ["cbox-box", "cbox-gaussian-crop", "veach", "hide"])
 def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
