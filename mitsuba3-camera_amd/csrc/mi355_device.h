@@ -1632,12 +1632,44 @@ MI_DEV v3 xf_point_proj(const float *m, v3 p) {                             // T
     float iw = 1.f / r[3];
     return V3(r[0] * iw, r[1] * iw, r[2] * iw);
 }
+// RealisticLensCamera::sample_direction (realisticlens.cpp:2296-2345): a point of the FRONT element is sampled, the ray from the
+// reference point through it is traced world -> film (interfaces in reverse order), the film hit gives the pixel.
+MI_DEV bool lens_sample_direction(const DScene &sc, v3 ref_p, float sx_, float sy_, v2 &uv, v3 &ap_local, float &weight) {
+    const float *Lf = sc.lens + MI_LENS_ROW * (sc.lens_count - 1u);
+    float dkx, dky; disk_concentric(sx_, sy_, dkx, dky);
+    v3 aperture_p = V3(dkx * Lf[2], dky * Lf[2], Lf[3]);
+    v3 dir = ref_p - aperture_p; float dist_ref = norm3(dir), inv_dist_ref = 1.f / dist_ref;
+    dir = dir * inv_dist_ref;
+    v3 o = ref_p, d = -dir;
+    bool ok = true;
+    for (int32_t k = (int32_t) sc.lens_count - 1; k >= 0 && ok; --k) ok = lens_interact(sc.lens + MI_LENS_ROW * k, o, d);
+    if (!ok) return false;
+    float tt = -o.z / d.z; v3 fp = fma3s(d, tt, o);
+    float rsx = (float) sc.crop_w / (float) sc.film_w, rsy = (float) sc.crop_h / (float) sc.film_h;
+    float rox = (float) sc.crop_x / (float) sc.film_w, roy = (float) sc.crop_y / (float) sc.film_h;
+    float sx = ((fp.x / sc.film_px + 1.f) * 0.5f - rox) / rsx, sy = ((fp.y / sc.film_py + 1.f) * 0.5f - roy) / rsy;
+    if (!(sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f)) return false;
+    float normalization = 1.f / ((2.f * sc.film_px * rsx) * (2.f * sc.film_py * rsy));     // 1 / area of the crop window on the film, :2197-2203
+    float ct_film = -d.z, inv_ct = 1.f / ct_film, rear_z = sc.lens[3];
+    float value = normalization * (inv_ct * inv_ct) * (inv_ct * inv_ct) * (rear_z * rear_z);
+    uv.x = sx * (float) sc.crop_w; uv.y = sy * (float) sc.crop_h;
+    ap_local = aperture_p;
+    weight = value * inv_dist_ref * inv_dist_ref * dir.z;
+    return true;
+}
 // PerspectiveCamera::sample_direction + importance, perspective.cpp:282-386
-MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, v2 &uv, v3 &ds_p, float &weight) {
+template <bool FULL>
+MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, float sx_, float sy_, v2 &uv, v3 &ds_p, float &weight) {
     const float *tw = sc.cam_to_world;
     v3 rel = p - V3(tw[3], tw[7], tw[11]);                                  // inverse of the rigid camera frame
     v3 ref_p = V3(tw[0] * rel.x + tw[4] * rel.y + tw[8] * rel.z, tw[1] * rel.x + tw[5] * rel.y + tw[9] * rel.z, tw[2] * rel.x + tw[6] * rel.y + tw[10] * rel.z);
     if (!(ref_p.z >= sc.near_clip && ref_p.z <= sc.far_clip)) return false;
+    if (FULL && sc.sensor_type == MI355_SENSOR_REALISTICLENS) {
+        v3 ap;
+        if (!lens_sample_direction(sc, ref_p, sx_, sy_, uv, ap, weight)) return false;
+        ds_p = xf_point(tw, ap);
+        return true;
+    }
     v3 screen = xf_point_proj(sc.camera_to_sample, ref_p);
     if (!(screen.x >= 0.f && screen.x <= 1.f && screen.y >= 0.f && screen.y <= 1.f)) return false;
     uv.x = screen.x * (float) sc.crop_w; uv.y = screen.y * (float) sc.crop_h;
@@ -1736,9 +1768,9 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         v3 p, n; float pdf; shape_sample_position<FULL>(sc, sh, sx, sy, p, n, pdf);
         float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
         SI si = si_from_position(p, n, (int32_t) em.shape);
-        (void) next_1d(rng); (void) next_1d(rng);                           // sensor->sample_direction's (unused) 2D sample
+        float ssx = next_1d(rng), ssy = next_1d(rng);                       // sensor->sample_direction's 2D sample (front-element point of a lens)
         v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-        bool seen = lane_on && sensor_sample_direction(sc, si.p, uv, ds_p, sensor_weight);
+        bool seen = lane_on && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
         (void) next_1d(rng);                                                // sample_wavelengths: the radiance itself in RGB mode
         v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
         bool cast = connect_sensor<FULL>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk);
@@ -1767,9 +1799,9 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         if (active) {
             SI si = compute_si<FULL>(sc, ray, hit);
             const DBsdf &bsdf = sc.bsdfs[sc.shapes[hit.shape].bsdf];
-            (void) next_1d(rng); (void) next_1d(rng);
+            float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-            bool seen = sensor_sample_direction(sc, si.p, uv, ds_p, sensor_weight);
+            bool seen = sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
             cast = connect_sensor<FULL>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk);
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
             v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);

@@ -1413,7 +1413,6 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     const bool full = (s->ds.features != 0u) != 0;
     float *nof = nullptr;
     if (p->integrator == MI355_INTEGRATOR_PTRACER) {
-        if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "the particle tracer needs a perspective sensor (sample_direction)");
         if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         if (full) hipLaunchKernelGGL(k_ptracer<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, s->d_counters);

@@ -261,8 +261,6 @@ class ParticleTracerIntegrator(Integrator):
         return film.width, film.height
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
-        if scene.sensor.type != abi.SENSOR_PERSPECTIVE:
-            raise PluginError("ptracer: only the perspective sensor implements sample_direction here")
         spp_res = self._resolve_spp(scene, spp)
         if self.samples_per_pass not in (-1, 0) and spp_res % min(self.samples_per_pass, spp_res) != 0:
             raise PluginError("sample_count (%d) must be a multiple of samples_per_pass (%d)." % (spp_res, self.samples_per_pass))

@@ -1459,12 +1459,43 @@ static v3 xf_point_proj(const float *m, v3 p) {                        /* Transf
 }
 /* PerspectiveCamera::sample_direction + importance (perspective.cpp:282-386); image_rect / normalization :190-199.
    Returns 0 when the point is not seen; else uv (pixels, crop-relative), the sensor position, direction, weight. */
-static int sensor_sample_direction(const OScene *sc, v3 p, v2 *uv, v3 *ds_p, v3 *ds_d, float *weight) {
+/* RealisticLensCamera::sample_direction (realisticlens.cpp:2296-2345): a point of the FRONT element is sampled, the ray from the
+   reference point through it is traced world -> film (interfaces in reverse, :2061-2075), the film hit gives the pixel. */
+static int lens_sample_direction(const OScene *sc, v3 ref_p, v2 sample, v2 *uv, v3 *ds_p_local, float *inv_dist, float *weight) {
+    const float *Lf = sc->lens + ORC_LENS_ROW * (sc->lens_count - 1);
+    v2 dk = square_to_uniform_disk_concentric(sample);
+    v3 aperture_p = V3(dk.x * Lf[2], dk.y * Lf[2], Lf[3]);
+    v3 dir = sub3(ref_p, aperture_p); float dist_ref = norm3(dir), inv_dist_ref = 1.f / dist_ref;
+    dir = scale3(dir, inv_dist_ref);
+    v3 o = ref_p, d = neg3(dir);
+    for (int32_t k = (int32_t) sc->lens_count - 1; k >= 0; --k) if (!lens_interact(sc->lens + ORC_LENS_ROW * k, &o, &d)) return 0;
+    float tt = -o.z / d.z; v3 fp = fma3s(d, tt, o);
+    /* m_film_to_sample: physical film -> [0,1]^2 of the crop window (inverse of the mapping in sample_lens_ray) */
+    float rsx = (float) sc->sensor.crop_width / (float) sc->sensor.film_width, rsy = (float) sc->sensor.crop_height / (float) sc->sensor.film_height;
+    float rox = (float) sc->sensor.crop_offset_x / (float) sc->sensor.film_width, roy = (float) sc->sensor.crop_offset_y / (float) sc->sensor.film_height;
+    float sx = ((fp.x / sc->film_px + 1.f) * 0.5f - rox) / rsx, sy = ((fp.y / sc->film_py + 1.f) * 0.5f - roy) / rsy;
+    int valid = sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
+    if (!valid) return 0;
+    float normalization = 1.f / ((2.f * sc->film_px * rsx) * (2.f * sc->film_py * rsy));                  /* 1 / area of the crop window on the film, :2197-2203 */
+    float ct_film = -d.z, inv_ct = 1.f / ct_film, rear_z = sc->lens[3];
+    float value = normalization * (inv_ct * inv_ct) * (inv_ct * inv_ct) * (rear_z * rear_z);
+    uv->x = sx * (float) sc->sensor.crop_width; uv->y = sy * (float) sc->sensor.crop_height;
+    *ds_p_local = aperture_p; *inv_dist = inv_dist_ref;
+    *weight = value * inv_dist_ref * inv_dist_ref * dir.z;                                                  /* ... * ct_ref, :2344 */
+    return 1;
+}
+static int sensor_sample_direction(const OScene *sc, v3 p, v2 sample, v2 *uv, v3 *ds_p, v3 *ds_d, float *weight) {
     const float *tw = sc->sensor.to_world;
     /* inverse of the rigid camera frame (no scale: perspective.cpp:144-145) */
     v3 rel = sub3(p, V3(tw[3], tw[7], tw[11]));
     v3 ref_p = V3(tw[0] * rel.x + tw[4] * rel.y + tw[8] * rel.z, tw[1] * rel.x + tw[5] * rel.y + tw[9] * rel.z, tw[2] * rel.x + tw[6] * rel.y + tw[10] * rel.z);
     if (!(ref_p.z >= sc->sensor.near_clip && ref_p.z <= sc->sensor.far_clip)) return 0;
+    if (sc->sensor.type == MI355_SENSOR_REALISTICLENS) {
+        v3 ap; float inv_dist;
+        if (!lens_sample_direction(sc, ref_p, sample, uv, &ap, &inv_dist, weight)) return 0;
+        *ds_p = xf_point(tw, ap); *ds_d = scale3(sub3(*ds_p, p), inv_dist);
+        return 1;
+    }
     v3 screen = xf_point_proj(sc->camera_to_sample, ref_p);
     if (!(screen.x >= 0.f && screen.x <= 1.f && screen.y >= 0.f && screen.y <= 1.f)) return 0;
     uv->x = screen.x * (float) sc->sensor.crop_width; uv->y = screen.y * (float) sc->sensor.crop_height;
@@ -1542,9 +1573,9 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         v3 p, n; float pdf; shape_sample_position(sh, s2, &p, &n, &pdf);
         float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
         SI si = si_from_position(p, n, (int32_t) em->shape);
-        (void) pcg32_float(&rng); (void) pcg32_float(&rng);                                        /* sensor->sample_direction's (unused) 2D sample */
+        v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);                                 /* sensor->sample_direction's 2D sample (front-element point of a lens) */
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
-        int seen = sensor_sample_direction(sc, si.p, &uv, &ds_p, &ds_d, &sensor_weight);
+        int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
         si.wi = ds_d;
         (void) pcg32_float(&rng);                                                                  /* sample_wavelengths: radiance in RGB mode */
         v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
@@ -1570,9 +1601,9 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
     while (active) {
         cnt->shade++;
         const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
-        (void) pcg32_float(&rng); (void) pcg32_float(&rng);
+        v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
-        int seen = sensor_sample_direction(sc, si.p, &uv, &ds_p, &ds_d, &sensor_weight);
+        int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
         connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt);
         float s1 = pcg32_float(&rng); v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
         v3 refl = bsdf_reflectance(sc, bsdf, &si); BSample bs; v3 bsdf_val;
