@@ -38,7 +38,7 @@ def main(iterations=40, res=128, spp=32, verbose=True):
         opt.step()
         opt[key] = opt[key].detach().clamp(0.0, 1.0)
         params.update(opt)
-        losses.append(float(loss)); errs.append(float((params[key].detach() - target_value).abs().sum()))
+        losses.append(float(loss.detach())); errs.append(float((params[key].detach() - target_value).abs().sum()))
         if verbose and it % 5 == 0:
             print("it %3d  loss %.6f  param error %.4f  value %s" % (it, losses[-1], errs[-1], params[key].detach().cpu().numpy().round(3)))
     return losses, errs

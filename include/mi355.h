@@ -53,14 +53,17 @@ extern "C" {
 /* ---- plugin type tags (names follow the reference's plugin names) -------------------- */
 enum { MI355_SHAPE_RECTANGLE = 0,   /* src/shapes/rectangle.cpp */
        MI355_SHAPE_MESH      = 1,   /* src/render/mesh.cpp (cube/obj/ply all arrive as meshes) */
-       MI355_SHAPE_SPHERE    = 2 }; /* src/shapes/sphere.cpp */
+       MI355_SHAPE_SPHERE    = 2,   /* src/shapes/sphere.cpp */
+       MI355_SHAPE_DISK      = 3 }; /* src/shapes/disk.cpp (unit disk in the xy plane of to_world; flip_normals is folded into to_world) */
 
 enum { MI355_BSDF_DIFFUSE        = 0,   /* src/bsdfs/diffuse.cpp */
        MI355_BSDF_ROUGHCONDUCTOR = 1,   /* src/bsdfs/roughconductor.cpp */
        MI355_BSDF_DIELECTRIC     = 2,   /* src/bsdfs/dielectric.cpp */
        MI355_BSDF_CONDUCTOR      = 3 }; /* src/bsdfs/conductor.cpp: delta reflection, reflectance * fresnel_conductor(eta, k) */
 
-enum { MI355_EMITTER_AREA = 0 };        /* src/emitters/area.cpp */
+enum { MI355_EMITTER_AREA = 0,          /* src/emitters/area.cpp */
+       MI355_EMITTER_DIRECTIONALAREA = 1 }; /* src/emitters/directionalarea.cpp: emits along the surface normal only (collimated beam).
+                                               Invisible to path / prb (eval = 0, sample_direction fails); a light source for ptracer */
 
 enum { MI355_SENSOR_PERSPECTIVE = 0,    /* src/sensors/perspective.cpp */
        MI355_SENSOR_REALISTICLENS = 1 };/* src/sensors/realisticlens.cpp */

@@ -13,9 +13,9 @@ ABI_VERSION = 4
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
-SHAPE_RECTANGLE, SHAPE_MESH, SHAPE_SPHERE = 0, 1, 2
+SHAPE_RECTANGLE, SHAPE_MESH, SHAPE_SPHERE, SHAPE_DISK = 0, 1, 2, 3
 BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_DIELECTRIC, BSDF_CONDUCTOR = 0, 1, 2, 3
-EMITTER_AREA = 0
+EMITTER_AREA, EMITTER_DIRECTIONALAREA = 0, 1
 SENSOR_PERSPECTIVE, SENSOR_REALISTICLENS = 0, 1
 RFILTER_BOX, RFILTER_GAUSSIAN, RFILTER_TENT = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1

@@ -412,6 +412,7 @@ MI_DEV bool sphere_intersect(P sp, const Ray &ray, float tlim, float &t) {
     return found && !no_hit && !out_bounds && !in_bounds;
 }
 
+#define MI_DISK_FIN 0xfffffffeu                                         // DPrim::fin of a disk: the plane test of a rectangle + x^2 + y^2 <= 1
 #define MI_BOX_FLAG 0x40000000u
 #define MI_SPHERE_FLAG 0x20000000u
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
@@ -426,6 +427,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
         bool h = prim_test(prims + k, ray, tlim, t, s, u);
+        if (FULL && prims[k].fin == MI_DISK_FIN) h = h && fmaf(s, s, u * u) <= 1.f;   // Disk::ray_intersect_preliminary_impl, disk.cpp:392-416
         tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
@@ -458,6 +460,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
         } else {
             const DPrim &pr = sc.prims[best];
             hit.shape = pr.shape; fin = pr.fin;
+            if (FULL && fin == MI_DISK_FIN) fin = 0xffffffffu;         // a disk keeps its local (x, y) like a rectangle
         }
         if (fin != 0xffffffffu) {
             const DPrimFin &f = sc.fins[fin];
@@ -490,7 +493,9 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
     MI_UNROLL_PRIMS
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
-        if (prim_test(prims + k, ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; }
+        bool h = prim_test(prims + k, ray, tlim, t, s, u);
+        if (FULL && prims[k].fin == MI_DISK_FIN) h = h && fmaf(s, s, u * u) <= 1.f;   // Disk::ray_test_impl, disk.cpp:418-431
+        if (h) { occluded = true; tlim = 0.f; }
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
         float t;
@@ -520,6 +525,14 @@ MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
         si.p = ray_at(ray, hit.t);
         si.n = ld3(sh.frame_n); si.sh_n = si.n; dp_du = ld3(sh.frame_s); dp_dv = ld3(sh.frame_t);
         si.uv.x = fmaf(hit.u, .5f, .5f); si.uv.y = fmaf(hit.v, .5f, .5f);
+    } else if (FULL && sh.type == MI355_SHAPE_DISK) {                     // Disk::compute_surface_interaction, disk.cpp:436-519
+        si.p = ray_at(ray, hit.t);
+        float r = sqrtf(fmaf(hit.u, hit.u, hit.v * hit.v)), inv_r = 1.f / r;
+        float v = atan2f(hit.v, hit.u) * (0.5f * MI_INV_PI); if (v < 0.f) v += 1.f;
+        si.uv.x = r; si.uv.y = v;
+        float cos_phi = r != 0.f ? hit.u * inv_r : 1.f, sin_phi = r != 0.f ? hit.v * inv_r : 0.f;
+        dp_du = xf_vector(sh.to_world, V3(cos_phi, sin_phi, 0.f)); dp_dv = xf_vector(sh.to_world, V3(-sin_phi, cos_phi, 0.f));
+        si.n = ld3(sh.frame_n); si.sh_n = si.n;
     } else if (FULL && sh.type == MI355_SHAPE_SPHERE) {                   // sphere.cpp:609-712, IsDiff && !FollowShape
         v3 center = ld3(sh.frame_s);
         si.p = ray_at(ray, hit.t);
@@ -866,8 +879,13 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     const DEmitter &em = sc.emitters[index];
     const DShape &sh = sc.shapes[em.shape];
     ds.emitter = (int32_t) index;
-    if (sh.type == MI355_SHAPE_RECTANGLE || sh.type == MI355_SHAPE_MESH) {   // Shape::sample_direction, shape.cpp:358-375
+    if (FULL && em.type != MI355_EMITTER_AREA) return false;               // DirectionalArea::sample_direction fails by design, directionalarea.cpp:126-130
+    if (sh.type == MI355_SHAPE_RECTANGLE || sh.type == MI355_SHAPE_MESH || (FULL && sh.type == MI355_SHAPE_DISK)) {   // Shape::sample_direction, shape.cpp:358-375
         if (sh.type == MI355_SHAPE_MESH) mesh_sample_position(sc, sh, sx, sy, ds.p, ds.n, ds.pdf);
+        else if (FULL && sh.type == MI355_SHAPE_DISK) {                    // Disk::sample_position, disk.cpp:173-191
+            float qx, qy; disk_concentric(sx, sy, qx, qy);
+            ds.p = xf_point(sh.to_world, V3(qx, qy, 0.f)); ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area;
+        }
         else { ds.p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f)); ds.n = ld3(sh.frame_n); ds.pdf = sh.inv_area; }
         ds.d = ds.p - si.p;
         float dist2 = sqnorm3(ds.d); ds.dist = sqrt_(dist2);
@@ -1688,6 +1706,9 @@ MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, 
     if (sh.type == MI355_SHAPE_MESH) { mesh_sample_position(sc, sh, sx, sy, p, n, pdf); return; }
     if (!FULL || sh.type == MI355_SHAPE_RECTANGLE) {
         p = xf_point(sh.to_world, V3(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f)); n = ld3(sh.frame_n); pdf = sh.inv_area;
+    } else if (sh.type == MI355_SHAPE_DISK) {                              // disk.cpp:173-191
+        float qx, qy; disk_concentric(sx, sy, qx, qy);
+        p = xf_point(sh.to_world, V3(qx, qy, 0.f)); n = ld3(sh.frame_n); pdf = sh.inv_area;
     } else {
         v3 center = ld3(sh.frame_s); float radius = sh.frame_t[0];
         float z = fmaf(-2.f, sy, 1.f), r = safe_sqrt_(fmaf(-z, z, 1.f)), ph = 2.f * MI_PI * sx;      // square_to_uniform_sphere, warp.h:250-255
@@ -1764,14 +1785,17 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         if (timed) (void) next_1d(rng);
         float es = next_1d(rng), idx_weight; uint32_t ei = pick_emitter(sc, es, idx_weight);
         const DEmitter &em = sc.emitters[ei]; const DShape &sh = sc.shapes[em.shape];
-        float sx = next_1d(rng), sy = next_1d(rng);
+        // "Don't connect delta emitters with sensor" (ptracer.cpp:114): the MASKED sampler calls of such a lane (next_2d(active),
+        // next_1d(active)) leave its stream where it is -- only the sensor's unmasked next_2d() advances it
+        const bool connect = !FULL || em.type == MI355_EMITTER_AREA;
+        float sx = 0.f, sy = 0.f; if (connect) { sx = next_1d(rng); sy = next_1d(rng); }
         v3 p, n; float pdf; shape_sample_position<FULL>(sc, sh, sx, sy, p, n, pdf);
-        float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
+        float pos_weight = (connect && pdf > 0.f) ? 1.f / pdf : 0.f;
         SI si = si_from_position(p, n, (int32_t) em.shape);
         float ssx = next_1d(rng), ssy = next_1d(rng);                       // sensor->sample_direction's 2D sample (front-element point of a lens)
         v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-        bool seen = lane_on && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
-        (void) next_1d(rng);                                                // sample_wavelengths: the radiance itself in RGB mode
+        bool seen = lane_on && connect && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
+        if (connect) (void) next_1d(rng);                                   // sample_wavelengths: the radiance itself in RGB mode
         v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
         bool cast = connect_sensor<FULL>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk);
         cnt.shadow += wave_count(cast);
@@ -1785,6 +1809,10 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
     SI esi = si_from_position(ep, en, (int32_t) em.shape);
     Ray ray = spawn_ray(esi.p, esi.n, si_to_world(esi, square_to_cosine_hemisphere(bx, by)));
     v3 throughput = ld3(em.radiance) * ((epdf > 0.f ? 1.f / epdf : 0.f) * MI_PI * idx_weight);
+    if (FULL && em.type == MI355_EMITTER_DIRECTIONALAREA) {                 // DirectionalArea::sample_ray, directionalarea.cpp:88-113: along the normal, weight = area * radiance
+        ray = spawn_ray(esi.p, esi.n, esi.n);
+        throughput = ld3(em.radiance) * ((1.f / esh.inv_area) * idx_weight);
+    }
     bool active = lane_on && max3(throughput) != 0.f;
     // ---- trace_light_ray, ptracer.cpp:200-284
     float eta = 1.f; int32_t depth = 1;

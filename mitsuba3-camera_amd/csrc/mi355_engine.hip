@@ -1091,7 +1091,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     }
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         const mi355_emitter_desc &e = d->emitters[i];
-        if (e.type != MI355_EMITTER_AREA) return fail(MI355_ERR_UNSUPPORTED, "emitter type not supported (area only)");
+        if (e.type != MI355_EMITTER_AREA && e.type != MI355_EMITTER_DIRECTIONALAREA) return fail(MI355_ERR_UNSUPPORTED, "emitter type not supported (area, directionalarea)");
+        if (e.type != MI355_EMITTER_AREA) ds.features |= 2u;
         if (e.shape >= d->n_shapes) return fail(MI355_ERR_INVALID, "emitter references a missing shape");
         DEmitter o; memset(&o, 0, sizeof(o)); o.type = e.type; memcpy(o.radiance, e.radiance, 12); o.shape = e.shape; o.grad_slot = -1;
         s->emitters.push_back(o);
@@ -1101,6 +1102,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         if (sd.bsdf >= d->n_bsdfs) return fail(MI355_ERR_INVALID, "shape references a missing bsdf");
         if (sd.emitter >= (int32_t) d->n_emitters) return fail(MI355_ERR_INVALID, "shape references a missing emitter");
         DShape o; memset(&o, 0, sizeof(o)); o.type = sd.type; o.bsdf = sd.bsdf; o.emitter = sd.emitter; o.bvh_root = -1;
+        // DirectionalArea::eval is zero and its pdf_direction is zero (directionalarea.cpp:126-136,165-168): a path that HITS such a shape
+        // sees a plain surface, so the shape record carries no emitter; the emitter table (NEE pick, ptracer) still lists it
+        if (sd.emitter >= 0 && d->emitters[sd.emitter].type == MI355_EMITTER_DIRECTIONALAREA) o.emitter = -1;
         o.flags = sd.flip_normals ? DSHAPE_FLIP : 0u;
         memcpy(o.to_world, sd.to_world, 48); memcpy(o.to_object, sd.to_object, 48);
         if (sd.type == MI355_SHAPE_RECTANGLE) {                             // Rectangle::update, rectangle.cpp:115-126
@@ -1166,7 +1170,20 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             o.inv_area = 1.0f / (4.f * MI_PI * (radius * radius));
             DSphere sp; memset(&sp, 0, sizeof(sp)); sp.center[0] = c.x; sp.center[1] = c.y; sp.center[2] = c.z; sp.radius = radius; sp.shape = i;
             s->spheres.push_back(sp); ds.features |= 2u;
-        } else return fail(MI355_ERR_UNSUPPORTED, "shape type not supported by this build (rectangle, mesh, sphere)");
+        } else if (sd.type == MI355_SHAPE_DISK) {                           // Disk::update, disk.cpp:113-127; surface_area :163-167
+            h3 du = hxf_vector(o.to_world, H3(1.f, 0.f, 0.f)), dv = hxf_vector(o.to_world, H3(0.f, 1.f, 0.f));
+            float lu = sqrtf(hdot(du, du)), lv = sqrtf(hdot(dv, dv));
+            if (!(lu > 0.f) || !(lv > 0.f)) return fail(MI355_ERR_INVALID, "disk transform is singular");
+            h3 fs = hscale(du, 1.f / lu), ft = hscale(dv, 1.f / lv);
+            h3 n = hxf_normal(o.to_object, H3(0.f, 0.f, 1.f)); n = hscale(n, 1.0f / sqrtf(hdot(n, n)));
+            o.frame_s[0] = fs.x; o.frame_s[1] = fs.y; o.frame_s[2] = fs.z; o.frame_t[0] = ft.x; o.frame_t[1] = ft.y; o.frame_t[2] = ft.z;
+            o.frame_n[0] = n.x; o.frame_n[1] = n.y; o.frame_n[2] = n.z;
+            float dd = hdot(hscale(ft, lv), fs), hgt = sqrtf(lv * lv - dd * dd);
+            o.inv_area = 1.0f / (MI_PI * lu * hgt);
+            DPrim pr; memset(&pr, 0, sizeof(pr)); memcpy(pr.m, o.to_object, 48);   // disk.cpp:392-416: the rectangle's plane test + x^2 + y^2 <= 1
+            pr.lo = -1.f; pr.smax = 2.f; pr.shape = i; pr.fin = MI_DISK_FIN;
+            s->prims.push_back(pr); ds.features |= 2u;
+        } else return fail(MI355_ERR_UNSUPPORTED, "shape type not supported by this build (rectangle, mesh, sphere, disk)");
         s->shapes.push_back(o);
     }
     // gradient layout: constant reflectances, textures, emitter radiances (mi355_scene_param_layout)

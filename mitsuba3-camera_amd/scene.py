@@ -148,11 +148,15 @@ class Shape:
             return float(np.linalg.norm(np.cross(s, t)))
         if self.type == abi.SHAPE_SPHERE:         # sphere.cpp:197-199
             return float(4 * math.pi * np.linalg.norm(self.to_world.transform_vector([1, 0, 0])) ** 2)
+        if self.type == abi.SHAPE_DISK:           # disk.cpp:163-167: pi * |dp_du| * height of the ellipse
+            du = self.to_world.transform_vector([1, 0, 0]); dv = self.to_world.transform_vector([0, 1, 0])
+            lu, lv = np.linalg.norm(du), np.linalg.norm(dv)
+            return float(math.pi * lu * math.sqrt(max(lv * lv - float(np.dot(dv, du / lu)) ** 2, 0.0)))
         p = self.vertex_positions; f = self.faces
         return float(0.5 * np.linalg.norm(np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]]), axis=1).sum())
 
     def bbox(self):
-        if self.type == abi.SHAPE_RECTANGLE:      # rectangle.cpp:128-138
+        if self.type in (abi.SHAPE_RECTANGLE, abi.SHAPE_DISK):      # rectangle.cpp:128-138 (a disk's box is bounded by its square)
             c = np.array([self.to_world.transform_affine(q) for q in ([-1, -1, 0], [-1, 1, 0], [1, -1, 0], [1, 1, 0])])
         elif self.type == abi.SHAPE_SPHERE:       # sphere.cpp:190-195
             ce = self.to_world.transform_affine([0, 0, 0]); r = np.linalg.norm(self.to_world.transform_vector([1, 0, 0]))
@@ -537,6 +541,20 @@ def _make_bsdf(scene, props, id):
         b.eta = _rgb(props.get("eta", 0.0), "conductor.eta", False); b.k = _rgb(props.get("k", 1.0), "conductor.k", False)
         scene.bsdfs.append(b)
         return b
+    if t == "dispersive":       # dispersive_dielectric.cpp: in RGB variants both media use their Cauchy IOR at 589.3 nm (:411-432)
+        def eval_ior(ior_d, v_d, wl=np.float32(0.5893)):
+            ior_d, v_d = np.float32(ior_d), np.float32(v_d)
+            inv = lambda x: np.float32(1) / np.float32(x)
+            b_ = (ior_d - np.float32(1)) * inv(v_d * (inv(np.float32(0.48613) ** 2) - inv(np.float32(0.65627) ** 2))) if v_d > np.float32(5.96e-8) else np.float32(0)
+            a_ = ior_d - b_ * inv(np.float32(0.5893) ** 2)
+            return np.float32(a_ + b_ * inv(wl * wl))
+        b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "dispersive.specular_reflectance", True), type=abi.BSDF_DIELECTRIC)
+        b.transmittance = _rgb(props.get("specular_transmittance", 1.0), "dispersive.specular_transmittance", True)
+        # eta = eval_ior(int) * rcp(eval_ior(ext))  (:250): handed over as int_ior / 1
+        b.int_ior = float(eval_ior(props.get("int_ior", 1.5046), props.get("int_V_d", 64.17)) * (np.float32(1) / eval_ior(props.get("ext_ior", 1.0), props.get("ext_V_d", 0.0))))
+        b.ext_ior = 1.0
+        scene.bsdfs.append(b)
+        return b
     if t == "dielectric":
         b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "dielectric.specular_reflectance", True), type=abi.BSDF_DIELECTRIC)
         b.transmittance = _rgb(props.get("specular_transmittance", 1.0), "dielectric.specular_transmittance", True)
@@ -584,12 +602,12 @@ def load_dict(d):
             scene.integrator_props = dict(v)
         elif vt in ("perspective", "realisticlens"):
             scene.sensor = Sensor(v)
-        elif vt in ("diffuse", "roughconductor", "conductor", "dielectric"):
+        elif vt in ("diffuse", "roughconductor", "conductor", "dielectric", "dispersive"):
             named[key] = _make_bsdf(scene, v, key)
-        elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere"):
+        elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere", "disk"):
             pending_shapes.append((key, v))
         elif vt in ("thinlens", "orthographic", "radialwarp", "volpath", "direct", "aov",
-                    "disk", "cylinder", "serialized", "constant", "point", "envmap", "directional",
+                    "cylinder", "serialized", "constant", "point", "envmap", "directional",
                     "plastic", "twosided"):
             raise PluginError('plugin "%s" is outside the hot path this engine replaces' % vt)
         else:
@@ -611,7 +629,9 @@ def load_dict(d):
             bsdf = named[bp["id"]]
         else:
             bsdf = _make_bsdf(scene, bp, key + ".bsdf")
-        kind = abi.SHAPE_RECTANGLE if vt == "rectangle" else (abi.SHAPE_SPHERE if vt == "sphere" else abi.SHAPE_MESH)
+        kind = {"rectangle": abi.SHAPE_RECTANGLE, "sphere": abi.SHAPE_SPHERE, "disk": abi.SHAPE_DISK}.get(vt, abi.SHAPE_MESH)
+        if vt == "disk" and v.get("flip_normals", False):      # disk.cpp:98-101: folded into to_world
+            tw = tw @ ScalarTransform4f.scale([1.0, 1.0, -1.0])
         if vt == "sphere":      # sphere.cpp:131-146: to_world * translate(center) * scale(radius)
             tw = tw @ ScalarTransform4f.translate(v.get("center", [0, 0, 0])) @ ScalarTransform4f.scale(float(v.get("radius", 1.0)))
         shape = Shape(key, kind, tw, bsdf, flip_normals=bool(v.get("flip_normals", False)))
@@ -638,9 +658,10 @@ def load_dict(d):
             shape.faces = np.ascontiguousarray(np.asarray(v["faces"], dtype=np.uint32).reshape(-1, 3))
         ep = v.get("emitter")
         if ep is not None:
-            if ep.get("type") != "area":
-                raise PluginError('emitter plugin "%s" is outside the path (area)' % ep.get("type"))
+            if ep.get("type") not in ("area", "directionalarea"):
+                raise PluginError('emitter plugin "%s" is outside the path (area, directionalarea)' % ep.get("type"))
             e = Emitter(_rgb(ep.get("radiance", 1.0), "area.radiance", False))
+            e.type = abi.EMITTER_AREA if ep.get("type") == "area" else abi.EMITTER_DIRECTIONALAREA
             e.shape = shape; shape.emitter = e
             scene.emitters.append(e)
         scene.shapes.append(shape)

@@ -310,7 +310,15 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
         const mi355_shape_desc *sd = &d->shapes[i]; OShape *o = &s->shapes[i];
         o->type = sd->type; o->bsdf = sd->bsdf; o->emitter = sd->emitter; o->flip_normals = sd->flip_normals;
         memcpy(o->to_world, sd->to_world, 48); memcpy(o->to_object, sd->to_object, 48);
-        if (sd->type == MI355_SHAPE_RECTANGLE) {
+        if (sd->type == MI355_SHAPE_DISK) {
+            /* Disk::update, disk.cpp:113-127; surface_area :163-167 */
+            v3 du = xf_vector(o->to_world, V3(1.f, 0.f, 0.f)), dv = xf_vector(o->to_world, V3(0.f, 1.f, 0.f));
+            float lu = norm3(du), lv = norm3(dv);
+            o->frame_s = scale3(du, 1.f / lu); o->frame_t = scale3(dv, 1.f / lv);
+            o->frame_n = normalize3(xf_normal(o->to_object, V3(0.f, 0.f, 1.f)));
+            float dd = dot3(scale3(o->frame_t, lv), o->frame_s), hgt = sqrtf(lv * lv - dd * dd);
+            o->inv_area = rcpf_(ORC_PI * lu * hgt);
+        } else if (sd->type == MI355_SHAPE_RECTANGLE) {
             /* Rectangle::update, rectangle.cpp:115-126 */
             o->frame_s = xf_vector(o->to_world, V3(2.f, 0.f, 0.f));
             o->frame_t = xf_vector(o->to_world, V3(0.f, 2.f, 0.f));
@@ -404,6 +412,15 @@ static inline int rect_intersect(const OShape *sh, const Ray *ray, float *t_out,
     *t_out = t; uv_out->x = local.x; uv_out->y = local.y;
     return hit;
 }
+/* Disk::ray_intersect_preliminary_impl / ray_test_impl: src/shapes/disk.cpp:392-431 */
+static inline int disk_intersect(const OShape *sh, const Ray *ray, float *t_out, v2 *uv_out) {
+    v3 o = xf_point(sh->to_object, ray->o), d = xf_vector(sh->to_object, ray->d);
+    float t = -o.z / d.z;
+    v3 local = fma3s(d, t, o);
+    int hit = t >= 0.f && t <= ray->maxt && local.x * local.x + local.y * local.y <= 1.f;
+    *t_out = t; uv_out->x = local.x; uv_out->y = local.y;
+    return hit;
+}
 static inline v3 mesh_vertex(const OShape *sh, uint32_t i) { return V3(sh->pos[3*i], sh->pos[3*i+1], sh->pos[3*i+2]); }
 /* Mesh::moeller_trumbore: include/mitsuba/render/mesh.h:430-453 */
 static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
@@ -469,9 +486,9 @@ static PI scene_intersect(OScene *sc, const Ray *ray_in) {
     Ray ray = *ray_in; PI pi; pi.t = INFINITY; pi.prim_uv.x = pi.prim_uv.y = 0; pi.prim_index = 0; pi.shape_index = 0xffffffffu;
     for (uint32_t i = 0; i < sc->n_shapes; ++i) {
         const OShape *sh = &sc->shapes[i];
-        if (sh->type == MI355_SHAPE_RECTANGLE) {
+        if (sh->type == MI355_SHAPE_RECTANGLE || sh->type == MI355_SHAPE_DISK) {
             float t; v2 uv;
-            if (rect_intersect(sh, &ray, &t, &uv) && t < pi.t) { pi.t = t; pi.prim_uv = uv; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
+            if ((sh->type == MI355_SHAPE_DISK ? disk_intersect(sh, &ray, &t, &uv) : rect_intersect(sh, &ray, &t, &uv)) && t < pi.t) { pi.t = t; pi.prim_uv = uv; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
         } else if (sh->type == MI355_SHAPE_SPHERE) {
             float t;
             if (sphere_intersect(sh, &ray, &t) && t < pi.t) { pi.t = t; pi.prim_uv.x = pi.prim_uv.y = 0.f; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
@@ -491,6 +508,7 @@ static int scene_ray_test(OScene *sc, const Ray *ray) {
     for (uint32_t i = 0; i < sc->n_shapes; ++i) {
         const OShape *sh = &sc->shapes[i]; float t; v2 uv;
         if (sh->type == MI355_SHAPE_RECTANGLE) { if (rect_intersect(sh, ray, &t, &uv)) return 1; }
+        else if (sh->type == MI355_SHAPE_DISK) { if (disk_intersect(sh, ray, &t, &uv)) return 1; }
         else if (sh->type == MI355_SHAPE_SPHERE) { if (sphere_test(sh, ray)) return 1; }
         else for (uint32_t f = 0; f < sh->face_count; ++f) {
             const uint32_t *fi = sh->faces + 3 * f;
@@ -509,7 +527,16 @@ static SI compute_si(const OScene *sc, const Ray *ray, const PI *pi) {
     if (!(pi->t != INFINITY)) { si.wi = neg3(ray->d); return si; }
     const OShape *sh = &sc->shapes[pi->shape_index];
     si.t = pi->t; si.shape = (int32_t) pi->shape_index; si.prim_index = pi->prim_index;
-    if (sh->type == MI355_SHAPE_RECTANGLE) {
+    if (sh->type == MI355_SHAPE_DISK) {
+        /* Disk::compute_surface_interaction, disk.cpp:436-519 (IsDiff && !FollowShape: si.p = ray(t)) */
+        si.p = ray_at(ray, pi->t);
+        float px = pi->prim_uv.x, py = pi->prim_uv.y, r = sqrtf(px * px + py * py), inv_r = 1.f / r;
+        float v = atan2f(py, px) * (0.5f * ORC_INV_PI); if (v < 0.f) v += 1.f;
+        si.uv.x = r; si.uv.y = v;
+        float cos_phi = r != 0.f ? px * inv_r : 1.f, sin_phi = r != 0.f ? py * inv_r : 0.f;
+        si.dp_du = xf_vector(sh->to_world, V3(cos_phi, sin_phi, 0.f)); si.dp_dv = xf_vector(sh->to_world, V3(-sin_phi, cos_phi, 0.f));
+        si.n = sh->frame_n; si.sh_n = sh->frame_n;
+    } else if (sh->type == MI355_SHAPE_RECTANGLE) {
         si.p = ray_at(ray, pi->t);
         si.n = sh->frame_n; si.sh_n = sh->frame_n; si.dp_du = sh->frame_s; si.dp_dv = sh->frame_t;
         si.uv.x = fmaf(pi->prim_uv.x, .5f, .5f); si.uv.y = fmaf(pi->prim_uv.y, .5f, .5f);
@@ -933,8 +960,10 @@ static void sample_emitter_direction(OScene *sc, const SI *si, v2 sample, int ac
     const mi355_emitter_desc *em = &sc->emitters[index];
     const OShape *sh = &sc->shapes[em->shape];
     ds->emitter = (int32_t) index;
-    if (sh->type == MI355_SHAPE_RECTANGLE || sh->type == MI355_SHAPE_MESH) {          /* Shape::sample_direction, shape.cpp:358-375 */
+    if (em->type == MI355_EMITTER_DIRECTIONALAREA) { ds->pdf = 0.f; return; }        /* DirectionalArea::sample_direction fails by design, directionalarea.cpp:126-130 */
+    if (sh->type == MI355_SHAPE_RECTANGLE || sh->type == MI355_SHAPE_MESH || sh->type == MI355_SHAPE_DISK) {   /* Shape::sample_direction, shape.cpp:358-375 */
         if (sh->type == MI355_SHAPE_MESH) mesh_sample_position(sh, sample, &ds->p, &ds->n, &ds->pdf);
+        else if (sh->type == MI355_SHAPE_DISK) { v2 q = square_to_uniform_disk_concentric(sample); ds->p = xf_point(sh->to_world, V3(q.x, q.y, 0.f)); ds->n = sh->frame_n; ds->pdf = sh->inv_area; }
         else { ds->p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f)); ds->n = sh->frame_n; ds->pdf = sh->inv_area; }
         ds->uv = sample;
         ds->d = sub3(ds->p, si->p);
@@ -992,6 +1021,7 @@ static float pdf_emitter_direction(const OScene *sc, int32_t emitter, v3 ref_p, 
     const OShape *sh = &sc->shapes[sc->emitters[emitter].shape];
     float dp = dot3(d, n);
     if (!(dp < 0.f)) return 0.f;
+    if (sc->emitters[emitter].type == MI355_EMITTER_DIRECTIONALAREA) return 0.f;     /* directionalarea.cpp:132-136 */
     float adp = fabsf(dp), pdf;
     if (sh->type == MI355_SHAPE_SPHERE) {                               /* Sphere::pdf_direction, sphere.cpp:313-325 */
         float sin_alpha = sh->radius * rcpf_(norm3(sub3(sh->center, ref_p))), cos_alpha = safe_sqrt_(1.f - sin_alpha * sin_alpha);
@@ -1231,7 +1261,7 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
             if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(sc, emitter, prev_p, d, si.sh_n, dist);
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
             const float *r = sc->emitters[emitter].radiance;
-            v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);   /* area.cpp:83-90 */
+            v3 le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f && sc->emitters[emitter].type == MI355_EMITTER_AREA) ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);   /* area.cpp:83-90; DirectionalArea::eval = 0 */
             result = fma3(throughput, scale3(le, mis_bsdf), result);
         }
         int active_next = (depth + 1 < max_depth) && si_valid;          /* path.cpp:177 */
@@ -1297,7 +1327,7 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
             float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(sc, emitter, prev_p, d, si.sh_n, dist);
             le_mis = mis_weight(prev_bsdf_pdf, em_pdf);
             const float *r = sc->emitters[emitter].radiance;
-            le_front = si.wi.z > 0.f && active_next;
+            le_front = si.wi.z > 0.f && active_next && sc->emitters[emitter].type == MI355_EMITTER_AREA;   /* DirectionalArea::eval = 0 */
             v3 e = le_front ? V3(r[0], r[1], r[2]) : V3(0, 0, 0);
             Le = mul3(scale3(beta, le_mis), e);
         }
@@ -1516,6 +1546,10 @@ static int sensor_sample_direction(const OScene *sc, v3 p, v2 sample, v2 *uv, v3
 /* Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229, mesh.cpp:749-803 */
 static void shape_sample_position(const OShape *sh, v2 sample, v3 *p, v3 *n, float *pdf) {
     if (sh->type == MI355_SHAPE_MESH) { mesh_sample_position(sh, sample, p, n, pdf); return; }
+    if (sh->type == MI355_SHAPE_DISK) {                                 /* disk.cpp:173-191 */
+        v2 q = square_to_uniform_disk_concentric(sample);
+        *p = xf_point(sh->to_world, V3(q.x, q.y, 0.f)); *n = sh->frame_n; *pdf = sh->inv_area; return;
+    }
     if (sh->type == MI355_SHAPE_RECTANGLE) {
         *p = xf_point(sh->to_world, V3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f)); *n = sh->frame_n; *pdf = sh->inv_area;
     } else {
@@ -1569,15 +1603,18 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         if (timed) (void) pcg32_float(&rng);
         float es = pcg32_float(&rng), idx_weight; uint32_t ei = pick_emitter(sc, &es, &idx_weight);
         const mi355_emitter_desc *em = &sc->emitters[ei]; const OShape *sh = &sc->shapes[em->shape];
-        v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
+        /* "Don't connect delta emitters with sensor" (:114): for such a lane the MASKED sampler calls below (next_2d(active),
+           next_1d(active)) leave its stream where it is -- only the sensor's unmasked next_2d() advances it */
+        const int connect = em->type != MI355_EMITTER_DIRECTIONALAREA;
+        v2 s2 = { 0.f, 0.f }; if (connect) { s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng); }
         v3 p, n; float pdf; shape_sample_position(sh, s2, &p, &n, &pdf);
-        float pos_weight = pdf > 0.f ? 1.f / pdf : 0.f;
+        float pos_weight = (connect && pdf > 0.f) ? 1.f / pdf : 0.f;
         SI si = si_from_position(p, n, (int32_t) em->shape);
         v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);                                 /* sensor->sample_direction's 2D sample (front-element point of a lens) */
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
-        int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
+        int seen = connect && sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
         si.wi = ds_d;
-        (void) pcg32_float(&rng);                                                                  /* sample_wavelengths: radiance in RGB mode */
+        if (connect) (void) pcg32_float(&rng);                                                     /* sample_wavelengths: radiance in RGB mode */
         v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
         v3 weight = scale3(rad, idx_weight * pos_weight * sensor_weight);
         connect_sensor(sc, &si, NULL, seen, uv, ds_p, weight, sample_scale, film_rgbw, cnt);
@@ -1592,6 +1629,10 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
     v3 local = square_to_cosine_hemisphere(sb);
     Ray ray = spawn_ray(esi.p, esi.n, si_to_world(&esi, local));
     v3 throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (epdf > 0.f ? 1.f / epdf : 0.f) * ORC_PI * idx_weight);
+    if (em->type == MI355_EMITTER_DIRECTIONALAREA) {                    /* DirectionalArea::sample_ray, directionalarea.cpp:88-113: along the normal, weight = area * radiance */
+        ray = spawn_ray(esi.p, esi.n, esi.n);
+        throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (1.f / esh->inv_area) * idx_weight);
+    }
     int active = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) != 0.f;
     /* ---- trace_light_ray, ptracer.cpp:200-284 */
     float eta = 1.f; int32_t depth = 1;

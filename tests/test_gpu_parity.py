@@ -647,6 +647,73 @@ def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
             integ.render_backward(scene, None, None)
 
 
+def _beam_scene(mi, res=32):
+    """The ingredients of the reference's lens-design notebook scene (notebooks/: a collimated `directionalarea` beam leaving a
+    `disk`, a `dispersive` glass element, a diffuse screen), light-traced onto a perspective film."""
+    T = mi.ScalarTransform4f
+    return {"type": "scene",
+            "sensor": {"type": "perspective", "fov": 40.0, "to_world": T.look_at([0, 0.6, 3.2], [0, 0, 0], [0, 1, 0]),
+                       "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "box"}}},
+            "glass": {"type": "dispersive", "cauchy_a": 1.5046, "cauchy_b": 0.0042},
+            "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}},
+            "beam": {"type": "disk", "to_world": T.translate([-1.5, 0, 0]) @ T.rotate([0, 1, 0], 90.0) @ T.scale(0.35),
+                     "bsdf": {"type": "ref", "id": "white"},
+                     "emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": [6.0, 5.0, 4.0]}}},
+            "lens": {"type": "sphere", "to_world": T.translate([-0.4, 0, 0]) @ T.scale(0.5), "bsdf": {"type": "ref", "id": "glass"}},
+            "screen": {"type": "rectangle", "to_world": T.translate([1.2, 0, 0]) @ T.rotate([0, 1, 0], -90.0) @ T.scale(1.2),
+                       "bsdf": {"type": "ref", "id": "white"}},
+            "floor": {"type": "disk", "to_world": T.translate([0, -0.6, 0]) @ T.rotate([1, 0, 0], -90.0) @ T.scale((2.0, 1.5, 1.0)),
+                      "bsdf": {"type": "ref", "id": "white"}}}
+
+
+@pytest.mark.parametrize("case", ["beam-ptracer", "beam-path", "disk-light"])
+def test_disk_and_directional_area(mi, orc, torch_cuda, case):
+    """Disk (disk.cpp:392-519, :173-191) as an intersected surface, as a sampled area light and as the source of a
+    `directionalarea` beam (directionalarea.cpp:88-136: sample_ray along the normal with weight area * radiance, never connected,
+    eval = 0), plus the `dispersive` material at its nominal wavelength."""
+    torch = torch_cuda
+    d = _beam_scene(mi)
+    if case == "disk-light":       # a plain area light on the disk, no collimation: path / prb / gradients see it
+        d["beam"]["emitter"] = {"type": "area", "radiance": {"type": "rgb", "value": [6.0, 5.0, 4.0]}}
+    scene = mi.load_dict(d)
+    o = orc.OracleScene(scene, mi.abi)
+    rays = _rays_for(scene, o, n=8192, seed=5)
+    got, ref = _gpu_intersect(mi, torch, scene, rays), o.ray_intersect(rays)
+    hg, hr = orc.unpack_hits(got), orc.unpack_hits(ref)
+    same = (hg["shape"] == hr["shape"]) & (hg["occluded"] == hr["occluded"])
+    assert same.mean() > 0.999 and np.allclose(hg["t"][same & np.isfinite(hr["t"])], hr["t"][same & np.isfinite(hr["t"])], rtol=5e-5, atol=5e-6)
+    assert (hr["shape"][np.isfinite(hr["t"])] == 0).any() and (hr["shape"][np.isfinite(hr["t"])] == 3).any()   # both disks are seen
+    if case == "beam-ptracer":
+        integ = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 4})
+        integ.counters(scene, reset=True); o.counters(reset=True)
+        f = integ.render(scene, seed=3, spp=64, develop=False).cpu().numpy()
+        c = integ.counters(scene, reset=True)
+        ref, _ = o.ptracer_render(o.params(integ, 3, 64), develop=False)
+        r = o.counters()
+        scale = np.percentile(ref[..., :3], 99.5)
+        assert ref[..., :3].max() > 0 and np.isfinite(f).all()
+        assert np.percentile(np.abs(f - ref), 99.5) < 5e-3 * scale and abs(f.sum() / ref.sum() - 1) < 5e-3
+        for k in ("n_isect", "n_shade", "n_shadow"):
+            assert abs(int(c[k]) - r[k]) <= 2e-3 * r[k] + 2, (k, c[k], r[k])
+        return
+    for name in ("path", "prb"):
+        integ = mi.make_integrator({"type": name, "max_depth": 6, "rr_depth": 3})
+        spp, seed, n = 8, 3, 32 * 32 * 8
+        ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
+        got = integ.lane_radiance(scene, seed, spp, 0, n).cpu().numpy()
+        close = np.isclose(got[:, :3], ref[:, :3], rtol=5e-4, atol=1e-5).all(axis=1) & (got[:, 3] == ref[:, 3])
+        assert close.mean() > 0.995, "diverged lanes: %g" % (1 - close.mean())
+        if case == "beam-path":    # a collimated emitter is invisible to unidirectional path tracing (no NEE, eval = 0)
+            assert (ref[:, :3] == 0).all() and (got[:, :3] == 0).all()
+    if case == "disk-light":
+        assert ref[:, :3].max() > 0
+        params = mi.traverse(scene)
+        gin = np.random.default_rng(4).normal(size=(32, 32, 3)).astype(np.float32)
+        g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
+        g_ref = o.render_backward(o.params(integ, 7, 16), gin)
+        assert np.abs(g_ref).max() > 0 and np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+
+
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
     pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the

@@ -494,6 +494,43 @@ def test_sphere_shape(orc, mi):
         assert (si[ok, 6] >= 0).all() and (si[ok, 6] <= 1).all() and (si[ok, 7] >= 0).all() and (si[ok, 7] <= 1).all()
 
 
+def test_disk_shape(orc, mi):
+    """The reference's own checks for the disk (src/shapes/tests/test_disk.py): test01 area = pi, test02 area / bbox under scale and
+    translation, test03 ray_test on a grid <=> x^2 + y^2 <= r^2 with the tangents agreeing with finite differences of si.p, test05's
+    uv = (r, phi / 2pi) at (0.9999999, 0)."""
+    T = mi.ScalarTransform4f
+    sc, o = _shape_scene(mi, orc, {"type": "disk"})
+    assert sc.shapes[0].primitive_count() == 1
+    assert np.isclose(o.surface_area(0), np.pi) and np.isclose(sc.shapes[0].surface_area(), np.pi)
+    for sx in [1, 2, 4]:
+        for tr in ([1.3, -3.0, 5], [-10000, 3.0, 31]):
+            sc, o = _shape_scene(mi, orc, {"type": "disk", "to_world": T.translate(tr) @ T.scale((sx, 2.5, 1.0))})
+            assert np.isclose(o.surface_area(0), sx * 2.5 * np.pi, rtol=1e-5) and np.isclose(sc.shapes[0].surface_area(), sx * 2.5 * np.pi, rtol=1e-5)
+            lo, hi = sc.shapes[0].bbox()
+            assert np.allclose(lo, np.array(tr) - [sx, 2.5, 0]) and np.allclose(hi, np.array(tr) + [sx, 2.5, 0])
+    for r in (1, 3, 5):
+        for tr in ([0.0, 0.0, 0.0], [1.0, -5.0, 0.0]):
+            sc, o = _shape_scene(mi, orc, {"type": "disk", "to_world": T.translate(tr) @ T.scale((r, r, 1.0))})
+            g = np.linspace(-1, 1, 10)
+            X, Y = np.meshgrid(1.1 * r * (g - tr[0]), 1.1 * r * (g - tr[1]))
+            rays = np.zeros((100, 8), dtype=np.float32)
+            rays[:, 0] = X.ravel(); rays[:, 1] = Y.ravel(); rays[:, 2] = -10; rays[:, 5] = 1; rays[:, 6] = np.finfo(np.float32).max
+            hits, si = o.ray_intersect(rays, with_si=True)
+            h = orc.unpack_hits(hits)
+            inside = (rays[:, 0] - tr[0]) ** 2 + (rays[:, 1] - tr[1]) ** 2 <= r * r
+            assert np.array_equal(h["occluded"].astype(bool), inside) and np.array_equal(np.isfinite(h["t"]), inside)
+            assert np.allclose(h["t"][inside], 10.0) and np.allclose(si[inside, 3:6], [0, 0, 1])
+            rad = np.hypot(rays[inside, 0] - tr[0], rays[inside, 1] - tr[1]) / r
+            assert np.allclose(si[inside, 6], rad, atol=1e-5) and (si[inside, 7] >= 0).all() and (si[inside, 7] <= 1).all()
+    sc, o = _shape_scene(mi, orc, {"type": "disk"})
+    rays = np.array([[0.9999999, 0.0, -10.0, 0, 0, 1, np.finfo(np.float32).max, 0]], dtype=np.float32)
+    hits, si = o.ray_intersect(rays, with_si=True)
+    assert np.allclose(si[0, 6:8], [0.9999999, 0.0], atol=1e-6)
+    # flip_normals is folded into the transform (disk.cpp:97-103)
+    d = mi.load_dict({"type": "disk", "flip_normals": True})
+    assert np.allclose(d.to_world.matrix[:3, 2], [0, 0, -1])
+
+
 # ---- scope row (f)-1: realistic lens camera --------------------------------------------------------------------
 def test_lens_materials(mi):
     """The reference's only pins for the fork-specific lens code: inline asserts of realisticlens.cpp:2444-2461."""
