@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 4u
+#define MI355_ABI_VERSION 5u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -166,6 +166,9 @@ typedef struct mi355_scene_desc {
                                           (path regeneration).  Same samples, same film; opt-in because on the Cornell box it
                                           measured 11.3 ms against 10.8 ms for the static assignment */
 
+#define MI355_FLAG_EMITTER_GRADS_ONLY 16u /* render_backward with MI355_INTEGRATOR_PTRACER: the caller acknowledges that only the
+                                          MI355_PARAM_EMITTER_RADIANCE slots are written; without it that call is MI355_ERR_UNSUPPORTED */
+
 enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path state in registers; the path integrator re-packs the
                                           live paths of a workgroup (wave ballot + prefix sum, SoA state exchanged through LDS) from
                                           bounce 2 on whenever that empties a whole wave */
@@ -198,6 +201,12 @@ typedef struct mi355_render_params {
        (rank r of G with tiles of T pixels: pixel_begin = r*T, pixel_tile = T, pixel_tile_stride = G*T).
        pixel_tile == 0: the contiguous range above. */
     uint32_t pixel_tile, pixel_tile_stride;
+    /* Passes of the JIT render loops (`samples_per_pass`, integrator.cpp:565-573 and :700-726): the sampler is seeded ONCE for a
+       wavefront of  pixels * spp / passes  streams and every stream draws `passes` consecutive samples, so the stream grid is
+       spp / passes  per pixel (global stream id = pixel * (spp / passes) + s; spp_begin / spp_count then count streams).
+       0 or 1 = one pass.  Honoured by MI355_INTEGRATOR_PTRACER (whose reference test fixture renders in 4 passes); the path / prb
+       integrators reject passes > 1 (MI355_ERR_UNSUPPORTED). */
+    uint32_t passes;
 } mi355_render_params;
 
 /* Per-event device counters behind the algorithmic-byte formula of SURVEY.md 8(d). */
@@ -270,7 +279,11 @@ int mi355_prb_splat_weights(mi355_scene *scene, const mi355_render_params *p,
 /* Steps 1b-3 (common.py:741-796, prb.py:59-257): deltaL = adjoint of splat/develop from
    d_grad_in (crop_h x crop_w x 3) and d_weight; primal replay; adjoint replay with the same
    RNG streams; parameter gradients are ACCUMULATED into d_grad_params (layout:
-   mi355_scene_param_layout).  Multi-GPU jobs all-reduce d_grad_params afterwards. */
+   mi355_scene_param_layout).  Multi-GPU jobs all-reduce d_grad_params afterwards.
+   MI355_INTEGRATOR_PTRACER (Integrator::render_backward, integrator.cpp:65-84, over ptracer.cpp; pinned by the hard-coded gradient
+   of test_ptracer.py:204-225): the light paths are replayed, every sensor connection gathers d_grad_in at its splat taps, and the
+   EMITTER RADIANCE slots alone are accumulated (requires MI355_FLAG_EMITTER_GRADS_ONLY; d_weight is unused and may be NULL: the
+   normalised splat has no weight channel).  Reflectance / texture / geometry gradients of light paths are not built. */
 int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
                           const float *d_grad_in, const float *d_weight,
                           float *d_grad_params, void *stream);

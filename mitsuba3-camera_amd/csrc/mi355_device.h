@@ -1737,10 +1737,49 @@ MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, floa
             atomicAdd(px, rgb.x * w); atomicAdd(px + 1, rgb.y * w); atomicAdd(px + 2, rgb.z * w);
         }
 }
+// Adjoint of the normalised splat: the film is linear in the splatted colour, so dL/d(colour) = sum over taps of w * dL/dfilm.
+MI_DEV v3 film_gather_normalized(const DScene &sc, const float *grad_rgb, float pos_x, float pos_y) {
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI_MAX_TAPS; ++i) { sx += i < sp.count ? sp.wx[i] : 0.f; sy += i < sp.count ? sp.wy[i] : 0.f; }
+    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    v3 g = V3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+            int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+            if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+            float w = sp.wy[ty] * (sp.wx[tx] * factor);
+            const float *px = grad_rgb + ((size_t) y * W + x) * 3;
+            g.x = fmaf(px[0], w, g.x); g.y = fmaf(px[1], w, g.y); g.z = fmaf(px[2], w, g.z);
+        }
+    return g;
+}
+// Gradient mode of the particle tracer (Integrator::render_backward, integrator.cpp:65-84, over ptracer.cpp) for the emitter
+// radiances: every splat is  radiance_c * unit_c  with unit_c free of the radiance, so the gradient is  sum unit_c * gather_c.
+// Accumulators: MI_PT_COPIES bank-spread copies per (emitter, channel) in LDS for the first MI_PT_EM_LDS emitters (the lanes of a wave
+// mostly add to the SAME emitter), global atomics for the rest.
+#define MI_PT_EM_LDS 16u
+#define MI_PT_COPIES 32u
+struct PtGradSink { const float *grad_rgb; float *s_acc; float *d_grad; const uint32_t *small_map; };
+MI_DEV void pt_grad_add(const DScene &sc, const PtGradSink &sink, uint32_t emitter, v3 g) {
+    const int32_t slot = sc.emitters[emitter].grad_slot;
+    if (slot < 0) return;
+    if (emitter < MI_PT_EM_LDS) {
+        float *a = sink.s_acc + emitter * 3u * MI_PT_COPIES + (threadIdx.x & (MI_PT_COPIES - 1u));
+        atomicAdd(a, g.x); atomicAdd(a + MI_PT_COPIES, g.y); atomicAdd(a + 2u * MI_PT_COPIES, g.z);
+    } else {
+        atomicAdd(sink.d_grad + sink.small_map[slot], g.x); atomicAdd(sink.d_grad + sink.small_map[slot + 1], g.y); atomicAdd(sink.d_grad + sink.small_map[slot + 2], g.z);
+    }
+}
 // connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
-template <bool FULL>
+// GRAD: `weight_unit` = weight / radiance of `emitter`; nothing is splatted, the gathered image adjoint goes to the sink.
+template <bool FULL, bool GRAD = false>
 MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bool seen, v2 uv, v3 ds_p, v3 weight, float sample_scale,
-                           float *film, uint32_t *stk) {
+                           float *film, uint32_t *stk, v3 weight_unit = V3(0.f, 0.f, 0.f), uint32_t emitter = 0u, const PtGradSink *sink = nullptr) {
     bool want = seen && (weight.x != 0.f || weight.y != 0.f || weight.z != 0.f);
     Ray sensor_ray = spawn_ray_to(si.p, si.n, ds_p);
     if (!want) { sensor_ray.o = sensor_ray.d = V3(0.f, 0.f, 1.f); sensor_ray.maxt = 0.f; }
@@ -1757,9 +1796,15 @@ MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bo
             v3 val; float pdf; bsdf_eval_pdf<FULL>(*bsdf, refl, si.wi, local_d, true, val, pdf);
             surface_weight = val * correction;
         }
+        if (GRAD) {
+            v3 ru = (weight_unit * surface_weight) * sample_scale;
+            if (ru.x != 0.f || ru.y != 0.f || ru.z != 0.f)
+                pt_grad_add(sc, *sink, emitter, ru * film_gather_normalized(sc, sink->grad_rgb, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y));
+        } else {
         v3 result = (weight * surface_weight) * sample_scale;
         if (result.x != 0.f || result.y != 0.f || result.z != 0.f)          // (a black splat changes nothing)
             film_put_normalized(sc, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result);
+        }
     }
     return want;
 }
@@ -1776,9 +1821,9 @@ MI_DEV SI si_from_position(v3 p, v3 n, int32_t shape) {                     // S
     si.wi = V3(0.f, 0.f, 1.f); si.prim = 0; si.shape = shape;
     return si;
 }
-template <bool FULL>
+template <bool FULL, bool GRAD = false>
 MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                           float sample_scale, float *film, uint32_t *stk, Counters3 &cnt) {
+                           float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr) {
     const bool timed = sc.shutter_open_time > 0.f;
     // ---- sample_visible_emitters, ptracer.cpp:99-171 (wave-uniform condition)
     if (max_depth != 0 && !hide_emitters) {
@@ -1788,6 +1833,9 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         // "Don't connect delta emitters with sensor" (ptracer.cpp:114): the MASKED sampler calls of such a lane (next_2d(active),
         // next_1d(active)) leave its stream where it is -- only the sensor's unmasked next_2d() advances it
         const bool connect = !FULL || em.type == MI355_EMITTER_AREA;
+        // 3.a (:121-141): in the JIT variants `dr::any_or<true>(active_e)` holds whatever the mask, so the infinite-emitter branch runs
+        // and its `sampler->next_2d(active)` consumes two numbers of every connectable lane (pinned by test_ptracer.py:225's value)
+        if (connect) { (void) next_1d(rng); (void) next_1d(rng); }
         float sx = 0.f, sy = 0.f; if (connect) { sx = next_1d(rng); sy = next_1d(rng); }
         v3 p, n; float pdf; shape_sample_position<FULL>(sc, sh, sx, sy, p, n, pdf);
         float pos_weight = (connect && pdf > 0.f) ? 1.f / pdf : 0.f;
@@ -1797,7 +1845,8 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         bool seen = lane_on && connect && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
         if (connect) (void) next_1d(rng);                                   // sample_wavelengths: the radiance itself in RGB mode
         v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
-        bool cast = connect_sensor<FULL>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk);
+        const float wu = idx_weight * pos_weight * sensor_weight;
+        bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk, V3(wu, wu, wu), ei, sink);
         cnt.shadow += wave_count(cast);
     }
     // ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115)
@@ -1809,6 +1858,9 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
     SI esi = si_from_position(ep, en, (int32_t) em.shape);
     Ray ray = spawn_ray(esi.p, esi.n, si_to_world(esi, square_to_cosine_hemisphere(bx, by)));
     v3 throughput = ld3(em.radiance) * ((epdf > 0.f ? 1.f / epdf : 0.f) * MI_PI * idx_weight);
+    float tu0 = (epdf > 0.f ? 1.f / epdf : 0.f) * MI_PI * idx_weight;        // throughput / radiance (gradient mode)
+    if (FULL && em.type == MI355_EMITTER_DIRECTIONALAREA) tu0 = (1.f / esh.inv_area) * idx_weight;
+    v3 tu = V3(tu0, tu0, tu0);
     if (FULL && em.type == MI355_EMITTER_DIRECTIONALAREA) {                 // DirectionalArea::sample_ray, directionalarea.cpp:88-113: along the normal, weight = area * radiance
         ray = spawn_ray(esi.p, esi.n, esi.n);
         throughput = ld3(em.radiance) * ((1.f / esh.inv_area) * idx_weight);
@@ -1830,7 +1882,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
             bool seen = sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
-            cast = connect_sensor<FULL>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk);
+            cast = connect_sensor<FULL, GRAD>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink);
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
             v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
             BSample bs; v3 bsdf_val; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bs, bsdf_val, true);
@@ -1838,7 +1890,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             float wi_dot_geo_n = dot3(si.n, -ray.d), wo_dot_geo_n = dot3(si.n, wo_world);
             next_active = wi_dot_geo_n * si.wi.z > 0.f && wo_dot_geo_n * bs.wo.z > 0.f;
             float correction = fabsf((si.wi.z * wo_dot_geo_n) / (bs.wo.z * wi_dot_geo_n));
-            throughput = throughput * (bsdf_val * correction);
+            throughput = throughput * (bsdf_val * correction); if (GRAD) tu = tu * (bsdf_val * correction);
             eta *= bs.eta;
             next_active = next_active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
             next_ray = spawn_ray(si.p, si.n, wo_world);
@@ -1852,9 +1904,8 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         active = active && hit.t != MI_INF;
         if (depth > rr_depth) {                                             // :271-277 (depth is wave-uniform)
             float q = fminf(max3(throughput) * (eta * eta), 0.95f);
-            bool survive = next_1d(rng) < q;
-            active = active && survive;
-            throughput = throughput * (1.f / q);
+            if (active) active = next_1d(rng) < q;                          // next_1d(active): a masked-out lane keeps its stream (matters for passes > 1)
+            throughput = throughput * (1.f / q); if (GRAD) tu = tu * (1.f / q);   // q detached (path.cpp:272 does so; ptracer.cpp:277 does not -- DESIGN.md)
         }
     }
 }

@@ -61,6 +61,7 @@ struct RenderArgs {
     uint32_t ppw;              // k_render_regen: shard pixels per wave
     uint32_t compact_mask;     // k_render_compact: bit `it` set = re-pack the workgroup's live paths after bounce `it`
     uint32_t compact_adaptive; // ... but only when that empties at least one wave
+    uint32_t passes;           // k_ptracer: consecutive samples per sampler stream (mi355_render_params::passes)
 };
 // q-th pixel of the shard -> global pixel index (mi355_render_params::pixel_tile)
 MI_DEV uint32_t shard_pixel(const RenderArgs &a, uint32_t q) {
@@ -706,11 +707,17 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 // Particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per light sample; a.n_local lanes of the shard, global
 // lane id = pixel * spp + s over the FILM grid.  Every connection splats normalised filter weights with plain float atomics --
 // the positions are scattered over the film, there is nothing to pre-reduce per wave.
-template <bool FULL>
-__global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, unsigned long long *g_counters) {
+// GRAD (render_backward for the emitter radiances): the same lanes, but every connection GATHERS dL/dimage at its splat taps and adds
+// unit-radiance value x gathered adjoint to the emitter's accumulator (LDS copies, one global atomic per workgroup and channel).
+template <bool FULL, bool GRAD>
+__global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
+                                                                 const uint32_t *small_map, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
     __shared__ uint32_t s_cnt[4];
+    __shared__ float s_acc[GRAD ? MI_PT_EM_LDS * 3u * MI_PT_COPIES : 1u];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (GRAD) for (uint32_t k = threadIdx.x; k < MI_PT_EM_LDS * 3u * MI_PT_COPIES; k += BLOCK) s_acc[k] = 0.f;
+    const PtGradSink sink = { grad_rgb, s_acc, d_grad, small_map };
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
@@ -720,8 +727,18 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     Counters3 cnt = {};
-    ptracer_sample<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt);
+    for (uint32_t pass = 0; pass < a.passes; ++pass)                       // one stream, `passes` samples (integrator.cpp:719-727)
+        ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt, &sink);
     __syncthreads();
+    if (GRAD) {
+        const uint32_t n = min(sc.n_emitters, MI_PT_EM_LDS) * 3u;
+        for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
+            float v = 0.f;
+            for (uint32_t c = 0; c < MI_PT_COPIES; ++c) v += s_acc[k * MI_PT_COPIES + c];
+            const int32_t slot = sc.emitters[k / 3u].grad_slot;
+            if (slot >= 0 && v != 0.f) atomicAdd(d_grad + small_map[slot + k % 3u], v);
+        }
+    }
     flush_counters(s_cnt, cnt, g_counters);
 }
 
@@ -1370,13 +1387,19 @@ static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderA
     // lanes cover the crop window, except for the particle tracer: the whole film (integrator.cpp:575-577)
     uint32_t npix = p->integrator == MI355_INTEGRATOR_PTRACER ? s->ds.film_w * s->ds.film_h : s->ds.crop_w * s->ds.crop_h;
     if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
-    if ((uint64_t) npix * p->spp > 0xffffffffull)
+    // samples_per_pass (integrator.cpp:565-573, :700-726): spp / passes sampler streams per pixel, `passes` samples from each
+    const uint32_t passes = p->passes ? p->passes : 1u;
+    if (passes > 1u && p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_UNSUPPORTED, "passes > 1 (samples_per_pass) is built for the particle tracer only");
+    if (p->spp % passes) return fail(MI355_ERR_INVALID, "spp must be a multiple of passes");
+    const uint32_t streams = p->spp / passes;
+    if ((uint64_t) npix * streams > 0xffffffffull)
         return fail(MI355_ERR_INVALID, "W*H*spp exceeds 2^32 lanes; split into passes (integrator.cpp:247-265)");
-    a->seed = p->seed; a->spp_total = p->spp; a->max_depth = (uint32_t) p->max_depth; a->rr_depth = (uint32_t) p->rr_depth; a->flags = p->flags;
+    a->passes = passes;
+    a->seed = p->seed; a->spp_total = streams; a->max_depth = (uint32_t) p->max_depth; a->rr_depth = (uint32_t) p->rr_depth; a->flags = p->flags;
     a->pixel_begin = p->pixel_begin; a->pixel_count = p->pixel_count ? p->pixel_count : npix - p->pixel_begin;
-    a->s_begin = p->spp_begin; a->s_count = p->spp_count ? p->spp_count : p->spp - p->spp_begin;
+    a->s_begin = p->spp_begin; a->s_count = p->spp_count ? p->spp_count : streams - p->spp_begin;
     if (p->pixel_begin > npix || a->pixel_count > npix - p->pixel_begin) return fail(MI355_ERR_INVALID, "pixel shard out of range");
-    if (p->spp_begin > p->spp || a->s_count > p->spp - p->spp_begin) return fail(MI355_ERR_INVALID, "spp shard out of range");
+    if (p->spp_begin > streams || a->s_count > streams - p->spp_begin) return fail(MI355_ERR_INVALID, "spp shard out of range");
     a->tile = p->pixel_tile; a->tile_stride = p->pixel_tile_stride;
     if (a->tile != 0u && a->pixel_count != 0u) {
         if (a->tile_stride < a->tile) return fail(MI355_ERR_INVALID, "pixel_tile_stride must be >= pixel_tile");
@@ -1432,8 +1455,8 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     if (p->integrator == MI355_INTEGRATOR_PTRACER) {
         if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
-        if (full) hipLaunchKernelGGL(k_ptracer<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, s->d_counters);
-        else hipLaunchKernelGGL(k_ptracer<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, s->d_counters);
+        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters);
+        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters);
         HIP_TRY(hipGetLastError());
         if ((rc = tm.end())) return rc;
         s->n_gen += a.n_local;
@@ -1494,12 +1517,24 @@ extern "C" int mi355_prb_splat_weights(mi355_scene *s, const mi355_render_params
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,
                                      float *d_grad_params, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
-    if (!d_grad_in || !d_weight || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
+    const bool pt = p->integrator == MI355_INTEGRATOR_PTRACER;
+    if (!d_grad_in || (!d_weight && !pt) || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
+    if (pt && !(p->flags & MI355_FLAG_EMITTER_GRADS_ONLY))
+        return fail(MI355_ERR_UNSUPPORTED, "ptracer render_backward is built for the emitter radiances only: pass MI355_FLAG_EMITTER_GRADS_ONLY to acknowledge that no other slot is written");
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
+    if (pt) {                                                               // Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp, radiances only
+        if (s->emitters.empty()) return MI355_OK;
+        const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
+        const dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
+        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters);
+        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters);
+        HIP_TRY(hipGetLastError());
+        return tm.end();
+    }
     uint32_t npix = s->ds.crop_w * s->ds.crop_h;
     hipLaunchKernelGGL(k_prepare_grad, dim3((npix + 255) / 256), dim3(256), 0, st, d_grad_in, d_weight, s->d_gw, npix);
     const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);

@@ -117,6 +117,7 @@ class Integrator:
         if self.rr_depth <= 0:
             raise PluginError('"rr_depth" must be set to a value greater than zero!')
         self.hide_emitters = bool(props.get("hide_emitters", False))
+        self.samples_per_pass = int(props.get("samples_per_pass", -1))
         self.mode = abi.MODE_FUSED
         self.timing = False
         self.backend = HipBackend()
@@ -139,6 +140,12 @@ class Integrator:
         p.max_depth = self.max_depth; p.rr_depth = self.rr_depth
         p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0) | (abi.FLAG_REGEN if getattr(self, "regen", False) else 0) | (abi.FLAG_TWO_PASS if getattr(self, "two_pass", False) else 0)
         p.mode = self.mode; p.integrator = self.integrator_id
+        spass = int(getattr(self, "samples_per_pass", -1))
+        if spass not in (-1, 0, 0xffffffff) and int(spp) > 0:           # integrator.cpp:565-573
+            per = min(spass, int(spp))
+            if int(spp) % per != 0:
+                raise PluginError("sample_count (%d) must be a multiple of samples_per_pass (%d)." % (int(spp), per))
+            p.passes = int(spp) // per
         gw, gh = self.lane_grid(f); npix = gw * gh
         if shard is not None:
             p.pixel_begin, p.pixel_count = shard[0], shard[1]
@@ -253,21 +260,44 @@ class ParticleTracerIntegrator(Integrator):
     name = "ptracer"
     default_max_depth = -1
 
-    def __init__(self, props=None):
-        super().__init__(props)
-        self.samples_per_pass = int((props or {}).get("samples_per_pass", -1))
-
     def lane_grid(self, film):
         return film.width, film.height
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
-        spp_res = self._resolve_spp(scene, spp)
-        if self.samples_per_pass not in (-1, 0) and spp_res % min(self.samples_per_pass, spp_res) != 0:
-            raise PluginError("sample_count (%d) must be a multiple of samples_per_pass (%d)." % (spp_res, self.samples_per_pass))
         return super().render(scene, sensor, seed, spp, develop, evaluate, shard, group)
 
-    def render_backward(self, *a, **k):
-        raise PluginError("ptracer: render_backward (AD through mesh vertices / IORs) is not built")
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
+        """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp for the EMITTER RADIANCES -- the parameter the
+        reference's own test differentiates (test_ptracer.py:204-225).  `params` must have been narrowed to radiance keys
+        (`params.keep([...])`, util.py:234-258): gradients of light paths with respect to reflectances, textures, mesh vertices or IORs
+        are not built, and a parameter that would silently receive a zero gradient is an error here."""
+        torch = _torch()
+        if params is None:
+            raise PluginError("ptracer.render_backward needs the SceneParameters it should differentiate (radiance keys only)")
+        bad = [k for k in params.keys() if params._entries[k][0] != abi.PARAM_EMITTER_RADIANCE]
+        if bad:
+            raise PluginError("ptracer.render_backward is built for emitter radiances only; drop these with params.keep(): %s" % ", ".join(sorted(bad)))
+        be = self.backend
+        dev = be.device(scene)
+        f = scene.sensor.film
+        spp = self._resolve_spp(scene, spp)
+        grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
+        if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
+            raise ValueError("grad_in must have shape (H, W, 3)")
+        band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
+        p = self._params(scene, seed, spp, shard=band)
+        p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
+        grads = params.grad_buffer(dev)
+        multi = shard is not None and shard[1] > 1
+        local = torch.zeros_like(grads) if multi else grads
+        if band is None or band[1] > 0:
+            abi.check(abi.lib().mi355_render_backward(scene.handle(), C.byref(p), C.c_void_p(grad_in.data_ptr()), None,
+                                                      C.c_void_p(local.data_ptr()), _stream_ptr(dev)))
+        if multi:
+            import torch.distributed as dist
+            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+            grads += local
+        return grads
 
 
 def make_integrator(props):
@@ -324,6 +354,18 @@ class SceneParameters:
     def _add(self, key, kind, index, value):
         self._entries[key] = (kind, index, tuple(value.shape))
         self._values[key] = value
+
+    def keep(self, keys):
+        """SceneParameters.keep (util.py:234-258): keep the parameters whose key matches one of `keys` (regular expressions, matched
+        from the start of the key as re.match does)."""
+        import re
+        if not isinstance(keys, list):
+            keys = [keys]
+        regexps = [re.compile(k).match for k in keys]
+        wanted = [k for k in self._entries if any(r(k) for r in regexps)]
+        for k in list(self._entries):
+            if k not in wanted:
+                del self._entries[k]; del self._values[k]; self._dirty.discard(k)
 
     def keys(self): return self._entries.keys()
     def __contains__(self, k): return k in self._entries

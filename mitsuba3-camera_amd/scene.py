@@ -583,6 +583,9 @@ def _make_bsdf(scene, props, id):
     return b
 
 
+BSDF_PLUGINS = ("diffuse", "roughconductor", "conductor", "dielectric", "dispersive")
+
+
 def load_dict(d):
     """mi.load_dict for the plugins on the path.  Returns a Scene (type 'scene') or a single-shape Scene-less
     object for shape dicts used by unit tests."""
@@ -602,7 +605,7 @@ def load_dict(d):
             scene.integrator_props = dict(v)
         elif vt in ("perspective", "realisticlens"):
             scene.sensor = Sensor(v)
-        elif vt in ("diffuse", "roughconductor", "conductor", "dielectric", "dispersive"):
+        elif vt in BSDF_PLUGINS:
             named[key] = _make_bsdf(scene, v, key)
         elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere", "disk"):
             pending_shapes.append((key, v))
@@ -618,7 +621,26 @@ def load_dict(d):
         tw = v.get("to_world", Transform4f())
         if not isinstance(tw, Transform4f):
             tw = Transform4f(tw)
-        bp = v.get("bsdf")
+        # children are recognised by their plugin class, not by their key (xml.cpp / Shape::Shape, shape.cpp:39-72)
+        bp = ep = None
+        for ck, cv in v.items():
+            if not isinstance(cv, dict) or "type" not in cv:
+                continue
+            ct = cv["type"]
+            if ct in BSDF_PLUGINS or (ct == "ref" and cv.get("id") in named):
+                if bp is not None:
+                    raise PluginError("Only a single BSDF child object can be specified per shape.")
+                bp = cv
+            elif ct in ("area", "directionalarea"):
+                if ep is not None:
+                    raise PluginError("Only a single Emitter child object can be specified per shape.")
+                ep = cv
+            elif ct == "ref":
+                raise PluginError('Referenced object "%s" not found!' % cv.get("id"))
+            elif ct in ("rgb", "bitmap", "spectrum"):
+                continue
+            else:
+                raise PluginError('shape child plugin "%s" is outside the path (bsdf: %s; emitter: area, directionalarea)' % (ct, ", ".join(BSDF_PLUGINS)))
         if bp is None:
             if default_bsdf is None:
                 default_bsdf = _make_bsdf(scene, {"type": "diffuse"}, "__default_bsdf")
@@ -656,10 +678,7 @@ def load_dict(d):
             if v.get("vertex_texcoords") is not None:
                 shape.vertex_texcoords = np.ascontiguousarray(np.asarray(v["vertex_texcoords"], dtype=np.float32).reshape(-1, 2))
             shape.faces = np.ascontiguousarray(np.asarray(v["faces"], dtype=np.uint32).reshape(-1, 3))
-        ep = v.get("emitter")
         if ep is not None:
-            if ep.get("type") not in ("area", "directionalarea"):
-                raise PluginError('emitter plugin "%s" is outside the path (area, directionalarea)' % ep.get("type"))
             e = Emitter(_rgb(ep.get("radiance", 1.0), "area.radiance", False))
             e.type = abi.EMITTER_AREA if ep.get("type") == "area" else abi.EMITTER_DIRECTIONALAREA
             e.shape = shape; shape.emitter = e

