@@ -16,8 +16,14 @@
  *   rectangle hit grid (src/shapes/tests/test_rectangle.py:33-57), cube hit/normal/uv
  *   (src/shapes/tests/test_cube.py:26-70), gaussian filter / imageblock / hdrfilm identities.
  * PCG32 arithmetic lives in Dr.Jit (absent): pinned to the published pcg32 demo vector instead.
- * Whole-image radiance and PRB gradients against llvm_ad_rgb are "parity unpinned"; they are
- * checked by self-consistency (finite differences, energy identities) only.
+ * END-TO-END PIN: the one whole-render number the reference's tests hard-code for this path -- the particle tracer's
+ * d mean(image) / d radiance = 0.33647 +- 1e-5 (src/integrators/tests/test_ptracer.py:204-225, JIT variants) -- is reproduced
+ * (0.3364746) by orc_ptracer_accumulate / orc_ptracer_backward.  It depends on, and therefore pins together: TEA seeding of the
+ * sampler streams and the PCG32 seeding order, the pass structure of the render loop, the order and masking of the sampler calls,
+ * Rectangle::sample_position, PerspectiveCamera::sample_direction / importance, sample_scale and the normalised splat.
+ * Whole-image radiance of the PATH integrator and PRB gradients against llvm_ad_rgb have no such number in the reference and stay
+ * "parity unpinned"; they share the sampler, sensor, shape and film code pinned above and are otherwise checked by
+ * self-consistency (finite differences, energy identities, agreement with the pinned light tracer).
  *
  * Each function cites the reference file:line it follows (paths relative to /root/reference).
  * Arithmetic notes: Dr.Jit's dot/cross/matrix-vector products are fmadd chains, ray(t) is an
