@@ -259,11 +259,11 @@ def main():
     pt = None
     if args.ptracer:
         pt = {}
-        for rf in ("box", "gaussian"):
+        for rf in ("box", "gaussian", "gaussian-direct"):          # gaussian: deferred tile-sorted splat (default); -direct: plain atomics
             dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
-            dp["sensor"]["film"]["rfilter"] = {"type": rf}
+            dp["sensor"]["film"]["rfilter"] = {"type": rf.split("-")[0]}
             scp = mi.load_dict(dp)
-            ip = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 5}); ip.timing = True
+            ip = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 5}); ip.timing = True; ip.direct_splat = rf.endswith("-direct")
             shard = (rank, world) if world > 1 else None
             ip.render(scp, seed=0, spp=args.prb_spp, shard=shard); barrier(); ip.counters(scp, reset=True)
             n_pt = max(2, args.steps // 3)

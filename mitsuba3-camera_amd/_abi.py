@@ -20,7 +20,7 @@ SENSOR_PERSPECTIVE, SENSOR_REALISTICLENS = 0, 1
 RFILTER_BOX, RFILTER_GAUSSIAN, RFILTER_TENT = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
-FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY = 1, 2, 4, 8, 16
+FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY, FLAG_DIRECT_SPLAT = 1, 2, 4, 8, 16, 32
 MODE_FUSED, MODE_WAVEFRONT, MODE_STATIC = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_PRB, INTEGRATOR_PTRACER = 0, 1, 2
 PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE = 0, 1, 2
@@ -111,6 +111,7 @@ SYMBOLS = [
     ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("mi355_debug_lane_radiance", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_debug_set_splat_capacity", C.c_int, [C.c_void_p, C.c_uint32]),
     ("mi355_perspective_projection", None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.c_float, C.c_float, C.c_float, f32p]),
     ("mi355_gaussian_coeffs", None, [C.c_float, f32p]),

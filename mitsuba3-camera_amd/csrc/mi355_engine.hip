@@ -15,6 +15,10 @@
 //   k_prb_backward<FULL>        prb.py's two walks (primal replay + adjoint replay): MI355_FLAG_TWO_PASS, and the redo pass
 //                               for workgroups whose one-pass queue overflowed
 //   k_exit_pupil                realisticlens exit-pupil LUT (64 rings x 2^20 rays) at scene creation
+//   k_ptracer<FULL, GRAD>       particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per light-sample stream;
+//                               GRAD = render_backward for the emitter radiances (gathers dL/dimage at the splat taps)
+//   k_splat_hist / _scan / _scatter / _tiles   deferred splat of the particle tracer's connections: counting sort by 16 x 16 film
+//                               tile (LDS-privatised), then per-tile accumulation in LDS (64-bit fixed point, integer atomics)
 //   k_develop                   HDRFilm::develop
 //   k_debug_intersect           Scene::ray_intersect_preliminary / ray_test on caller rays
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
@@ -46,6 +50,7 @@
 #define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
 #define CSTATE_WORDS 23                     // per lane, k_render_compact (21 + eta, prev_delta in FULL scenes)
 #define MAX_SMALL_GRAD 1024
+#define MAX_SPLAT_RECORDS (128ull << 20)   // deferred-splat queue of the particle tracer: 40 B per record (unsorted + sorted copy)
 #define GRAD_QUEUE 496                      // texture-gradient records per workgroup (16 KB, 2 per lane); overflow -> direct atomics
 // one LDS region per workgroup, reused in turn by: BVH traversal stacks | compaction state exchange | film splat staging
 #define CMAX(a, b) ((a) > (b) ? (a) : (b))
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 // unit-radiance value x gathered adjoint to the emitter's accumulator (LDS copies, one global atomic per workgroup and channel).
 template <bool FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
-                                                                 const uint32_t *small_map, unsigned long long *g_counters) {
+                                                                 const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
     __shared__ uint32_t s_cnt[4];
     __shared__ float s_acc[GRAD ? MI_PT_EM_LDS * 3u * MI_PT_COPIES : 1u];
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     Counters3 cnt = {};
     for (uint32_t pass = 0; pass < a.passes; ++pass)                       // one stream, `passes` samples (integrator.cpp:719-727)
-        ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt, &sink);
+        ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt, &sink, (!GRAD && queue.cap) ? &queue : nullptr);
     __syncthreads();
     if (GRAD) {
         const uint32_t n = min(sc.n_emitters, MI_PT_EM_LDS) * 3u;
@@ -740,6 +745,146 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
         }
     }
     flush_counters(s_cnt, cnt, g_counters);
+}
+
+// ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------
+#define SPLAT_CHUNK 8192u                                                   // records per workgroup in the histogram / scatter passes
+#define SPLAT_RUN 4096u                                                     // records per workgroup in the tile pass
+#define SPLAT_MAX_TILES 8000u                                               // LDS bins: 2 x 4 B per tile in the scatter pass stays under 64 KB (films up to ~1430^2; larger ones splat directly)
+// Tile histogram of the record queue; one LDS histogram per chunk, flushed with one global atomic per non-empty bin.
+__global__ __launch_bounds__(256) void k_splat_hist(DScene sc, SplatQueue q, uint32_t n_tiles) {
+    extern __shared__ uint32_t s_bins[];
+    const uint32_t n = min(*q.count, q.cap);
+    for (uint32_t c0 = blockIdx.x * SPLAT_CHUNK; c0 < n; c0 += gridDim.x * SPLAT_CHUNK) {
+        for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) s_bins[k] = 0u;
+        __syncthreads();
+        const uint32_t c1 = min(c0 + SPLAT_CHUNK, n);
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256u) { const float4 a = q.rec_a[i]; atomicAdd(s_bins + splat_tile_of(sc, q, a.x, a.y), 1u); }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { const uint32_t v = s_bins[k]; if (v) atomicAdd(q.hist + k, v); }
+        __syncthreads();
+    }
+}
+// Exclusive scan of the tile histogram (one workgroup); also clamps the record count to the capacity and clears the cursors.
+__global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint32_t *offsets, uint32_t *cursor, uint32_t n_tiles, uint32_t *count, uint32_t cap) {
+    __shared__ uint32_t s_part[1024]; __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) { s_carry = 0u; if (*count > cap) *count = cap; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? hist[i] : 0u;
+        s_part[threadIdx.x] = v; __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {                          // Hillis-Steele inclusive scan
+            uint32_t t = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u; __syncthreads();
+            s_part[threadIdx.x] += t; __syncthreads();
+        }
+        const uint32_t incl = s_part[threadIdx.x], carry = s_carry;
+        if (i < n_tiles) { offsets[i] = carry + incl - v; cursor[i] = 0u; }
+        __syncthreads();
+        if (threadIdx.x == 1023u) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n_tiles] = s_carry;
+}
+// Counting sort, scatter step.  Per chunk: LDS histogram -> one global cursor atomic per non-empty tile reserves the chunk's range in
+// that tile -> every record takes the next slot of its tile's reservation (LDS atomic).
+__global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b, uint32_t n_tiles) {
+    extern __shared__ uint32_t s_bins[];                                    // [n_tiles] counts, then bases; [n_tiles] local cursors
+    uint32_t *s_cur = s_bins + n_tiles;
+    const uint32_t n = *q.count;
+    for (uint32_t c0 = blockIdx.x * SPLAT_CHUNK; c0 < n; c0 += gridDim.x * SPLAT_CHUNK) {
+        for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { s_bins[k] = 0u; s_cur[k] = 0u; }
+        __syncthreads();
+        const uint32_t c1 = min(c0 + SPLAT_CHUNK, n);
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256u) { const float4 a = q.rec_a[i]; atomicAdd(s_bins + splat_tile_of(sc, q, a.x, a.y), 1u); }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { const uint32_t v = s_bins[k]; if (v) s_bins[k] = offsets[k] + atomicAdd(cursor + k, v); }
+        __syncthreads();
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256u) {
+            const float4 a = q.rec_a[i]; const float b = q.rec_b[i];
+            const uint32_t t = splat_tile_of(sc, q, a.x, a.y);
+            const uint32_t dst = s_bins[t] + atomicAdd(s_cur + t, 1u);
+            out_a[dst] = a; out_b[dst] = b;
+        }
+        __syncthreads();
+    }
+}
+// Tile pass: workgroup b owns the sorted records [b * SPLAT_RUN, (b + 1) * SPLAT_RUN) -- equal work whatever the distribution over
+// the film.  For every tile that run touches: the tile plus its apron lives in LDS, every record adds its normalised taps there, and
+// the tile goes to the film with one float atomic per touched pixel and channel.
+// The LDS accumulators are 64-bit FIXED POINT, added with integer atomics: on this chip an LDS fp32 atomic add keeps the LDS busy for
+// ~122 cycles per wave instruction (2 cycles per lane; profiles/r01_j_ptracer_pmc_summary.txt) against ~9 for an integer one.  The
+// scale is a power of two chosen per run from the largest colour component m of its records: contributions are <= m, a pixel
+// receives at most SPLAT_RUN of them, so with m * scale <= 2^50 the sum stays below 2^62, and the quantum is 2^-50 of m -- finer
+// than the fp32 additions it replaces.  (Non-finite colours take the float path, so that they reach the film as they are.)
+#define MI_SPLAT_TW (MI_SPLAT_TILE + 2 * MI_SPLAT_APRON)
+__global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, const uint32_t *offsets, const float4 *rec_a, const float *rec_b, float *film, uint32_t n_tiles) {
+    __shared__ long long s_tile[MI_SPLAT_TW * MI_SPLAT_TW * 3];
+    __shared__ uint32_t s_max;
+    const uint32_t n = *q.count;
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+    for (uint32_t r0 = blockIdx.x * SPLAT_RUN; r0 < n; r0 += gridDim.x * SPLAT_RUN) {
+        const uint32_t r1 = min(r0 + SPLAT_RUN, n);
+        uint32_t lo = 0, hi = n_tiles;                                      // last tile whose range starts at or before r0
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (offsets[mid] <= r0) lo = mid; else hi = mid; }
+        uint32_t start = r0;
+        for (uint32_t tile = lo; tile < n_tiles && start < r1; ++tile) {
+            const uint32_t stop = min(offsets[tile + 1], r1);
+            if (stop <= start) continue;                                    // empty tile
+            for (uint32_t k = threadIdx.x; k < MI_SPLAT_TW * MI_SPLAT_TW * 3; k += 256u) s_tile[k] = 0ll;
+            if (threadIdx.x == 0) s_max = 0u;
+            __syncthreads();
+            float m = 0.f;
+            for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) { const float4 a = rec_a[j]; m = fmaxf(m, fmaxf(fabsf(a.z), fmaxf(fabsf(a.w), fabsf(rec_b[j])))); if (!(fabsf(a.z) + fabsf(a.w) + fabsf(rec_b[j]) < MI_INF)) m = MI_INF; }
+            atomicMax(&s_max, __float_as_uint(m));                          // (m >= 0: the bit patterns order like the values)
+            __syncthreads();
+            m = __uint_as_float(s_max);
+            const bool fixed = m < MI_INF;                                  // uniform over the workgroup
+            int e = 0; (void) frexpf(m, &e);                                // m < 2^e
+            const int se = min(50 - e, 120);
+            const float scale = ldexpf(1.f, se), inv_scale = ldexpf(1.f, -se);
+            const int32_t ox = (int32_t) (tile % q.tiles_x) * MI_SPLAT_TILE - MI_SPLAT_APRON, oy = (int32_t) (tile / q.tiles_x) * MI_SPLAT_TILE - MI_SPLAT_APRON;
+            if (m != 0.f) for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) {
+                const float4 a = rec_a[j]; const float b = rec_b[j];
+                Splat sp = splat_weights(sc, a.x, a.y);
+                float sx = 0.f, sy = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI_MAX_TAPS; ++i) { sx += i < sp.count ? sp.wx[i] : 0.f; sy += i < sp.count ? sp.wy[i] : 0.f; }
+                float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+#pragma unroll
+                for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+                        const int32_t x = sp.x0 + tx, y = sp.y0 + ty;
+                        if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
+                        const float w = sp.wy[ty] * (sp.wx[tx] * factor);
+                        const int32_t lx = x - ox, ly = y - oy;
+                        if (w == 0.f || lx < 0 || ly < 0 || lx >= MI_SPLAT_TW || ly >= MI_SPLAT_TW) continue;   // (inside by construction)
+                        if (fixed) {
+                            unsigned long long *px = reinterpret_cast<unsigned long long *>(s_tile) + (ly * MI_SPLAT_TW + lx) * 3;
+                            atomicAdd(px, (unsigned long long) __float2ll_rn((a.z * w) * scale));
+                            atomicAdd(px + 1, (unsigned long long) __float2ll_rn((a.w * w) * scale));
+                            atomicAdd(px + 2, (unsigned long long) __float2ll_rn((b * w) * scale));
+                        } else {                                            // non-finite colours: straight to the film
+                            float *px = film + ((size_t) y * W + x) * 4;
+                            atomicAdd(px, a.z * w); atomicAdd(px + 1, a.w * w); atomicAdd(px + 2, b * w);
+                        }
+                    }
+            }
+            __syncthreads();
+            if (fixed && m != 0.f) for (uint32_t k = threadIdx.x; k < MI_SPLAT_TW * MI_SPLAT_TW; k += 256u) {
+                const int32_t x = ox + (int32_t) (k % MI_SPLAT_TW), y = oy + (int32_t) (k / MI_SPLAT_TW);
+                if (x < 0 || y < 0 || x >= W || y >= H) continue;
+                const long long r = s_tile[3 * k], g = s_tile[3 * k + 1], bl = s_tile[3 * k + 2];
+                float *px = film + ((size_t) y * W + x) * 4;
+                if (r != 0ll) atomicAdd(px, (float) r * inv_scale);
+                if (g != 0ll) atomicAdd(px + 1, (float) g * inv_scale);
+                if (bl != 0ll) atomicAdd(px + 2, (float) bl * inv_scale);
+            }
+            __syncthreads();
+            start = stop;
+        }
+    }
 }
 
 // HDRFilm::develop, hdrfilm.cpp:304-409
@@ -866,6 +1011,9 @@ struct mi355_scene {
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
     uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
+    // deferred splat of the particle tracer: record queue (unsorted + sorted copy), tile histogram / offsets / cursors, record counter
+    float4 *d_rec_a = nullptr, *d_srt_a = nullptr; float *d_rec_b = nullptr, *d_srt_b = nullptr; uint32_t rec_capacity = 0;
+    uint32_t *d_tile_u32 = nullptr; uint32_t tile_capacity = 0; uint32_t splat_cap_override = 0;
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow, [4] redone backward workgroups
     uint64_t n_gen = 0, n_splat = 0;
     hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
@@ -1335,7 +1483,8 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf };
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf,
+                     s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_tile_u32 };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -1455,9 +1604,43 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     if (p->integrator == MI355_INTEGRATOR_PTRACER) {
         if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
-        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters);
-        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters);
+        // Reconstruction filters with more than one tap: deferred, tile-sorted splat (see film_put_deferred).  The queue holds every
+        // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
+        SplatQueue q; memset(&q, 0, sizeof(q));
+        const uint64_t per_lane = (uint64_t) a.passes * (p->max_depth < 0 ? 64u : (uint32_t) p->max_depth);
+        const uint32_t all_tiles = ((s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE) * ((s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE);
+        if (s->ds.rfilter != MI355_RFILTER_BOX && !(p->flags & MI355_FLAG_DIRECT_SPLAT) && (uint64_t) a.n_local * per_lane < 0xffffffffull && all_tiles <= SPLAT_MAX_TILES) {
+            const uint64_t want = std::min<uint64_t>((uint64_t) a.n_local * a.passes * (p->max_depth < 0 ? 8u : std::min<uint32_t>((uint32_t) p->max_depth, 8u)), s->splat_cap_override ? s->splat_cap_override : MAX_SPLAT_RECORDS);
+            q.tiles_x = (s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE; q.tiles_y = (s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE;
+            const uint32_t n_tiles = q.tiles_x * q.tiles_y;
+            if (s->rec_capacity < want) {
+                for (void *b : { (void *) s->d_rec_a, (void *) s->d_srt_a, (void *) s->d_rec_b, (void *) s->d_srt_b }) if (b) HIP_TRY(hipFree(b));
+                s->d_rec_a = s->d_srt_a = nullptr; s->d_rec_b = s->d_srt_b = nullptr; s->rec_capacity = 0;
+                HIP_TRY(hipMalloc((void **) &s->d_rec_a, want * sizeof(float4))); HIP_TRY(hipMalloc((void **) &s->d_srt_a, want * sizeof(float4)));
+                HIP_TRY(hipMalloc((void **) &s->d_rec_b, want * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_srt_b, want * sizeof(float)));
+                s->rec_capacity = (uint32_t) want;
+            }
+            if (s->tile_capacity < n_tiles) {                               // [count | hist n | offsets n + 1 | cursor n]
+                if (s->d_tile_u32) HIP_TRY(hipFree(s->d_tile_u32));
+                s->d_tile_u32 = nullptr; s->tile_capacity = 0;
+                HIP_TRY(hipMalloc((void **) &s->d_tile_u32, (3 * (size_t) n_tiles + 2) * sizeof(uint32_t))); s->tile_capacity = n_tiles;
+            }
+            q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.cap = (uint32_t) want; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + 1;
+            HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (1 + (size_t) n_tiles) * sizeof(uint32_t), st));
+        }
+        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
+        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
         HIP_TRY(hipGetLastError());
+        if (q.cap) {
+            const uint32_t n_tiles = q.tiles_x * q.tiles_y;
+            uint32_t *offsets = q.hist + n_tiles, *cursor = offsets + n_tiles + 1;
+            const uint32_t chunks = std::min<uint32_t>((q.cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK, 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
+            hipLaunchKernelGGL(k_splat_hist, dim3(chunks), dim3(256), n_tiles * sizeof(uint32_t), st, s->ds, q, n_tiles);
+            hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles, q.count, q.cap);
+            hipLaunchKernelGGL(k_splat_scatter, dim3(chunks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b, n_tiles);
+            hipLaunchKernelGGL(k_splat_tiles, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b, d_film_rgbw, n_tiles);
+            HIP_TRY(hipGetLastError());
+        }
         if ((rc = tm.end())) return rc;
         s->n_gen += a.n_local;
         return MI355_OK;
@@ -1530,8 +1713,8 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         if (s->emitters.empty()) return MI355_OK;
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         const dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
-        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters);
-        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters);
+        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{});
+        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{});
         HIP_TRY(hipGetLastError());
         return tm.end();
     }
@@ -1626,6 +1809,10 @@ extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_para
     }
     HIP_TRY(hipGetLastError());
     return MI355_OK;
+}
+extern "C" int mi355_debug_set_splat_capacity(mi355_scene *s, uint32_t records) {
+    if (!s) return fail(MI355_ERR_INVALID, "null argument");
+    s->splat_cap_override = records; return MI355_OK;
 }
 extern "C" int mi355_debug_ray_intersect(mi355_scene *s, const float *d_rays, uint32_t n, float *d_hits, void *stream) {
     if (!s || !d_rays || !d_hits) return fail(MI355_ERR_INVALID, "null argument");

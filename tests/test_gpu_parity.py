@@ -648,6 +648,35 @@ def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
             integ.render_backward(scene, None, None)
 
 
+@pytest.mark.parametrize("rfilter", [{"type": "gaussian"}, {"type": "tent"}, {"type": "gaussian", "stddev": 0.3}])
+def test_particle_tracer_deferred_splat(mi, orc, torch_cuda, rfilter):
+    """The tile-sorted, LDS-accumulated splat (film_put_deferred -> k_splat_scan / k_splat_scatter / k_splat_tiles) against the direct
+    atomics and the oracle: same film up to summation order -- on a film that is not a multiple of the tile size, with a crop window,
+    with the queue capped far below the number of connections (overflow records take the direct path), and over two shards."""
+    torch = torch_cuda
+    d = small_cbox(mi, 48, rfilter=rfilter, width=52, height=37, crop_offset_x=3, crop_offset_y=2, crop_width=45, crop_height=33)
+    scene = mi.load_dict(d); o = orc.OracleScene(scene, mi.abi)
+    integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 3})
+    ref, _ = o.ptracer_render(o.params(integ, 6, 32), develop=False)
+    scale = np.percentile(ref[..., :3], 99)
+    deferred = integ.render(scene, seed=6, spp=32, develop=False).cpu().numpy()
+    integ.direct_splat = True
+    direct = integ.render(scene, seed=6, spp=32, develop=False).cpu().numpy()
+    integ.direct_splat = False
+    assert np.abs(direct - ref).max() < 2e-3 * scale and np.abs(deferred - ref).max() < 2e-3 * scale
+    assert np.allclose(deferred, direct, rtol=1e-4, atol=1e-5 * scale) and (deferred[..., 3] == 0).all()
+    mi.abi.check(mi.abi.lib().mi355_debug_set_splat_capacity(scene.handle(), 5000))
+    capped = integ.render(scene, seed=6, spp=32, develop=False).cpu().numpy()
+    mi.abi.check(mi.abi.lib().mi355_debug_set_splat_capacity(scene.handle(), 0))
+    assert np.allclose(capped, direct, rtol=1e-4, atol=1e-5 * scale)
+    acc = torch.zeros((33, 45, 4), device="cuda")
+    for r in range(2):
+        p = integ._params(scene, 6, 32, shard=mi.shard_tiles(52, 37, r, 2, rows=8))
+        mi.abi.check(mi.abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), direct, rtol=1e-4, atol=1e-5 * scale)
+
+
 def test_particle_tracer_gradient_reference_test06(mi, orc, torch_cuda, kats):
     """src/integrators/tests/test_ptracer.py:204-225 (test06_ptracer_gradients) as written there, against ITS hard-coded number:
     traverse -> keep the radiance -> set it to 1 -> render (seed 0) -> loss = mean(image) -> render_backward(seed 3, 64 spp in 4 passes)
