@@ -711,6 +711,30 @@ def test_particle_tracer_gradient_reference_test06(mi, orc, torch_cuda, kats):
         mi.PathIntegrator({"max_depth": 4, "samples_per_pass": 16}).render(scene, seed=3, spp=64)
 
 
+def test_particle_tracer_reference_test01_to_05(mi, orc, torch_cuda):
+    """test_ptracer.py test01 (area and directionalarea: >= 20 % of the image lit at 2 spp), test03 (hide_emitters -> black), test04
+    (no emitter -> black, also undeveloped) and test05 (crop window == cropped full render, "even the noise pattern") on the device."""
+    torch = torch_cuda
+    from test_oracle_path import ptracer_test_scene, ptracer_test_scene_directional
+    for d in (ptracer_test_scene(mi, radiance=(1.0, 0.5, 0.2)), ptracer_test_scene_directional(mi)):
+        scene = mi.load_dict(d); integ = mi.make_integrator(scene.integrator_props)
+        img = integ.render(scene, seed=0, spp=2).cpu().numpy()
+        o = orc.OracleScene(scene, mi.abi); ref, _ = o.ptracer_render(o.params(integ, 0, 2))
+        assert (img > 0).sum() >= 0.2 * img.size and np.allclose(img, ref, rtol=1e-3, atol=1e-5)
+    scene = mi.load_dict(ptracer_test_scene(mi, hide_emitters=True))
+    assert (mi.make_integrator(scene.integrator_props).render(scene, seed=0, spp=4).cpu().numpy() == 0).all()
+    d = ptracer_test_scene(mi); del d["emitter"]
+    d["receiver"] = ptracer_test_scene_directional(mi)["receiver"]
+    scene = mi.load_dict(d); integ = mi.make_integrator(scene.integrator_props)
+    assert (integ.render(scene, seed=0, spp=2).cpu().numpy() == 0).all() and (integ.render(scene, seed=0, spp=2, develop=False).cpu().numpy() == 0).all()
+    full = mi.load_dict(ptracer_test_scene(mi, radiance=(1.0, 0.5, 0.2)))
+    integ = mi.make_integrator(full.integrator_props)
+    image1 = integ.render(full, seed=0, spp=4).cpu().numpy()
+    d = ptracer_test_scene(mi, radiance=(1.0, 0.5, 0.2)); d["sensor"]["film"].update(crop_offset_x=2, crop_offset_y=3, crop_width=6, crop_height=4)
+    image3 = integ.render(mi.load_dict(d), seed=0, spp=4).cpu().numpy()
+    assert image3.shape == (4, 6, 3) and np.allclose(image1[3:7, 2:8], image3, atol=1e-4)
+
+
 def test_particle_tracer_radiance_gradients_match_oracle(mi, orc, torch_cuda):
     """k_ptracer<GRAD> against the oracle on a scene with three emitters (rectangle, sphere, a collimated disk beam), a Gaussian film
     filter, Russian roulette and two passes; shards add up; a zero radiance channel still receives its derivative."""
@@ -818,6 +842,43 @@ def test_disk_and_directional_area(mi, orc, torch_cuda, case):
         g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
         g_ref = o.render_backward(o.params(integ, 7, 16), gin)
         assert np.abs(g_ref).max() > 0 and np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+
+
+@pytest.mark.parametrize("scene_name,integrator_name", [("cbox", "path"), ("cbox", "prb"), ("veach", "path")])
+def test_image_z_test_against_oracle(mi, orc, torch_cuda, scene_name, integrator_name):
+    """The reference's render test (src/render/tests/test_renders.py:159-233) with the oracle in the role of the stored reference
+    image: per-pixel Z-test of the device image (sample budget 2e6, seed 0) against the reference mean, with the reference's
+    per-sample variance clamped at 1e-4, significance 0.01 with the Sidak correction over the pixels, passed when >= 99.75 % of the
+    pixels accept.  Different seeds on the two sides: this is the statistical statement (same estimator), not lane parity."""
+    import math
+    res = 16
+    if scene_name == "cbox":
+        scene = mi.load_dict(small_cbox(mi, res, rfilter={"type": "box"}))
+    else:
+        d = mi.veach_mis_scene(res); d["sensor"]["film"]["rfilter"] = {"type": "box"}; scene = mi.load_dict(d)
+    integ = mi.make_integrator({"type": integrator_name, "max_depth": 6, "rr_depth": 5})
+    o = orc.OracleScene(scene, mi.abi)
+    spp_ref = 2048 if scene_name == "cbox" else 8192
+    lanes = o.lane_radiance(o.params(integ, 12345, spp_ref), 0, res * res * spp_ref)[:, :3].reshape(res * res, spp_ref, 3).astype(np.float64)
+    ref, ref_var = lanes.mean(axis=1).reshape(res, res, 3), lanes.var(axis=1).reshape(res, res, 3)    # box filter: a lane lands in its own pixel
+    pixel_count = res * res
+    spp = int(2e6) // pixel_count
+    img = integ.render(scene, seed=0, spp=spp).cpu().numpy().astype(np.float64)
+    got = integ.lane_radiance(scene, 0, spp, 0, res * res * spp).cpu().numpy()[:, :3].reshape(res * res, spp, 3).astype(np.float64)
+    assert np.allclose(got.mean(axis=1).reshape(res, res, 3), img, rtol=1e-4, atol=1e-6)           # the image IS the mean of its lanes
+    # the reference image itself is an estimate here, so both sample variances enter (the glossy scene's heavy tails make the
+    # variance of a 2048-sample reference alone too optimistic for a handful of pixels)
+    var_pair = np.maximum(ref_var, 1e-4) / spp_ref + np.maximum(got.var(axis=1).reshape(res, res, 3), 1e-4) / spp
+    z = np.abs(img - ref) / np.sqrt(var_pair)
+    p_value = 2.0 * (1.0 - 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0))))
+    alpha = 1.0 - (1.0 - 0.01) ** (1.0 / pixel_count)
+    success = p_value > alpha
+    assert np.count_nonzero(success) / 3 >= 0.9975 * pixel_count, (np.count_nonzero(~success), p_value.min(), alpha)
+    if scene_name == "cbox":
+        assert abs(img.mean() / ref.mean() - 1) < 0.01
+    else:               # rare, very bright samples carry the glossy scene's mean: compare where the estimates are stable
+        calm = (ref_var / spp_ref < (0.02 * ref) ** 2) & (ref > 0)
+        assert calm.mean() > 0.3 and abs(np.median(img[calm] / ref[calm]) - 1) < 0.01
 
 
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):

@@ -223,6 +223,29 @@ def ptracer_test_scene(mi, radiance=(1.0, 1.0, 1.0), **integrator):
                         "area_emitter": {"type": "area", "radiance": {"type": "rgb", "value": radiance}}}}
 
 
+def ptracer_test_scene_directional(mi):
+    """create_test_scene(emitter='directionalarea') of test_ptracer.py:63-108: a collimated 2 x 2 beam from (4, 1, 0) towards the
+    origin and the receiver plane the reference adds for it."""
+    T = mi.ScalarTransform4f
+    d = ptracer_test_scene(mi)
+    d["emitter"] = {"type": "rectangle", "to_world": T.look_at(origin=(4, 1, 0), target=(0, 0, 0), up=(0, 1, 0)),
+                    "area_emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": (1.0, 0.5, 0.2)}}}
+    d["receiver"] = {"type": "rectangle", "to_world": T.look_at(origin=(0, 0, 0), target=(1, 0, 0), up=(0, 1, 0)), "bsdf": {"type": "diffuse"}}
+    return d
+
+
+def test_particle_tracer_reference_test01_directionalarea(mi, orc):
+    """test_ptracer.py:113-118 (test01_render_simple) for the `directionalarea` emitter: seed 0, 2 spp, at least 20 % of the image
+    values are lit -- light reaches the film only through sample_ray + one diffuse bounce on the receiver."""
+    sc = mi.load_dict(ptracer_test_scene_directional(mi)); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.make_integrator(sc.integrator_props)
+    img, _ = o.ptracer_render(o.params(integ, 0, 2))
+    assert (img > 0).sum() >= 0.2 * img.size
+    integ.max_depth = 1                                              # only directly visible emitters: a collimated one is never connected
+    z, _ = o.ptracer_render(o.params(integ, 0, 2))
+    assert (z == 0).all()
+
+
 def test_particle_tracer_reference_golden_gradient(mi, orc, kats):
     """The one number the reference's tests hard-code for this integrator (test_ptracer.py:225): d mean(image) / d radiance = 0.33647
     (atol 1e-5) for seed 3, 64 spp in 4 passes.  The image is linear in the radiance, so the gradient is sum(image at radiance 1) /
