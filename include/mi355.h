@@ -292,6 +292,15 @@ int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
                           const float *d_grad_in, const float *d_weight,
                           float *d_grad_params, void *stream);
 
+/* Integrator::render_forward (include/mitsuba/render/integrator.h:104-190; RBIntegrator.render_forward, common.py:498-629; prb.py in
+   dr.ADMode.Forward): forward-mode derivative of the render.  d_tangent_params holds one float per differentiable scene float,
+   laid out like the gradient buffer (mi355_scene_param_layout) -- what dr.set_grad() put on the parameters.  Every sample's
+   dL = sum over its vertices of d(Le + Lr_dir + Lr_ind)/d(theta) . tangent is splatted with weight 1 into d_film_rgbw
+   (ACCUMULATED, like mi355_render_accumulate); mi355_film_develop of that accumulator is the gradient image.  path and prb
+   share it (the path integrator differentiates through the same estimator). */
+int mi355_render_forward(mi355_scene *scene, const mi355_render_params *p,
+                         const float *d_tangent_params, float *d_film_rgbw, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 

@@ -1246,14 +1246,18 @@ MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_dept
 // vector load would have to wait for them (vmcnt retires in order).
 // One record (8 dwords) per textured vertex: texture id, texel ids of the (0,0) and (1,1) taps, the two lerp weights and
 // dLoss/d(albedo rgb); the other two taps and the 12 (tap, channel) atomics are expanded at flush time.
-struct GradSink { float *s_grad; float *g_grad; float *q; uint32_t *qn; uint32_t qcap; };
+struct GradSink { float *s_grad; float *g_grad; float *q; uint32_t *qn; uint32_t qcap; const uint32_t *small_map; };
 
-template <bool BACKWARD, bool FULL>
+// FWD (with BACKWARD): prb.py in dr.ADMode.Forward, driven by RBIntegrator.render_forward (common.py:498-629).  The same second walk
+// with L = state_in, but every d(Le + Lr_dir + Lr_ind)/d(theta) is contracted with the parameter TANGENT (sink.g_grad, laid out like the
+// gradient buffer; sink.small_map resolves the constant parameters) and summed into the lane's dL, returned in L_out.
+template <bool BACKWARD, bool FULL, bool FWD = false>
 MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                        bool active, uint32_t *stk, v3 dL, v3 state_in, GradSink sink,
                        v3 &L_out, bool &valid_out, Counters3 &cnt) {
     uint32_t depth = 0; v3 L = BACKWARD ? state_in : V3(0.f, 0.f, 0.f); v3 beta = V3(1.f, 1.f, 1.f); float eta = 1.f;
     v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    v3 fwd_acc = V3(0.f, 0.f, 0.f);                                          // FWD: the lane's dL
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
         cnt.isect += wave_count(active);
@@ -1280,6 +1284,12 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                 // last vertex (uniform over the wave): active_next is false for every lane, so Lr_dir = 0, the BSDF sample is
                 // unused and bsdf.eval(..., active_next) = 0 -- only Le and its emitter gradient remain (prb.py:134,173,230).
                 L = BACKWARD ? L - Le : L + Le;
+                if (FWD) {
+                    if (emitter >= 0 && le_front && sc.emitters[emitter].grad_slot >= 0) {
+                        const uint32_t *sm = sink.small_map + sc.emitters[emitter].grad_slot;
+                        fwd_acc = fwd_acc + (beta * le_mis) * V3(sink.g_grad[sm[0]], sink.g_grad[sm[1]], sink.g_grad[sm[2]]);
+                    }
+                } else
                 if (BACKWARD && emitter >= 0 && le_front && sc.emitters[emitter].grad_slot >= 0) {
                     float *gb = sink.s_grad + sc.emitters[emitter].grad_slot;
                     atomicAdd(gb + 0, dL.x * beta.x * le_mis); atomicAdd(gb + 1, dL.y * beta.y * le_mis); atomicAdd(gb + 2, dL.z * beta.z * le_mis);
@@ -1334,6 +1344,32 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                 float dval_em = em_act ? MI_INV_PI * wo.z : 0.f;
                 dLo = dLo + ((beta_pre * mis_em) * dval_em) * em_weight;   // d Lr_dir / d albedo
                 v3 ga = dL * dLo;
+                if (FWD) {
+                    v3 dalb = V3(0.f, 0.f, 0.f);
+                    if (is_diffuse && bsdf.texture >= 0) {
+                        const DTexture &tx = sc.textures[bsdf.texture];
+                        const float *tb = sink.g_grad + tx.grad_offset;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (tx.grad_slot >= 0 && taps.idx[k] >= 0) {
+                            if (tx.c == 3) { dalb.x = fmaf(taps.w[k], tb[taps.idx[k] * 3 + 0], dalb.x); dalb.y = fmaf(taps.w[k], tb[taps.idx[k] * 3 + 1], dalb.y);
+                                             dalb.z = fmaf(taps.w[k], tb[taps.idx[k] * 3 + 2], dalb.z); }
+                            else { float v = taps.w[k] * tb[taps.idx[k]]; dalb = dalb + V3(v, v, v); }
+                        }
+                    } else if (is_diffuse && bsdf.grad_slot >= 0) {
+                        const uint32_t *sm = sink.small_map + bsdf.grad_slot;
+                        dalb = V3(sink.g_grad[sm[0]], sink.g_grad[sm[1]], sink.g_grad[sm[2]]);
+                    }
+                    if (is_diffuse) fwd_acc = fwd_acc + dLo * dalb;      // (other lobes carry no parameter; their inv * 0 may be NaN)
+                    if (emitter >= 0 && le_front && sc.emitters[emitter].grad_slot >= 0) {          // d Le / d radiance
+                        const uint32_t *sm = sink.small_map + sc.emitters[emitter].grad_slot;
+                        fwd_acc = fwd_acc + (beta_pre * le_mis) * V3(sink.g_grad[sm[0]], sink.g_grad[sm[1]], sink.g_grad[sm[2]]);
+                    }
+                    if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
+                        const uint32_t *sm = sink.small_map + sc.emitters[ds.emitter].grad_slot;
+                        v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
+                        fwd_acc = fwd_acc + w * V3(sink.g_grad[sm[0]], sink.g_grad[sm[1]], sink.g_grad[sm[2]]);
+                    }
+                } else {
                 bool textured = is_diffuse && bsdf.texture >= 0 && sc.textures[bsdf.texture < 0 ? 0 : bsdf.texture].grad_slot >= 0 && sink.g_grad != nullptr;
                 // (nearest-filter lookups have one tap and take the direct path; a slot that is allocated must be written)
                 bool queued = textured && sc.textures[bsdf.texture].c == 3 && sink.q != nullptr && taps.idx[3] >= 0;
@@ -1379,13 +1415,14 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
                     v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
                     atomicAdd(gb + 0, dL.x * w.x); atomicAdd(gb + 1, dL.y * w.y); atomicAdd(gb + 2, dL.z * w.z);
                 }
+                }
             }
             depth += 1;                                                    // prb.py:249
             active = active_next;
         }
         cnt.shadow += wave_count(shadow_req);
     }
-    L_out = L; valid_out = depth != 0;
+    L_out = FWD ? fwd_acc : L; valid_out = depth != 0;
 }
 
 // One bounce of PRBIntegrator.sample in PRIMAL mode (prb.py:59-257, same arithmetic as prb_sample<false>) on the path

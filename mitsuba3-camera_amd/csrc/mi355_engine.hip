@@ -464,6 +464,38 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
     gw[i] = make_float4(grad_in[3 * i] * inv, grad_in[3 * i + 1] * inv, grad_in[3 * i + 2] * inv, 0.f);
 }
 
+// RBIntegrator.render_forward (common.py:498-629): primal walk for L, forward-mode walk (same sampler stream) contracting every
+// d(Le + Lr_dir + Lr_ind)/d(theta) with the parameter tangents, dL splatted with weight 1 like a radiance sample.
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_render_forward(DScene sc, RenderArgs a, const float *tangent, const uint32_t *small_map,
+                                                                                      float *film, unsigned long long *g_counters) {
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    float *smem_wave = smem + wave * WAVE_FLOATS;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    LaneInfo li = lane_info(sc, a, i);
+    Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
+    float pos_x, pos_y; Ray ray;
+    float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
+    bool trace = li.act && cam_w > 0.f;
+    Counters3 cnt = {};
+    const bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
+    GradSink none = { nullptr, nullptr, nullptr, nullptr, 0, nullptr }, sink = { nullptr, const_cast<float *>(tangent), nullptr, nullptr, 0, small_map };
+    Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:578
+    v3 L, dl; bool valid;
+    prb_sample<false, FULL>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, trace, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
+    prb_sample<true, FULL, true>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, V3(1.f, 1.f, 1.f), L, sink, dl, valid, cnt);
+    dl = (trace ? dl : V3(0.f, 0.f, 0.f)) * cam_w;                          // value = dL * weight, common.py:604-611
+    __syncthreads();                                                        // traversal stack region is reused below
+    Splat sp = splat_weights(sc, pos_x, pos_y);
+    float values[4] = { dl.x, dl.y, dl.z, 1.f };
+    film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
@@ -1695,6 +1727,23 @@ extern "C" int mi355_prb_splat_weights(mi355_scene *s, const mi355_render_params
     if (a.n_local == 0) return MI355_OK;
     hipLaunchKernelGGL(k_splat_weights, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, a, d_weight);
     HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p, const float *d_tangent_params, float *d_film_rgbw, void *stream) {
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (!d_tangent_params || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    if (p->integrator != MI355_INTEGRATOR_PATH && p->integrator != MI355_INTEGRATOR_PRB) return fail(MI355_ERR_UNSUPPORTED, "render_forward is built for the path / prb integrators");
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0) return MI355_OK;
+    hipStream_t st = (hipStream_t) stream;
+    Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
+    if ((rc = tm.begin())) return rc;
+    const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_render_forward<true>, grid, block, 0, st, s->ds, a, d_tangent_params, (const uint32_t *) s->d_small_map, d_film_rgbw, s->d_counters);
+    else hipLaunchKernelGGL(k_render_forward<false>, grid, block, 0, st, s->ds, a, d_tangent_params, (const uint32_t *) s->d_small_map, d_film_rgbw, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tm.end())) return rc;
+    s->n_gen += a.n_local; s->n_splat += a.n_local;
     return MI355_OK;
 }
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,

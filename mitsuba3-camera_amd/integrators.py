@@ -223,6 +223,32 @@ class Integrator:
             grads += local
         return grads
 
+    # ---- Integrator::render_forward -----------------------------------------------------------------
+    def render_forward(self, scene, params, sensor=0, seed=0, spp=0, shard=None, group=None):
+        """Forward-mode derivative of the render (RBIntegrator.render_forward, common.py:498-629): returns the gradient image
+        (H x W x 3) for the parameter tangents set with `params.set_tangent(key, value)` -- the counterpart of dr.set_grad() on a
+        scene parameter.  With no tangent set the image is zero, as in the reference."""
+        torch = _torch()
+        be = self.backend
+        dev = be.device(scene)
+        f = scene.sensor.film
+        spp = self._resolve_spp(scene, spp)
+        if params is None:
+            raise PluginError("render_forward needs the SceneParameters carrying the tangents")
+        tangent = params.tangent_buffer(dev)
+        film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
+        band = shard_of(f, shard[0], shard[1]) if shard is not None else None
+        p = self._params(scene, seed, spp, shard=band)
+        p.integrator = abi.INTEGRATOR_PRB
+        if band is None or band[1] > 0:
+            abi.check(abi.lib().mi355_render_forward(scene.handle(), C.byref(p), C.c_void_p(tangent.data_ptr()), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
+        if shard is not None and shard[1] > 1:
+            import torch.distributed as dist
+            dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
+        img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
+        be.develop(scene, film, img)
+        return img
+
     def counters(self, scene, reset=False):
         c = abi.Counters()
         abi.check(abi.lib().mi355_get_counters(scene.handle(), C.byref(c), 1 if reset else 0))
@@ -265,6 +291,9 @@ class ParticleTracerIntegrator(Integrator):
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
         return super().render(scene, sensor, seed, spp, develop, evaluate, shard, group)
+
+    def render_forward(self, *a, **k):
+        raise PluginError("ptracer: render_forward is not built (render_backward for the emitter radiances is)")
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
         """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp for the EMITTER RADIANCES -- the parameter the
@@ -338,13 +367,14 @@ class SceneParameters:
         self._values = {}
         self._dirty = set()
         self._grads = None
+        self._tangents = None
         scene.handle()
         dev = torch.device("cuda", scene._device)
         layout, total = scene_param_layout(scene)
         self._layout = {(k, i): (off, size) for k, i, off, size in layout}
         self._total = total
         for i, b in enumerate(scene.bsdfs):
-            if b.texture is None:
+            if b.texture is None and (abi.PARAM_BSDF_REFLECTANCE, i) in self._layout:     # diffuse reflectances (the engine's layout)
                 self._add("%s.reflectance.value" % b.id, abi.PARAM_BSDF_REFLECTANCE, i, torch.tensor(b.reflectance, device=dev))
         for i, t in enumerate(scene.textures):
             self._add("%s.reflectance.data" % t.id, abi.PARAM_TEXTURE_DATA, i, torch.tensor(t.data, device=dev))
@@ -418,6 +448,25 @@ class SceneParameters:
         if self._grads is None or self._grads.device != device:
             self._grads = torch.zeros(max(self._total, 1), dtype=torch.float32, device=device)
         return self._grads
+
+    def set_tangent(self, key, value):
+        """dr.set_grad(params[key], value) for render_forward: the direction in parameter space along which the image is differentiated."""
+        torch = _torch()
+        kind, index, shape = self._entries[key]
+        off, size = self._layout[(kind, index)]
+        if self._tangents is None:
+            self._tangents = torch.zeros(max(self._total, 1), dtype=torch.float32, device=self._values[key].device)
+        v = torch.as_tensor(value, dtype=torch.float32, device=self._tangents.device)
+        self._tangents[off:off + size] = v.expand(shape).reshape(-1) if v.numel() != size else v.reshape(-1)
+
+    def clear_tangents(self):
+        self._tangents = None
+
+    def tangent_buffer(self, device):
+        torch = _torch()
+        if self._tangents is None or self._tangents.device != device:
+            self._tangents = torch.zeros(max(self._total, 1), dtype=torch.float32, device=device)
+        return self._tangents
 
     def zero_grad(self):
         if self._grads is not None:

@@ -1312,7 +1312,10 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
  * mode 0 = Primal (returns L), mode 1 = Backward (state_in = L, accumulates parameter
  * gradients; closed form of dr.backward_from(dL * Lo), see DESIGN.md "PRB adjoint")
  * ---------------------------------------------------------------------------------------- */
-typedef struct { float *grad; const mi355_param_info *layout; uint32_t n_params; const int32_t *bsdf_slot, *tex_slot, *em_slot; } GradCtx;
+typedef struct { float *grad; const mi355_param_info *layout; uint32_t n_params; const int32_t *bsdf_slot, *tex_slot, *em_slot;
+                 /* Forward mode (prb.py mode == dr.ADMode.Forward, driven by RBIntegrator.render_forward, common.py:498-629): `grad` is then
+                    READ as the tangent of every parameter and the walk accumulates dL = sum d(Le + Lr_dir + Lr_ind)/d(theta) * tangent */
+                 int forward; v3 *dl_acc; } GradCtx;
 
 static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_params *rp, int backward,
                        v3 dL, v3 state_in, const GradCtx *g, v3 *L_out, int *valid_out, Cnt *cnt) {
@@ -1385,6 +1388,32 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
             dLo_dalb = add3(dLo_dalb, mul3(scale3(scale3(beta_pre, mis_em), dval_em), em_weight));
             v3 ga = mul3(dL, dLo_dalb);
             uint32_t bidx = sc->shapes[si.shape].bsdf;
+            if (g->forward) {
+                v3 dalb = V3(0, 0, 0);
+                if (bsdf->reflectance_texture >= 0) {
+                    int32_t slot = g->tex_slot[bsdf->reflectance_texture];
+                    if (slot >= 0) {
+                        const OTexture *t = &sc->textures[bsdf->reflectance_texture];
+                        const float *tb = g->grad + g->layout[slot].offset;
+                        for (int k = 0; k < 4; ++k) if (tidx[k] >= 0) {
+                            if (t->c == 3) { dalb.x = fmaf(twgt[k], tb[tidx[k]*3+0], dalb.x); dalb.y = fmaf(twgt[k], tb[tidx[k]*3+1], dalb.y); dalb.z = fmaf(twgt[k], tb[tidx[k]*3+2], dalb.z); }
+                            else { float v = twgt[k] * tb[tidx[k]]; dalb.x += v; dalb.y += v; dalb.z += v; }
+                        }
+                    }
+                } else if (bsdf->type == MI355_BSDF_DIFFUSE && g->bsdf_slot[bidx] >= 0) {
+                    const float *tb = g->grad + g->layout[g->bsdf_slot[bidx]].offset; dalb = V3(tb[0], tb[1], tb[2]);
+                }
+                if (bsdf->type == MI355_BSDF_DIFFUSE) *g->dl_acc = add3(*g->dl_acc, mul3(dLo_dalb, dalb));   /* (other lobes carry no parameter; their inv * 0 may be NaN) */
+                if (emitter >= 0 && g->em_slot[emitter] >= 0 && le_front) {
+                    const float *tb = g->grad + g->layout[g->em_slot[emitter]].offset;
+                    *g->dl_acc = add3(*g->dl_acc, mul3(scale3(beta_pre, le_mis), V3(tb[0], tb[1], tb[2])));
+                }
+                if (active_em && ds.emitter >= 0 && g->em_slot[ds.emitter] >= 0 && dot3(ds.d, ds.n) < 0.f) {
+                    const float *tb = g->grad + g->layout[g->em_slot[ds.emitter]].offset;
+                    v3 w = scale3(mul3(scale3(beta_pre, mis_em), bsdf_value_em), rcpf_(ds.pdf));
+                    *g->dl_acc = add3(*g->dl_acc, mul3(w, V3(tb[0], tb[1], tb[2])));
+                }
+            } else {
             if (bsdf->reflectance_texture >= 0) {
                 int32_t slot = g->tex_slot[bsdf->reflectance_texture];
                 if (slot >= 0) {
@@ -1411,6 +1440,7 @@ static void prb_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_param
                 /* em_weight = em_val / ds.pdf (prb.py:154-155); ds.pdf already carries the emitter pmf (scene.cpp:324) */
                 v3 w = scale3(mul3(scale3(beta_pre, mis_em), bsdf_value_em), rcpf_(ds.pdf));
                 gb[0] += dL.x * w.x; gb[1] += dL.y * w.y; gb[2] += dL.z * w.z;
+            }
             }
         }
         depth += 1;                                                       /* prb.py:249 (si valid here) */
@@ -1967,6 +1997,59 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
     }
     for (int t = 0; t < n_threads; ++t) for (uint64_t i = 0; i < total; ++i) grad[i] += grads[total * (size_t) t + i];
     free(grads); free(bsdf_slot); free(tex_slot); free(em_slot);
+}
+
+/* RBIntegrator.render_forward (common.py:498-629): primal walk (1), forward-mode walk (2) with the same sampler stream, dL splatted
+   with weight 1 into an RGBW accumulator whose develop() is the gradient image.  `tangent` = one float per differentiable scene
+   float, laid out like the gradient buffer (orc_param_layout): what dr.set_grad() put on the parameters. */
+ORC_API uint64_t orc_render_forward(OScene *sc, const mi355_render_params *rp, const float *tangent, float *film_rgbw, int n_threads) {
+    uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
+    mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
+    int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1)), *em_slot = (int32_t *) malloc(4 * (sc->n_emitters + 1));
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) bsdf_slot[i] = -1;
+    for (uint32_t i = 0; i < sc->n_textures; ++i) tex_slot[i] = -1;
+    for (uint32_t i = 0; i < sc->n_emitters; ++i) em_slot[i] = -1;
+    for (int i = 0; i < np; ++i) {
+        if (layout[i].kind == MI355_PARAM_BSDF_REFLECTANCE) bsdf_slot[layout[i].index] = i;
+        else if (layout[i].kind == MI355_PARAM_TEXTURE_DATA) tex_slot[layout[i].index] = i;
+        else em_slot[layout[i].index] = i;
+    }
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
+    float *films = (float *) calloc(fsz * (size_t) n_threads, sizeof(float));
+    #pragma omp parallel num_threads(n_threads)
+    {
+#ifdef _OPENMP
+        float *film = films + fsz * (size_t) omp_get_thread_num();
+#else
+        float *film = films;
+#endif
+        Cnt cnt = { 0, 0, 0 };
+        #pragma omp for schedule(dynamic, 64)
+        for (int64_t q = 0; q < (int64_t) pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
+            uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;
+            pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+            v2 sp; Ray ray; float cw = camera_ray(sc, &rng, lane, rp->spp, &sp, &ray);
+            v3 dl = V3(0, 0, 0);
+            if (cw != 0.f) {
+                pcg32 rng2 = rng;                                            /* sampler.clone(), common.py:578 */
+                v3 L; int valid;
+                prb_sample(sc, &rng2, ray, rp, 0, V3(0,0,0), V3(0,0,0), NULL, &L, &valid, &cnt);
+                GradCtx g = { (float *) tangent, layout, (uint32_t) np, bsdf_slot, tex_slot, em_slot, 1, &dl };
+                v3 L2;
+                prb_sample(sc, &rng, ray, rp, 1, V3(1, 1, 1), L, &g, &L2, &valid, &cnt);
+            }
+            float vals[4] = { dl.x * cw, dl.y * cw, dl.z * cw, 1.f };       /* value = dL * weight, weight = 1 (common.py:604-611) */
+            film_put(sc, film, 4, sp, vals);
+        }
+    }
+    for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
+    free(films); free(bsdf_slot); free(tex_slot); free(em_slot);
+    return (uint64_t) pn * sn;
 }
 
 /* ----------------------------------------------------------------------------------------

@@ -62,6 +62,8 @@ def lib(abi):
     l.orc_param_layout.argtypes = [C.c_void_p, C.POINTER(abi.ParamInfo), C.c_uint32, C.POINTER(C.c_uint64)]
     l.orc_prb_splat_weights.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p]
     l.orc_render_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_render_forward.restype = C.c_uint64
+    l.orc_render_forward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int]
     l.orc_ptracer_backward.restype = C.c_uint64
     l.orc_ptracer_backward.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int]
     l.orc_ray_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -159,6 +161,14 @@ class OracleScene:
         grad_in = np.ascontiguousarray(grad_in, dtype=np.float32); weight = np.ascontiguousarray(weight, dtype=np.float32)
         self.l.orc_render_backward(self.h, C.byref(p), _p(grad_in), _p(weight), _p(g), threads)
         return g
+
+    def render_forward(self, p, tangent, threads=0, develop=True):
+        """RBIntegrator.render_forward (common.py:498-629): gradient image for the parameter tangent `tangent` (gradient-buffer layout)."""
+        _, total = self.param_layout()
+        tangent = np.ascontiguousarray(tangent, dtype=np.float32); assert tangent.size == max(total, 1)
+        film = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        self.l.orc_render_forward(self.h, C.byref(p), _p(tangent), _p(film), threads)
+        return self.develop(film) if develop else film
 
     def ptracer_backward(self, p, grad_in, threads=0):
         """Integrator::render_backward (integrator.cpp:65-84) of the particle tracer, emitter radiances only."""

@@ -592,6 +592,60 @@ def test_mesh_emitter_and_smooth_conductor(mi, orc, torch_cuda, integrator_name)
     assert np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
 
 
+@pytest.mark.parametrize("scene_name", ["cbox-textured", "veach"])
+def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
+    """Integrator::render_forward (k_render_forward): the gradient image against the oracle's for a random tangent over ALL parameters,
+    the transpose identity <g, J v> == <J^T g, v> against the device's own render_backward, the reference's finite-difference check
+    (test_ad_integrators.py:742-786) against the device's own primal renders, shards adding up, and zero tangents -> zero image."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    if scene_name == "veach":
+        scene = mi.load_dict(mi.veach_mis_scene(32)); props = {"max_depth": 5, "rr_depth": 2}
+    else:
+        scene = mi.load_dict(_textured_cbox(mi)); props = {"max_depth": 6, "rr_depth": 3}
+    integ = mi.PRBIntegrator(props)
+    o = orc.OracleScene(scene, mi.abi)
+    params = mi.traverse(scene)
+    lay, total = o.param_layout()
+    v = rng.normal(size=total).astype(np.float32)
+    for key in params.keys():
+        kind, index, shape = params._entries[key]; off, size = params._layout[(kind, index)]
+        params.set_tangent(key, torch.tensor(v[off:off + size].reshape(shape)))
+    gimg = integ.render_forward(scene, params, seed=5, spp=32).cpu().numpy()
+    ref = o.render_forward(o.params(integ, 5, 32), v)
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.percentile(np.abs(gimg - ref), 99.5) < 2e-3 * scale and abs(gimg.sum() / ref.sum() - 1) < 5e-3
+    gin = rng.normal(size=gimg.shape).astype(np.float32)
+    g = integ.render_backward(scene, params, torch.tensor(gin), seed=5, spp=32).cpu().numpy()
+    a, b = float((gimg.astype(np.float64) * gin).sum()), float((g.astype(np.float64) * v).sum())
+    assert abs(a - b) < 2e-3 * max(abs(a), abs(b)), (a, b)
+    # shards of the sample plane: the accumulators add up
+    f = scene.sensor.film; acc = torch.zeros((f.crop_height, f.crop_width, 4), device="cuda")
+    for r in range(2):
+        p = integ._params(scene, 5, 32, shard=mi.shard_tiles(f.crop_width, f.crop_height, r, 2, rows=8)); p.integrator = mi.abi.INTEGRATOR_PRB
+        mi.abi.check(mi.abi.lib().mi355_render_forward(scene.handle(), C.byref(p), C.c_void_p(params.tangent_buffer(acc.device).data_ptr()), C.c_void_p(acc.data_ptr()), None))
+    img2 = torch.empty((f.crop_height, f.crop_width, 3), device="cuda")
+    mi.abi.check(mi.abi.lib().mi355_film_develop(scene.handle(), C.c_void_p(acc.data_ptr()), C.c_void_p(img2.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.allclose(img2.cpu().numpy(), gimg, rtol=1e-3, atol=1e-4 * scale)
+    params.clear_tangents()
+    assert (integ.render_forward(scene, params, seed=5, spp=8).cpu().numpy() == 0).all()
+    if scene_name == "cbox-textured":       # finite differences of one wall colour with the roulette off: the estimator is polynomial in it
+        integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 100})
+        key = [k for k in params.keys() if params._entries[k][0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
+        t = torch.tensor([1.0, 0.5, -0.25], device="cuda")
+        params.set_tangent(key, t)
+        gimg = integ.render_forward(scene, params, seed=9, spp=256).cpu().numpy()
+        base = params[key].clone(); eps = 1e-2
+        params[key] = base + eps * t; params.update(); hi = integ.render(scene, seed=9, spp=256).cpu().numpy().astype(np.float64)
+        params[key] = base - eps * t; params.update(); lo = integ.render(scene, seed=9, spp=256).cpu().numpy().astype(np.float64)
+        params[key] = base; params.update()
+        fd = (hi - lo) / (2 * eps)
+        assert np.abs(fd).max() > 0 and np.allclose(gimg, fd, rtol=1e-2, atol=2e-3 * np.abs(fd).max())
+        with pytest.raises(mi.PluginError):
+            mi.ParticleTracerIntegrator({}).render_forward(scene, params)
+
+
 # ---- scope row (f)-3, forward part: the particle tracer ----------------------------------------------------------
 @pytest.mark.parametrize("case", ["cbox-box", "cbox-gaussian-crop", "veach", "hide", "lens"])
 def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):

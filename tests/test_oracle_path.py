@@ -309,3 +309,37 @@ def test_particle_tracer_radiance_gradient_is_exact(mi, orc):
         nz = rads[e] != 0
         assert np.allclose(g[off:off + 3][nz], (expect / np.where(nz, rads[e], 1))[nz], rtol=2e-3, atol=1e-4), (e, g[off:off + 3], expect)
         assert np.isfinite(g[off:off + 3]).all() and (g[off:off + 3][~nz] != 0).all()   # a zero channel still has a derivative
+
+
+def test_render_forward_is_the_transpose_of_render_backward(mi, orc):
+    """RBIntegrator.render_forward (common.py:498-629; prb.py forward mode) restated in the oracle: for any parameter tangent v and any
+    image adjoint g,  <g, J v> == <J^T g, v>  with the same seeds (both walks evaluate the same per-vertex derivatives), and the
+    gradient image of a single albedo matches a central finite difference of the primal image (the reference's own check,
+    test_ad_integrators.py:742-786) -- exactly so while the roulette is off, because the estimator is then polynomial in the albedo."""
+    rng = np.random.default_rng(3)
+    d = small_cbox(mi, 16)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "data": rng.uniform(0.2, 0.8, (8, 8, 3)).astype(np.float32)}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.PRBIntegrator({"max_depth": 5, "rr_depth": 3})
+    lay, total = o.param_layout()
+    v = rng.normal(size=total).astype(np.float32)
+    gin = rng.normal(size=(16, 16, 3)).astype(np.float32)
+    p = o.params(integ, 4, 64)
+    jv = o.render_forward(p, v)
+    jtg = o.render_backward(p, gin)
+    a, b = float((jv.astype(np.float64) * gin).sum()), float((jtg.astype(np.float64) * v).sum())
+    assert abs(a - b) < 1e-4 * max(abs(a), abs(b)), (a, b)
+    assert (o.render_forward(p, np.zeros(total, dtype=np.float32)) == 0).all()          # no tangent, zero gradient image
+    # finite differences of one wall colour, roulette off
+    integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 100})
+    p = o.params(integ, 9, 128)
+    kind, index, off, size = [l for l in lay if l[0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
+    t = np.zeros(total, dtype=np.float32); t[off:off + 3] = (1.0, 0.5, -0.25)
+    gimg = o.render_forward(p, t)
+    base = np.array(sc.bsdfs[index].reflectance, dtype=np.float32); eps = 1e-2
+    o.set_param(kind, index, base + eps * t[off:off + 3]); hi, _ = o.render(p)
+    o.set_param(kind, index, base - eps * t[off:off + 3]); lo, _ = o.render(p)
+    o.set_param(kind, index, base)
+    fd = (hi.astype(np.float64) - lo) / (2 * eps)
+    assert np.abs(gimg).max() > 0 and np.allclose(gimg, fd, rtol=5e-3, atol=5e-4 * np.abs(fd).max())
