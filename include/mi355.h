@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 5u
+#define MI355_ABI_VERSION 6u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -144,6 +144,9 @@ typedef struct mi355_sensor_desc {
     uint32_t sample_exit_pupil;         /* realisticlens `sample_exit_pupil` (:851): aim at the exit-pupil bounds of the film point's radius
                                            (LUT of 64 x 2^20 traced rays, :1685-1806, built at scene creation) instead of the whole rear
                                            element; ray weight = shutter_open_time * bounds_area / z_rear^2 (:2282-2285) */
+    uint32_t sample_border;             /* Film::sample_border (film.cpp:32): the lanes of the sampling integrators cover the crop window grown by
+                                           the filter's border_size = ceil(radius - 0.5 - 2 RayEps) (rfilter.cpp:23) on every side
+                                           (integrator.cpp:133-134, :307-308; common.py:255-278), so edge pixels receive their full footprint */
 } mi355_sensor_desc;
 
 typedef struct mi355_scene_desc {

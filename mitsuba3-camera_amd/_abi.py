@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -63,7 +63,7 @@ class SensorDesc(C.Structure):
                 ("rfilter", C.c_uint32), ("rfilter_param", C.c_float),
                 ("lens_count", C.c_uint32), ("lens_data", f32p),
                 ("film_diagonal", C.c_float), ("focus_distance", C.c_float),
-                ("shutter_open_time", C.c_float), ("sample_exit_pupil", C.c_uint32)]
+                ("shutter_open_time", C.c_float), ("sample_exit_pupil", C.c_uint32), ("sample_border", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

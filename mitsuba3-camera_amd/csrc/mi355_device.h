@@ -122,6 +122,7 @@ struct DScene {
     float camera_to_sample[16];   // perspective sensor, particle tracer: sample_direction (perspective.cpp:282-340)
     float image_rect[4], normalization;   // lo.x, lo.y, hi.x, hi.y of the image plane at z = 1 and 1 / its area (perspective.cpp:190-199)
     float shutter_open_time;      // > 0: one extra sampler draw per sample for the time (integrator.cpp:442-444)
+    uint32_t grid_w, grid_h, border;                                       // lane grid of the sampling integrators: crop window + 2 * border (Film::sample_border)
     uint32_t sample_exit_pupil; float film_diagonal; const float *pupil;   // exit-pupil bounds, 64 x (min.x, min.y, max.x, max.y)
 };
 

@@ -85,8 +85,8 @@ MI_DEV LaneInfo lane_info(const DScene &sc, const RenderArgs &a, uint32_t i) {
     li.pixel = shard_pixel(a, ii / a.s_count);
     uint32_t s = a.s_begin + ii % a.s_count;
     li.lane = li.pixel * a.spp_total + s;
-    uint32_t y = li.pixel / sc.crop_w;
-    li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
+    uint32_t y = li.pixel / sc.grid_w;                                     // pos -= border_size, integrator.cpp:307-308
+    li.py = (int32_t) (y + sc.crop_y) - (int32_t) sc.border; li.px = (int32_t) (li.pixel - y * sc.grid_w + sc.crop_x) - (int32_t) sc.border;
     return li;
 }
 
@@ -131,7 +131,7 @@ MI_DEV void film_splat(const DScene &sc, const RenderArgs &a, float *smem_wave, 
             uint32_t ig = i_wave_first + g * seg;
             if (ig < a.n_local && sum != 0.f) {
                 uint32_t pixel = shard_pixel(a, ig / a.s_count);
-                int32_t py = (int32_t) (pixel / sc.crop_w), px = (int32_t) (pixel - (uint32_t) py * sc.crop_w);
+                int32_t py = (int32_t) (pixel / sc.grid_w), px = (int32_t) (pixel - (uint32_t) py * sc.grid_w) - (int32_t) sc.border; py -= (int32_t) sc.border;
                 int32_t x = px - n + (int32_t) (t % 5u), y = py - n + (int32_t) (t / 5u);
                 if (x >= 0 && y >= 0 && x < W && y < H) atomicAdd(film + ((size_t) y * W + x) * CH + c, sum);
             }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
     if (OUT == OUT_LANES) {   // lanes of the whole job, no sharding
         li.act = i < a.n_local; li.lane = a.lane_begin + (li.act ? i : 0);
         li.pixel = li.lane / a.spp_total;
-        uint32_t y = li.pixel / sc.crop_w; li.py = (int32_t) (y + sc.crop_y); li.px = (int32_t) (li.pixel - y * sc.crop_w + sc.crop_x);
+        uint32_t y = li.pixel / sc.grid_w; li.py = (int32_t) (y + sc.crop_y) - (int32_t) sc.border; li.px = (int32_t) (li.pixel - y * sc.grid_w + sc.crop_x) - (int32_t) sc.border;
     } else li = lane_info(sc, a, i);
     Counters3 cnt = {};
     PROF_START(cnt);
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen
             const uint32_t remaining = a.s_count - s_next;
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
             const uint32_t pixel = shard_pixel(a, q);                          // wave-uniform
-            const uint32_t y = pixel / scl.crop_w;
-            const int32_t py = (int32_t) (y + scl.crop_y), px = (int32_t) (pixel - y * scl.crop_w + scl.crop_x);
+            const uint32_t y = pixel / scl.grid_w;
+            const int32_t py = (int32_t) (y + scl.crop_y) - (int32_t) scl.border, px = (int32_t) (pixel - y * scl.grid_w + scl.crop_x) - (int32_t) scl.border;
             if (!active && rank < remaining) {
                 uint32_t lane = pixel * a.spp_total + a.s_begin + s_next + rank;   // global lane id, integrator.cpp:293-305
                 Pcg32 rng; sampler_seed(rng, a.seed, lane);
@@ -1432,6 +1432,11 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     memcpy(ds.cam_to_world, se.to_world, 48);
     ds.near_clip = se.near_clip; ds.far_clip = se.far_clip;
     ds.crop_w = se.crop_width; ds.crop_h = se.crop_height; ds.crop_x = se.crop_offset_x; ds.crop_y = se.crop_offset_y;
+    {   // Film::sample_border: border_size = ceil(radius - 0.5 - 2 RayEps), rfilter.cpp:23
+        const float radius = se.rfilter == MI355_RFILTER_BOX ? 0.5f : (se.rfilter == MI355_RFILTER_GAUSSIAN ? 4.f * se.rfilter_param : se.rfilter_param);
+        ds.border = se.sample_border ? (uint32_t) std::max(0.f, ceilf(radius - .5f - 2.f * MI_RAY_EPS)) : 0u;
+        ds.grid_w = ds.crop_w + 2u * ds.border; ds.grid_h = ds.crop_h + 2u * ds.border;
+    }
     ds.rfilter = se.rfilter;
     if (se.rfilter == MI355_RFILTER_GAUSSIAN) { mi355_gaussian_coeffs(se.rfilter_param, ds.filter_coeff); ds.filter_radius = 4.f * se.rfilter_param; }
     else if (se.rfilter == MI355_RFILTER_TENT) ds.filter_radius = se.rfilter_param;
@@ -1566,7 +1571,7 @@ extern "C" int mi355_scene_param_layout(const mi355_scene *s, mi355_param_info *
 static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderArgs *a) {
     if (!s || !p) return fail(MI355_ERR_INVALID, "null argument");
     // lanes cover the crop window, except for the particle tracer: the whole film (integrator.cpp:575-577)
-    uint32_t npix = p->integrator == MI355_INTEGRATOR_PTRACER ? s->ds.film_w * s->ds.film_h : s->ds.crop_w * s->ds.crop_h;
+    uint32_t npix = p->integrator == MI355_INTEGRATOR_PTRACER ? s->ds.film_w * s->ds.film_h : s->ds.grid_w * s->ds.grid_h;
     if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
     // samples_per_pass (integrator.cpp:565-573, :700-726): spp / passes sampler streams per pixel, `passes` samples from each
     const uint32_t passes = p->passes ? p->passes : 1u;
@@ -1842,7 +1847,7 @@ extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
 extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_params *p, uint32_t lane_begin, uint32_t count, float *d_out, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_out) return fail(MI355_ERR_INVALID, "null output");
-    uint64_t total = (uint64_t) s->ds.crop_w * s->ds.crop_h * p->spp;
+    uint64_t total = (uint64_t) s->ds.grid_w * s->ds.grid_h * p->spp;
     if ((uint64_t) lane_begin + count > total) return fail(MI355_ERR_INVALID, "lane range outside the job");
     HIP_TRY(hipSetDevice(s->device));
     if (!count) return MI355_OK;

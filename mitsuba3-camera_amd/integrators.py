@@ -128,8 +128,10 @@ class Integrator:
         return []
 
     def lane_grid(self, film):
-        """Pixel grid the lanes are laid over: lane = pixel * spp + s (crop window for sampling integrators)."""
-        return film.crop_width, film.crop_height
+        """Pixel grid the lanes are laid over: lane = pixel * spp + s -- the crop window of a sampling integrator, grown by the
+        filter's border on every side when the film samples its border (integrator.cpp:133-134)."""
+        b = film.border_size if film.sample_border else 0
+        return film.crop_width + 2 * b, film.crop_height + 2 * b
 
     # ---- parameter block for the C ABI -----------------------------------------------------------
     def _params(self, scene, seed, spp, shard=None, spp_shard=None):
@@ -202,7 +204,7 @@ class Integrator:
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
         if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
             raise ValueError("grad_in must have shape (H, W, 3)")
-        band = shard_of(f, shard[0], shard[1]) if shard is not None else None
+        band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
         p = self._params(scene, seed, spp, shard=band)
         p.integrator = abi.INTEGRATOR_PRB
         weight = torch.zeros((f.crop_height, f.crop_width), dtype=torch.float32, device=dev)
@@ -237,7 +239,7 @@ class Integrator:
             raise PluginError("render_forward needs the SceneParameters carrying the tangents")
         tangent = params.tangent_buffer(dev)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
-        band = shard_of(f, shard[0], shard[1]) if shard is not None else None
+        band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
         p = self._params(scene, seed, spp, shard=band)
         p.integrator = abi.INTEGRATOR_PRB
         if band is None or band[1] > 0:

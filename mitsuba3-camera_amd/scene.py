@@ -328,6 +328,9 @@ class Film:
         else:
             raise PluginError('rfilter plugin "%s" is outside the path (box, gaussian, tent)' % rt)
 
+        self.sample_border = bool(props.get("sample_border", False))         # film.cpp:32
+        # ReconstructionFilter::border_size (rfilter.cpp:23), RayEpsilon = 1500 * 2^-24 (math.h:17-23)
+        self.border_size = int(math.ceil(np.float32(self.radius) - np.float32(0.5) - np.float32(2.0) * np.float32(1500.0 * 2.0 ** -24)))
         self.diagonal = 0.001 * float(props.get("diagonal", 35.0))          # fork: physical film diagonal [m], film.cpp:46-48
 
     def physical_size(self):
@@ -443,6 +446,7 @@ class Scene:
         d.sensor.film_diagonal = f.diagonal
         d.sensor.to_world[:] = se.to_world.affine12().tolist()
         d.sensor.shutter_open_time = se.shutter_open_time; d.sensor.sample_exit_pupil = 1 if se.sample_exit_pupil else 0
+        d.sensor.sample_border = 1 if se.film.sample_border else 0
         d.sensor.x_fov, d.sensor.near_clip, d.sensor.far_clip = se.x_fov, se.near_clip, se.far_clip
         d.sensor.film_width, d.sensor.film_height = f.width, f.height
         d.sensor.crop_offset_x, d.sensor.crop_offset_y = f.crop_offset_x, f.crop_offset_y

@@ -290,6 +290,7 @@ typedef struct {
     mi355_sensor_desc sensor;
     float sample_to_camera[16], camera_to_sample[16];
     float filter_coeff[10]; float filter_radius;
+    uint32_t border;                                        /* Film::sample_border ? ReconstructionFilter::border_size : 0 */
     float *lens; uint32_t lens_count; float film_px, film_py;   /* realisticlens: interface table, physical half extents */
     float pupil[64 * 4];                                          /* exit-pupil bounds (min.x, min.y, max.x, max.y) per film-radius segment */
     uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
@@ -374,6 +375,10 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
         orc_gaussian_coeffs(d->sensor.rfilter_param, s->filter_coeff); s->filter_radius = 4.f * d->sensor.rfilter_param;
     } else if (d->sensor.rfilter == MI355_RFILTER_TENT) s->filter_radius = d->sensor.rfilter_param;
     else s->filter_radius = 0.5f;
+    {   /* rfilter.cpp:23: border_size = ceil(radius - 0.5 - 2 RayEps) */
+        float bs = ceilf(s->filter_radius - .5f - 2.f * RAY_EPS);
+        s->border = d->sensor.sample_border ? (uint32_t) (bs > 0.f ? bs : 0.f) : 0u;
+    }
     return s;
 }
 ORC_API void orc_scene_destroy(OScene *s) {
@@ -1041,8 +1046,9 @@ static float pdf_emitter_direction(const OScene *sc, int32_t emitter, v3 ref_p, 
  * PerspectiveCamera::sample_ray_differential (perspective.cpp:239-280)
  * ---------------------------------------------------------------------------------------- */
 static void lane_to_pixel(const OScene *sc, uint32_t lane, uint32_t spp, int32_t *px, int32_t *py) {
-    uint32_t idx = lane / spp, W = sc->sensor.crop_width;                /* integrator.cpp:293-310 */
+    uint32_t b = sc->border, idx = lane / spp, W = sc->sensor.crop_width + 2u * b;   /* integrator.cpp:293-310; film_size += 2 border :133-134 */
     *py = (int32_t) (idx / W); *px = (int32_t) (idx - W * (idx / W));
+    *px -= (int32_t) b; *py -= (int32_t) b;                              /* pos -= border_size, :307-308 */
     *px += (int32_t) sc->sensor.crop_offset_x; *py += (int32_t) sc->sensor.crop_offset_y;
 }
 static Ray sample_primary_ray(const OScene *sc, v2 sample_pos) {
@@ -1838,7 +1844,7 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
  * drivers
  * ---------------------------------------------------------------------------------------- */
 static void shard_bounds(const OScene *sc, const mi355_render_params *rp, uint32_t *p0, uint32_t *pn, uint32_t *s0, uint32_t *sn) {
-    uint32_t npix = sc->sensor.crop_width * sc->sensor.crop_height;
+    uint32_t npix = (sc->sensor.crop_width + 2u * sc->border) * (sc->sensor.crop_height + 2u * sc->border);
     *p0 = rp->pixel_begin; *pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin;
     *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : rp->spp - rp->spp_begin;
 }

@@ -343,3 +343,22 @@ def test_render_forward_is_the_transpose_of_render_backward(mi, orc):
     o.set_param(kind, index, base)
     fd = (hi.astype(np.float64) - lo) / (2 * eps)
     assert np.abs(gimg).max() > 0 and np.allclose(gimg, fd, rtol=5e-3, atol=5e-4 * np.abs(fd).max())
+
+
+def test_film_sample_border(mi, orc):
+    """Film::sample_border (film.cpp:32; integrator.cpp:133-134, :307-308; common.py:255-278): the lane grid grows by the filter's
+    border_size = ceil(radius - 0.5 - 2 RayEps) (rfilter.cpp:23) on every side, so that edge pixels collect their full footprint."""
+    for rf, b in (({"type": "gaussian"}, 2), ({"type": "gaussian", "stddev": 0.3}, 1), ({"type": "tent"}, 1), ({"type": "box"}, 0)):
+        sc = mi.load_dict(small_cbox(mi, 12, rfilter=rf, sample_border=True))
+        assert sc.sensor.film.border_size == b
+        integ = mi.PathIntegrator({"max_depth": 3})
+        assert integ.lane_grid(sc.sensor.film) == (12 + 2 * b, 12 + 2 * b)
+        o = orc.OracleScene(sc, mi.abi)
+        img, lanes = o.render(o.params(integ, 1, 8))
+        assert lanes == (12 + 2 * b) ** 2 * 8 and np.isfinite(img).all()
+    on = mi.load_dict(small_cbox(mi, 12, sample_border=True)); off = mi.load_dict(small_cbox(mi, 12))
+    integ = mi.PRBIntegrator({"max_depth": 3})
+    w_on = orc.OracleScene(on, mi.abi); w_off = orc.OracleScene(off, mi.abi)
+    W_on = w_on.splat_weights(w_on.params(integ, 0, 256)); W_off = w_off.splat_weights(w_off.params(integ, 0, 256))
+    assert abs(W_on[0, 0] / W_on[6, 6] - 1) < 0.05 and W_off[0, 0] / W_off[6, 6] < 0.8          # corner: full footprint vs the part of it that lies inside the window
+    assert np.allclose(W_on[4:8, 4:8], W_off[4:8, 4:8], rtol=0.1)
