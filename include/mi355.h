@@ -172,9 +172,9 @@ typedef struct mi355_scene_desc {
 #define MI355_FLAG_EMITTER_GRADS_ONLY 16u /* render_backward with MI355_INTEGRATOR_PTRACER: the caller acknowledges that only the
                                           MI355_PARAM_EMITTER_RADIANCE slots are written; without it that call is MI355_ERR_UNSUPPORTED */
 
-#define MI355_FLAG_DIRECT_SPLAT   32u  /* particle tracer, film filters with more than one tap: splat every connection with direct float
-                                          atomics instead of the default deferred, tile-sorted splat (same film up to summation order;
-                                          a debugging / comparison switch -- 234 ms against 2x ms on the Cornell box) */
+#define MI355_FLAG_DIRECT_SPLAT   32u  /* particle tracer: splat every connection with direct float atomics instead of the default deferred,
+                                          tile-sorted splat (same film up to summation order; a debugging / comparison switch -- Gaussian
+                                          filter 234.6 ms against 7.1 ms on the Cornell box 512^2 x 64 spp) */
 
 enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path state in registers; the path integrator re-packs the
                                           live paths of a workgroup (wave ballot + prefix sum, SoA state exchanged through LDS) from

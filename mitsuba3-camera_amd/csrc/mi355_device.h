@@ -1785,7 +1785,11 @@ MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, floa
 // atomics, so the film is complete whatever the capacity.
 #define MI_SPLAT_TILE 16
 #define MI_SPLAT_APRON 2                                                    // (MI_MAX_TAPS - 1) / 2
-struct SplatQueue { float4 *rec_a; float *rec_b; uint32_t *count; uint32_t *hist; uint32_t cap, tiles_x, tiles_y; };
+// The queue is cut into MI_SPLAT_SEGS segments, each with its own append counter (a workgroup appends to segment blockIdx % SEGS): one
+// counter for the whole launch would take ~1 M same-address atomics, ~4 ns each.  Counters sit 128 B apart.
+#define MI_SPLAT_SEGS 256u
+#define MI_SPLAT_COUNTER_STRIDE 32u
+struct SplatQueue { float4 *rec_a; float *rec_b; uint32_t *count; uint32_t *hist; uint32_t cap, seg_cap, tiles_x, tiles_y; };
 MI_DEV uint32_t splat_tile_of(const DScene &sc, const SplatQueue &q, float pos_x, float pos_y) {
     // tile of the centre pixel, clamped into the crop window (taps that stick out of the window are dropped anyway)
     int32_t cx = (int32_t) floorf(pos_x) - (int32_t) sc.crop_x, cy = (int32_t) floorf(pos_y) - (int32_t) sc.crop_y;
@@ -1804,10 +1808,12 @@ MI_DEV void film_put_deferred(const DScene &sc, const SplatQueue &q, float *film
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
     const uint32_t leader = (uint32_t) __ffsll((long long) m) - 1u;
     uint32_t base = 0;
-    if ((threadIdx.x & 63u) == leader) base = atomicAdd(q.count, (uint32_t) __popcll(m));
+    const uint32_t seg = blockIdx.x % MI_SPLAT_SEGS;
+    if ((threadIdx.x & 63u) == leader) base = atomicAdd(q.count + seg * MI_SPLAT_COUNTER_STRIDE, (uint32_t) __popcll(m));
     base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
-    const uint32_t idx = base + rank;
-    if (idx < q.cap && base <= 0xffffffffu - 64u) {
+    const uint32_t local = base + rank;
+    if (local < q.seg_cap && base <= 0xffffffffu - 64u) {
+        const uint32_t idx = seg * q.seg_cap + local;
         q.rec_a[idx] = make_float4(pos_x, pos_y, rgb.x, rgb.y); q.rec_b[idx] = rgb.z;
     } else film_put_normalized(sc, film, pos_x, pos_y, rgb);               // queue full: the slow way, same result
 }

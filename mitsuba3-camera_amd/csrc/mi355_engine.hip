@@ -786,21 +786,24 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
 // Tile histogram of the record queue; one LDS histogram per chunk, flushed with one global atomic per non-empty bin.
 __global__ __launch_bounds__(256) void k_splat_hist(DScene sc, SplatQueue q, uint32_t n_tiles) {
     extern __shared__ uint32_t s_bins[];
-    const uint32_t n = min(*q.count, q.cap);
-    for (uint32_t c0 = blockIdx.x * SPLAT_CHUNK; c0 < n; c0 += gridDim.x * SPLAT_CHUNK) {
+    const uint32_t cps = (q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK;      // chunks per segment
+    for (uint32_t w = blockIdx.x; w < MI_SPLAT_SEGS * cps; w += gridDim.x) {
+        const uint32_t seg = w / cps, c0 = seg * q.seg_cap + (w % cps) * SPLAT_CHUNK;
+        const uint32_t seg_end = seg * q.seg_cap + min(q.count[seg * MI_SPLAT_COUNTER_STRIDE], q.seg_cap);
+        if (c0 >= seg_end) continue;                                        // (uniform over the workgroup)
         for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) s_bins[k] = 0u;
         __syncthreads();
-        const uint32_t c1 = min(c0 + SPLAT_CHUNK, n);
+        const uint32_t c1 = min(c0 + SPLAT_CHUNK, seg_end);
         for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256u) { const float4 a = q.rec_a[i]; atomicAdd(s_bins + splat_tile_of(sc, q, a.x, a.y), 1u); }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { const uint32_t v = s_bins[k]; if (v) atomicAdd(q.hist + k, v); }
         __syncthreads();
     }
 }
-// Exclusive scan of the tile histogram (one workgroup); also clamps the record count to the capacity and clears the cursors.
-__global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint32_t *offsets, uint32_t *cursor, uint32_t n_tiles, uint32_t *count, uint32_t cap) {
+// Exclusive scan of the tile histogram (one workgroup); clears the cursors; offsets[n_tiles] = number of queued records.
+__global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint32_t *offsets, uint32_t *cursor, uint32_t n_tiles) {
     __shared__ uint32_t s_part[1024]; __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) { s_carry = 0u; if (*count > cap) *count = cap; }
+    if (threadIdx.x == 0) s_carry = 0u;
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += 1024u) {
         const uint32_t i = base + threadIdx.x;
@@ -823,11 +826,14 @@ __global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint3
 __global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b, uint32_t n_tiles) {
     extern __shared__ uint32_t s_bins[];                                    // [n_tiles] counts, then bases; [n_tiles] local cursors
     uint32_t *s_cur = s_bins + n_tiles;
-    const uint32_t n = *q.count;
-    for (uint32_t c0 = blockIdx.x * SPLAT_CHUNK; c0 < n; c0 += gridDim.x * SPLAT_CHUNK) {
+    const uint32_t cps = (q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK;
+    for (uint32_t w = blockIdx.x; w < MI_SPLAT_SEGS * cps; w += gridDim.x) {
+        const uint32_t seg = w / cps, c0 = seg * q.seg_cap + (w % cps) * SPLAT_CHUNK;
+        const uint32_t seg_end = seg * q.seg_cap + min(q.count[seg * MI_SPLAT_COUNTER_STRIDE], q.seg_cap);
+        if (c0 >= seg_end) continue;
         for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { s_bins[k] = 0u; s_cur[k] = 0u; }
         __syncthreads();
-        const uint32_t c1 = min(c0 + SPLAT_CHUNK, n);
+        const uint32_t c1 = min(c0 + SPLAT_CHUNK, seg_end);
         for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256u) { const float4 a = q.rec_a[i]; atomicAdd(s_bins + splat_tile_of(sc, q, a.x, a.y), 1u); }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { const uint32_t v = s_bins[k]; if (v) s_bins[k] = offsets[k] + atomicAdd(cursor + k, v); }
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, 
 __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, const uint32_t *offsets, const float4 *rec_a, const float *rec_b, float *film, uint32_t n_tiles) {
     __shared__ long long s_tile[MI_SPLAT_TW * MI_SPLAT_TW * 3];
     __shared__ uint32_t s_max;
-    const uint32_t n = *q.count;
+    const uint32_t n = offsets[n_tiles];                                    // records actually queued
     const int W = (int) sc.crop_w, H = (int) sc.crop_h;
     for (uint32_t r0 = blockIdx.x * SPLAT_RUN; r0 < n; r0 += gridDim.x * SPLAT_RUN) {
         const uint32_t r1 = min(r0 + SPLAT_RUN, n);
@@ -1646,8 +1652,10 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         SplatQueue q; memset(&q, 0, sizeof(q));
         const uint64_t per_lane = (uint64_t) a.passes * (p->max_depth < 0 ? 64u : (uint32_t) p->max_depth);
         const uint32_t all_tiles = ((s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE) * ((s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE);
-        if (s->ds.rfilter != MI355_RFILTER_BOX && !(p->flags & MI355_FLAG_DIRECT_SPLAT) && (uint64_t) a.n_local * per_lane < 0xffffffffull && all_tiles <= SPLAT_MAX_TILES) {
-            const uint64_t want = std::min<uint64_t>((uint64_t) a.n_local * a.passes * (p->max_depth < 0 ? 8u : std::min<uint32_t>((uint32_t) p->max_depth, 8u)), s->splat_cap_override ? s->splat_cap_override : MAX_SPLAT_RECORDS);
+        if (!(p->flags & MI355_FLAG_DIRECT_SPLAT) && (uint64_t) a.n_local * per_lane < 0xffffffffull && all_tiles <= SPLAT_MAX_TILES) {
+            uint64_t want = std::min<uint64_t>((uint64_t) a.n_local * a.passes * (p->max_depth < 0 ? 8u : std::min<uint32_t>((uint32_t) p->max_depth, 8u)), s->splat_cap_override ? s->splat_cap_override : MAX_SPLAT_RECORDS);
+            const uint64_t seg_cap = std::max<uint64_t>((want + MI_SPLAT_SEGS - 1u) / MI_SPLAT_SEGS, 1u);   // MI_SPLAT_SEGS segments of equal capacity
+            want = seg_cap * MI_SPLAT_SEGS;
             q.tiles_x = (s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE; q.tiles_y = (s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE;
             const uint32_t n_tiles = q.tiles_x * q.tiles_y;
             if (s->rec_capacity < want) {
@@ -1657,13 +1665,14 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
                 HIP_TRY(hipMalloc((void **) &s->d_rec_b, want * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_srt_b, want * sizeof(float)));
                 s->rec_capacity = (uint32_t) want;
             }
-            if (s->tile_capacity < n_tiles) {                               // [count | hist n | offsets n + 1 | cursor n]
+            const size_t n_cnt = (size_t) MI_SPLAT_SEGS * MI_SPLAT_COUNTER_STRIDE;
+            if (s->tile_capacity < n_tiles) {                               // [segment counters | hist n | offsets n + 1 | cursor n]
                 if (s->d_tile_u32) HIP_TRY(hipFree(s->d_tile_u32));
                 s->d_tile_u32 = nullptr; s->tile_capacity = 0;
-                HIP_TRY(hipMalloc((void **) &s->d_tile_u32, (3 * (size_t) n_tiles + 2) * sizeof(uint32_t))); s->tile_capacity = n_tiles;
+                HIP_TRY(hipMalloc((void **) &s->d_tile_u32, (n_cnt + 3 * (size_t) n_tiles + 1) * sizeof(uint32_t))); s->tile_capacity = n_tiles;
             }
-            q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.cap = (uint32_t) want; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + 1;
-            HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (1 + (size_t) n_tiles) * sizeof(uint32_t), st));
+            q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.cap = (uint32_t) want; q.seg_cap = (uint32_t) seg_cap; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + n_cnt;
+            HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (n_cnt + (size_t) n_tiles) * sizeof(uint32_t), st));
         }
         if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
         else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
@@ -1671,9 +1680,9 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         if (q.cap) {
             const uint32_t n_tiles = q.tiles_x * q.tiles_y;
             uint32_t *offsets = q.hist + n_tiles, *cursor = offsets + n_tiles + 1;
-            const uint32_t chunks = std::min<uint32_t>((q.cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK, 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
+            const uint32_t chunks = std::min<uint32_t>(MI_SPLAT_SEGS * ((q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK), 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
             hipLaunchKernelGGL(k_splat_hist, dim3(chunks), dim3(256), n_tiles * sizeof(uint32_t), st, s->ds, q, n_tiles);
-            hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles, q.count, q.cap);
+            hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles);
             hipLaunchKernelGGL(k_splat_scatter, dim3(chunks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b, n_tiles);
             hipLaunchKernelGGL(k_splat_tiles, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b, d_film_rgbw, n_tiles);
             HIP_TRY(hipGetLastError());
