@@ -230,13 +230,15 @@ def main():
     c4 = None
     if args.veach:
         sc4 = mi.load_dict(mi.veach_mis_scene(1024))
-        i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); i4.timing = True
+        i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+        tuned4 = i4.tune(sc4, 512)                                    # re-packing or path regeneration, whichever is faster on this scene
+        i4.timing = True
         sh4 = mi.shard_tiles(1024, 1024, rank, world, rows=TILE_ROWS) if world > 1 else None
         film4 = torch.zeros((1024, 1024, 4), dtype=torch.float32, device=dev)
         h4 = sc4.handle(local_rank)
         def step4(seed):
             film4.zero_()
-            p = i4._params(sc4, seed, 512, shard=sh4)
+            p = i4._params(sc4, seed, 512, shard=sh4)                 # (carries MI355_FLAG_REGEN when tune() chose it)
             mi.abi.check(lib.mi355_render_accumulate(h4, C.byref(p), C.c_void_p(film4.data_ptr()), stream))
             if dist is not None:
                 dist.all_reduce(film4, op=dist.ReduceOp.SUM)
@@ -252,6 +254,7 @@ def main():
         c4 = {"metric": "Msamples/s forward, Veach-MIS scene 1024^2 @512spp (BASELINE configs[3])", "value": round(1024 * 1024 * 512 * n4 / dt4 / 1e6, 2),
               "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2), "kernel_ms": round(k4["kernel_ms"] / max(k4["kernel_launches"], 1), 3),
               "events_per_lane": {k: round(k4[k] / max(k4["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")},
+              "variant": "regen" if i4.regen else "repack", "tuned_kernel_ms": {k: round(v, 2) for k, v in tuned4.items()},
               "finite": bool(torch.isfinite(film4).all().item())}
         sc4.release()
 

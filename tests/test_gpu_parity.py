@@ -1013,6 +1013,17 @@ def test_image_z_test_against_oracle(mi, orc, torch_cuda, scene_name, integrator
         assert calm.mean() > 0.3 and abs(np.median(img[calm] / ref[calm]) - 1) < 0.01
 
 
+def test_tune_picks_a_variant_without_changing_the_image(mi, torch_cuda, veach64):
+    """PathIntegrator.tune(): times re-packing against path regeneration on the device and keeps the faster; the film is the same."""
+    integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+    before = integ.render(veach64, seed=3, spp=128).cpu().numpy()
+    t = integ.tune(veach64, spp=128)
+    assert set(t) == {"repack", "regen"} and all(v > 0 for v in t.values()) and integ.regen == (t["regen"] < t["repack"]) and not integ.timing
+    after = integ.render(veach64, seed=3, spp=128).cpu().numpy()
+    assert np.allclose(before, after, rtol=1e-4, atol=1e-6)
+    assert set(integ.tune(veach64, spp=16)) == {"repack"} and integ.regen is False        # regeneration needs >= 128 spp
+
+
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
     pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the
