@@ -185,7 +185,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
     if (INTEGRATOR == MI355_INTEGRATOR_PATH)
         path_sample<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, trace, stk, rgb, valid, cnt);
     else {
-        GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 };
+        GradSink none = { nullptr, nullptr, nullptr, nullptr, 0, nullptr };
         prb_sample<false, FULL>(sc, rng, ray, a.max_depth, a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, trace, stk,
                           V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, rgb, valid, cnt);
     }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
     dL = dL * cam_w;                                                        // value = L * weight, common.py:752
     Counters3 cnt = {};
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
-    GradSink none = { nullptr, nullptr, nullptr, nullptr, 0 }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE };
+    GradSink none = { nullptr, nullptr, nullptr, nullptr, 0, nullptr }, sink = { s_grad, g_grad, s_q, &s_qn, GRAD_QUEUE, nullptr };
     Pcg32 rng2 = rng;                                                       // sampler.clone(), common.py:767
     v3 L, L2; bool valid;
     prb_sample<false, FULL>(sc, rng2, ray, a.max_depth, a.rr_depth, hide, trace, stk, V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 0.f), none, L, valid, cnt);
