@@ -169,8 +169,8 @@ typedef struct mi355_scene_desc {
                                           (path regeneration).  Same samples, same film; opt-in because on the Cornell box it
                                           measured 11.3 ms against 10.8 ms for the static assignment */
 
-#define MI355_FLAG_EMITTER_GRADS_ONLY 16u /* render_backward with MI355_INTEGRATOR_PTRACER: the caller acknowledges that only the
-                                          MI355_PARAM_EMITTER_RADIANCE slots are written; without it that call is MI355_ERR_UNSUPPORTED */
+#define MI355_FLAG_EMITTER_GRADS_ONLY 16u /* render_backward with MI355_INTEGRATOR_PTRACER: only the MI355_PARAM_EMITTER_RADIANCE slots are
+                                          wanted -- one walk per light path instead of the two that albedo / texture gradients need */
 
 #define MI355_FLAG_DIRECT_SPLAT   32u  /* particle tracer: splat every connection with direct float atomics instead of the default deferred,
                                           tile-sorted splat (same film up to summation order; a debugging / comparison switch -- Gaussian
@@ -288,9 +288,11 @@ int mi355_prb_splat_weights(mi355_scene *scene, const mi355_render_params *p,
    RNG streams; parameter gradients are ACCUMULATED into d_grad_params (layout:
    mi355_scene_param_layout).  Multi-GPU jobs all-reduce d_grad_params afterwards.
    MI355_INTEGRATOR_PTRACER (Integrator::render_backward, integrator.cpp:65-84, over ptracer.cpp; pinned by the hard-coded gradient
-   of test_ptracer.py:204-225): the light paths are replayed, every sensor connection gathers d_grad_in at its splat taps, and the
-   EMITTER RADIANCE slots alone are accumulated (requires MI355_FLAG_EMITTER_GRADS_ONLY; d_weight is unused and may be NULL: the
-   normalised splat has no weight channel).  Reflectance / texture / geometry gradients of light paths are not built. */
+   of test_ptracer.py:204-225): the light paths are replayed and every sensor connection gathers d_grad_in at its splat taps.
+   Emitter radiances, constant diffuse reflectances and reflectance textures -- every parameter of mi355_scene_param_layout -- receive
+   their gradients (path replay: two walks per light path; MI355_FLAG_EMITTER_GRADS_ONLY: radiances only, one walk).  d_weight is
+   unused and may be NULL: the normalised splat has no weight channel.  The roulette probability is treated as detached (path.cpp:272
+   does so explicitly, ptracer.cpp:277 does not; identical while depth <= rr_depth).  Geometry / IOR gradients are not built. */
 int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
                           const float *d_grad_in, const float *d_weight,
                           float *d_grad_params, void *stream);

@@ -1838,29 +1838,29 @@ MI_DEV v3 film_gather_normalized(const DScene &sc, const float *grad_rgb, float 
         }
     return g;
 }
-// Gradient mode of the particle tracer (Integrator::render_backward, integrator.cpp:65-84, over ptracer.cpp) for the emitter
-// radiances: every splat is  radiance_c * unit_c  with unit_c free of the radiance, so the gradient is  sum unit_c * gather_c.
-// Accumulators: MI_PT_COPIES bank-spread copies per (emitter, channel) in LDS for the first MI_PT_EM_LDS emitters (the lanes of a wave
-// mostly add to the SAME emitter), global atomics for the rest.
-#define MI_PT_EM_LDS 16u
-#define MI_PT_COPIES 32u
-struct PtGradSink { const float *grad_rgb; float *s_acc; float *d_grad; const uint32_t *small_map; };
-MI_DEV void pt_grad_add(const DScene &sc, const PtGradSink &sink, uint32_t emitter, v3 g) {
-    const int32_t slot = sc.emitters[emitter].grad_slot;
+// Gradient mode of the particle tracer (Integrator::render_backward, integrator.cpp:65-84, over ptracer.cpp).
+//   emitter radiances: every splat is  radiance_c * unit_c  with unit_c free of the radiance, so the gradient is  sum unit_c * gather_c
+//                      (gather = the image adjoint collected at the splat's taps);
+//   diffuse albedos (constants and textures), `all` mode: the albedo at light-path vertex j is a linear factor of the connection made
+//                      AT j (bsdf eval) and of every later one (bsdf sample weight), so  d/d albedo_j = (1 / albedo_j) * S_j  with
+//                      S_j = sum_{k >= j} <gather_k, splat_k>.  Path replay: walk 1 sums S_1 (and does the radiances), walk 2 re-traces
+//                      the same path from the same sampler state, emits S_j / albedo_j at vertex j and then subtracts connection j.
+// Accumulators for the "small" parameters (constant albedos, radiances): 2^copy_shift bank-spread copies per float in LDS (the lanes
+// of a wave mostly add to the SAME parameter), flushed once per workgroup; texture gradients go out as global atomics on the texels.
+struct PtGradSink { const float *grad_rgb; float *s_grad; uint32_t copy_shift; float *d_grad; const uint32_t *small_map; bool all; };
+MI_DEV void pt_grad_add(const PtGradSink &sink, int32_t slot, v3 g) {
     if (slot < 0) return;
-    if (emitter < MI_PT_EM_LDS) {
-        float *a = sink.s_acc + emitter * 3u * MI_PT_COPIES + (threadIdx.x & (MI_PT_COPIES - 1u));
-        atomicAdd(a, g.x); atomicAdd(a + MI_PT_COPIES, g.y); atomicAdd(a + 2u * MI_PT_COPIES, g.z);
-    } else {
-        atomicAdd(sink.d_grad + sink.small_map[slot], g.x); atomicAdd(sink.d_grad + sink.small_map[slot + 1], g.y); atomicAdd(sink.d_grad + sink.small_map[slot + 2], g.z);
-    }
+    const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
+    float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
+    atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
 }
 // connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
 // GRAD: `weight_unit` = weight / radiance of `emitter`; nothing is splatted, the gathered image adjoint goes to the sink.
 template <bool FULL, bool GRAD = false>
 MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bool seen, v2 uv, v3 ds_p, v3 weight, float sample_scale,
                            float *film, uint32_t *stk, v3 weight_unit = V3(0.f, 0.f, 0.f), uint32_t emitter = 0u, const PtGradSink *sink = nullptr,
-                           const SplatQueue *queue = nullptr) {
+                           const SplatQueue *queue = nullptr, bool add_radiance = true, v3 *dv_out = nullptr) {
+    if (GRAD && dv_out) *dv_out = V3(0.f, 0.f, 0.f);
     bool want = seen && (weight.x != 0.f || weight.y != 0.f || weight.z != 0.f);
     Ray sensor_ray = spawn_ray_to(si.p, si.n, ds_p);
     if (!want) { sensor_ray.o = sensor_ray.d = V3(0.f, 0.f, 1.f); sensor_ray.maxt = 0.f; }
@@ -1879,8 +1879,11 @@ MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bo
         }
         if (GRAD) {
             v3 ru = (weight_unit * surface_weight) * sample_scale;
-            if (ru.x != 0.f || ru.y != 0.f || ru.z != 0.f)
-                pt_grad_add(sc, *sink, emitter, ru * film_gather_normalized(sc, sink->grad_rgb, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y));
+            if (ru.x != 0.f || ru.y != 0.f || ru.z != 0.f) {
+                const v3 g = film_gather_normalized(sc, sink->grad_rgb, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y);
+                if (add_radiance) pt_grad_add(*sink, sc.emitters[emitter].grad_slot, ru * g);
+                if (dv_out) *dv_out = ((weight * surface_weight) * sample_scale) * g;      // <gather, splat> of this connection
+            }
         } else {
         v3 result = (weight * surface_weight) * sample_scale;
         const bool lit = result.x != 0.f || result.y != 0.f || result.z != 0.f;   // (a black splat changes nothing)
@@ -1905,7 +1908,10 @@ MI_DEV SI si_from_position(v3 p, v3 n, int32_t shape) {                     // S
 }
 template <bool FULL, bool GRAD = false>
 MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                           float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr, const SplatQueue *queue = nullptr) {
+                           float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr, const SplatQueue *queue = nullptr,
+                           int walk = 1, v3 *S = nullptr) {
+    // GRAD, `all` mode: walk 1 adds every connection's <gather, splat> to *S (and does the radiance gradients); walk 2 starts from that
+    // total, emits S / albedo at every diffuse vertex and subtracts the vertex's own connection afterwards.
     const bool timed = sc.shutter_open_time > 0.f;
     // ---- sample_visible_emitters, ptracer.cpp:99-171 (wave-uniform condition)
     if (max_depth != 0 && !hide_emitters) {
@@ -1928,7 +1934,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         if (connect) (void) next_1d(rng);                                   // sample_wavelengths: the radiance itself in RGB mode
         v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
         const float wu = idx_weight * pos_weight * sensor_weight;
-        bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk, V3(wu, wu, wu), ei, sink, queue);
+        bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk, V3(wu, wu, wu), ei, sink, queue, walk == 1);
         cnt.shadow += wave_count(cast);
     }
     // ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115)
@@ -1964,9 +1970,32 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
             bool seen = sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
-            cast = connect_sensor<FULL, GRAD>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink, queue);
+            v3 dv = V3(0.f, 0.f, 0.f);
+            cast = connect_sensor<FULL, GRAD>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink, queue,
+                                              walk == 1, (GRAD && S) ? &dv : nullptr);
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
-            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
+            TexTaps taps;
+            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, (GRAD && S && walk == 2) ? &taps : nullptr) : ld3(bsdf.reflectance);
+            if (GRAD && S) {
+                if (walk == 1) *S = *S + dv;
+                else {
+                    if (!FULL || bsdf.type == MI355_BSDF_DIFFUSE) {
+                        const v3 ga = V3(refl.x != 0.f ? S->x / refl.x : 0.f, refl.y != 0.f ? S->y / refl.y : 0.f, refl.z != 0.f ? S->z / refl.z : 0.f);
+                        if (bsdf.texture < 0) pt_grad_add(*sink, bsdf.grad_slot, ga);
+                        else if (sc.textures[bsdf.texture].grad_slot >= 0) {
+                            const DTexture &tx = sc.textures[bsdf.texture];
+                            float *gb = sink->d_grad + tx.grad_offset;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (taps.idx[k] >= 0 && taps.w[k] != 0.f) {
+                                if (tx.c == 3) { atomicAdd(gb + taps.idx[k] * 3 + 0, taps.w[k] * ga.x); atomicAdd(gb + taps.idx[k] * 3 + 1, taps.w[k] * ga.y);
+                                                 atomicAdd(gb + taps.idx[k] * 3 + 2, taps.w[k] * ga.z); }
+                                else atomicAdd(gb + taps.idx[k], taps.w[k] * (ga.x + ga.y + ga.z));
+                            }
+                        }
+                    }
+                    *S = *S - dv;
+                }
+            }
             BSample bs; v3 bsdf_val; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bs, bsdf_val, true);
             v3 wo_world = si_to_world(si, bs.wo);
             float wi_dot_geo_n = dot3(si.n, -ray.d), wo_dot_geo_n = dot3(si.n, wo_world);

@@ -744,17 +744,19 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 // Particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per light sample; a.n_local lanes of the shard, global
 // lane id = pixel * spp + s over the FILM grid.  Every connection splats normalised filter weights with plain float atomics --
 // the positions are scattered over the film, there is nothing to pre-reduce per wave.
-// GRAD (render_backward for the emitter radiances): the same lanes, but every connection GATHERS dL/dimage at its splat taps and adds
-// unit-radiance value x gathered adjoint to the emitter's accumulator (LDS copies, one global atomic per workgroup and channel).
+// GRAD (render_backward): the same lanes, but every connection GATHERS dL/dimage at its splat taps.  Radiance gradients need one walk;
+// with `all_params` every sample is walked twice from the same sampler state (see PtGradSink) for the albedo / texture gradients.
+// The small-parameter accumulators live in dynamic LDS: (n_small << copy_shift) floats.
 template <bool FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
-                                                                 const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue) {
+                                                                 const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
+                                                                 uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
     __shared__ uint32_t s_cnt[4];
-    __shared__ float s_acc[GRAD ? MI_PT_EM_LDS * 3u * MI_PT_COPIES : 1u];
+    extern __shared__ float s_grad_dyn[];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-    if (GRAD) for (uint32_t k = threadIdx.x; k < MI_PT_EM_LDS * 3u * MI_PT_COPIES; k += BLOCK) s_acc[k] = 0.f;
-    const PtGradSink sink = { grad_rgb, s_acc, d_grad, small_map };
+    if (GRAD) for (uint32_t k = threadIdx.x; k < (n_small << copy_shift); k += BLOCK) s_grad_dyn[k] = 0.f;
+    const PtGradSink sink = { grad_rgb, s_grad_dyn, copy_shift, d_grad, small_map, all_params != 0u };
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
@@ -764,16 +766,21 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     Counters3 cnt = {};
-    for (uint32_t pass = 0; pass < a.passes; ++pass)                       // one stream, `passes` samples (integrator.cpp:719-727)
-        ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt, &sink, (!GRAD && queue.cap) ? &queue : nullptr);
+    const bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
+    for (uint32_t pass = 0; pass < a.passes; ++pass) {                      // one stream, `passes` samples (integrator.cpp:719-727)
+        if (GRAD && all_params) {
+            v3 S = V3(0.f, 0.f, 0.f); Pcg32 replay = rng;
+            ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, nullptr, 1, &S);
+            ptracer_sample<FULL, GRAD>(sc, replay, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, nullptr, 2, &S);
+        } else
+            ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, (!GRAD && queue.cap) ? &queue : nullptr);
+    }
     __syncthreads();
     if (GRAD) {
-        const uint32_t n = min(sc.n_emitters, MI_PT_EM_LDS) * 3u;
-        for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
+        for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) {
             float v = 0.f;
-            for (uint32_t c = 0; c < MI_PT_COPIES; ++c) v += s_acc[k * MI_PT_COPIES + c];
-            const int32_t slot = sc.emitters[k / 3u].grad_slot;
-            if (slot >= 0 && v != 0.f) atomicAdd(d_grad + small_map[slot + k % 3u], v);
+            for (uint32_t c = 0; c < (1u << copy_shift); ++c) v += s_grad_dyn[(k << copy_shift) + c];
+            if (v != 0.f) atomicAdd(d_grad + small_map[k], v);
         }
     }
     flush_counters(s_cnt, cnt, g_counters);
@@ -1674,8 +1681,8 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
             q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.cap = (uint32_t) want; q.seg_cap = (uint32_t) seg_cap; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + n_cnt;
             HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (n_cnt + (size_t) n_tiles) * sizeof(uint32_t), st));
         }
-        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
-        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q);
+        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
+        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
         HIP_TRY(hipGetLastError());
         if (q.cap) {
             const uint32_t n_tiles = q.tiles_x * q.tiles_y;
@@ -1765,8 +1772,6 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     const bool pt = p->integrator == MI355_INTEGRATOR_PTRACER;
     if (!d_grad_in || (!d_weight && !pt) || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
-    if (pt && !(p->flags & MI355_FLAG_EMITTER_GRADS_ONLY))
-        return fail(MI355_ERR_UNSUPPORTED, "ptracer render_backward is built for the emitter radiances only: pass MI355_FLAG_EMITTER_GRADS_ONLY to acknowledge that no other slot is written");
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
@@ -1776,8 +1781,13 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         if (s->emitters.empty()) return MI355_OK;
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         const dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
-        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{});
-        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, 0, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{});
+        const uint32_t n_small_pt = (uint32_t) s->small_map.size();
+        uint32_t cs = 5;                                                    // 32 bank-spread copies while they fit in 8 KB
+        while (cs > 0 && (n_small_pt << cs) > 2048u) --cs;
+        const uint32_t all = (p->flags & MI355_FLAG_EMITTER_GRADS_ONLY) ? 0u : 1u;
+        const size_t dyn = (size_t) (n_small_pt << cs) * sizeof(float);
+        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
+        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
         HIP_TRY(hipGetLastError());
         return tm.end();
     }

@@ -319,16 +319,14 @@ class ParticleTracerIntegrator(Integrator):
         raise PluginError("ptracer: render_forward is not built (render_backward for the emitter radiances is)")
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
-        """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp for the EMITTER RADIANCES -- the parameter the
-        reference's own test differentiates (test_ptracer.py:204-225).  `params` must have been narrowed to radiance keys
-        (`params.keep([...])`, util.py:234-258): gradients of light paths with respect to reflectances, textures, mesh vertices or IORs
-        are not built, and a parameter that would silently receive a zero gradient is an error here."""
+        """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp: gradients of every differentiable parameter of this build
+        (emitter radiances, diffuse reflectances, reflectance textures) by path replay of the light paths; the reference's own test
+        value for the radiance (test_ptracer.py:204-225) is reproduced.  When `params` holds radiance keys only (params.keep), the
+        cheaper single-walk kernel runs.  Gradients with respect to geometry / IORs are not built."""
         torch = _torch()
         if params is None:
-            raise PluginError("ptracer.render_backward needs the SceneParameters it should differentiate (radiance keys only)")
-        bad = [k for k in params.keys() if params._entries[k][0] != abi.PARAM_EMITTER_RADIANCE]
-        if bad:
-            raise PluginError("ptracer.render_backward is built for emitter radiances only; drop these with params.keep(): %s" % ", ".join(sorted(bad)))
+            raise PluginError("ptracer.render_backward needs the SceneParameters that receive the gradients")
+        radiance_only = all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
         be = self.backend
         dev = be.device(scene)
         f = scene.sensor.film
@@ -338,7 +336,8 @@ class ParticleTracerIntegrator(Integrator):
             raise ValueError("grad_in must have shape (H, W, 3)")
         band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
         p = self._params(scene, seed, spp, shard=band)
-        p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
+        if radiance_only:
+            p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
         grads = params.grad_buffer(dev)
         multi = shard is not None and shard[1] > 1
         local = torch.zeros_like(grads) if multi else grads

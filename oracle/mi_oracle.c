@@ -1547,8 +1547,13 @@ static v3 film_gather_normalized(const OScene *sc, const float *grad_rgb, v2 pos
    `acc` holds 3 doubles per emitter.  (Russian roulette: the reference differentiates 1/q THROUGH the throughput because
    ptracer.cpp:277 has no detach, unlike path.cpp:272; this restatement keeps q detached -- identical while depth <= rr_depth,
    which covers every case the reference tests.) */
-typedef struct { const float *grad_image; double *acc; } PtGrad;
-static __thread PtGrad g_ptg = { NULL, NULL };
+typedef struct { const float *grad_image; double *acc;
+                 /* all parameters (`grad` != NULL): every light-path vertex j with a diffuse BSDF also receives
+                        d/d albedo_j = (1 / albedo_j) * sum_{k >= j} <image adjoint gathered at splat k, splat k>
+                    -- albedo_j is a linear factor of the connection made AT j (bsdf eval) and of every later one (bsdf sample weight) */
+                 float *grad; const mi355_param_info *layout; const int32_t *bsdf_slot, *tex_slot; v3 last_dv; } PtGrad;
+static __thread PtGrad g_ptg = { NULL, NULL, NULL, NULL, NULL, NULL, { 0.f, 0.f, 0.f } };
+#define PT_MAXV 64
 static v3 xf_point_proj(const float *m, v3 p) {                        /* Transform4f * Point3f with the homogeneous divide */
     float r[4];
     for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], p.x, v); v = fmaf(m[i*4+1], p.y, v); v = fmaf(m[i*4+2], p.z, v); r[i] = v; }
@@ -1656,6 +1661,7 @@ static void connect_sensor(OScene *sc, const SI *si, const mi355_bsdf_desc *bsdf
         v3 ru = scale3(mul3(weight_unit, surface_weight), sample_scale), g = film_gather_normalized(sc, g_ptg.grad_image, pos);
         double *a = g_ptg.acc + 3 * (size_t) emitter;
         a[0] += (double) (ru.x * g.x); a[1] += (double) (ru.y * g.y); a[2] += (double) (ru.z * g.z);
+        g_ptg.last_dv = mul3(result, g);
         return;
     }
     film_put_normalized(sc, film_rgbw, pos, result);
@@ -1725,6 +1731,7 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (1.f / esh->inv_area) * idx_weight);
     }
     int active = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) != 0.f;
+    v3 v_dv[PT_MAXV], v_rho[PT_MAXV]; int32_t v_bsdf[PT_MAXV], v_tidx[PT_MAXV][4]; float v_twgt[PT_MAXV][4]; int nv = 0;
     /* ---- trace_light_ray, ptracer.cpp:200-284 */
     float eta = 1.f; int32_t depth = 1;
     PI pi; SI si;
@@ -1736,9 +1743,15 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
         int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
+        g_ptg.last_dv = V3(0.f, 0.f, 0.f);
         connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt, scale3(tu, sensor_weight), ei);
         float s1 = pcg32_float(&rng); v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
         v3 refl = bsdf_reflectance(sc, bsdf, &si); BSample bs; v3 bsdf_val;
+        if (g_ptg.grad && nv < PT_MAXV) {
+            v_dv[nv] = g_ptg.last_dv; v_rho[nv] = refl; v_bsdf[nv] = (int32_t) sc->shapes[si.shape].bsdf;
+            if (bsdf->reflectance_texture >= 0) (void) texture_eval(&sc->textures[bsdf->reflectance_texture], si.uv, v_tidx[nv], v_twgt[nv]);
+            nv++;
+        }
         bsdf_sample(bsdf, refl, si.wi, s1, s2, 1, &bs, &bsdf_val);
         v3 wo_world = si_to_world(&si, bs.wo);
         float wi_dot_geo_n = dot3(si.n, neg3(ray.d)), wo_dot_geo_n = dot3(si.n, wo_world);
@@ -1757,6 +1770,28 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
             float q = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * (eta * eta), 0.95f);
             active = active && pcg32_float(&rng) < q;       /* next_1d(active): dead lanes still advance their stream -- irrelevant, they are done */
             throughput = scale3(throughput, 1.f / q); tu = scale3(tu, 1.f / q);
+        }
+    }
+    if (g_ptg.grad) {                                                   /* suffix sums over the path's connections */
+        v3 S = V3(0.f, 0.f, 0.f);
+        for (int j = nv - 1; j >= 0; --j) {
+            S = add3(S, v_dv[j]);
+            const mi355_bsdf_desc *b = &sc->bsdfs[v_bsdf[j]];
+            if (b->type != MI355_BSDF_DIFFUSE) continue;
+            v3 ga = V3(v_rho[j].x != 0.f ? S.x / v_rho[j].x : 0.f, v_rho[j].y != 0.f ? S.y / v_rho[j].y : 0.f, v_rho[j].z != 0.f ? S.z / v_rho[j].z : 0.f);
+            if (b->reflectance_texture >= 0) {
+                int32_t slot = g_ptg.tex_slot[b->reflectance_texture];
+                if (slot < 0) continue;
+                const OTexture *t = &sc->textures[b->reflectance_texture];
+                float *gb = g_ptg.grad + g_ptg.layout[slot].offset;
+                for (int k = 0; k < 4; ++k) if (v_tidx[j][k] >= 0) {
+                    if (t->c == 3) { gb[v_tidx[j][k]*3+0] += v_twgt[j][k] * ga.x; gb[v_tidx[j][k]*3+1] += v_twgt[j][k] * ga.y; gb[v_tidx[j][k]*3+2] += v_twgt[j][k] * ga.z; }
+                    else gb[v_tidx[j][k]] += v_twgt[j][k] * (ga.x + ga.y + ga.z);
+                }
+            } else {
+                int32_t slot = g_ptg.bsdf_slot[v_bsdf[j]];
+                if (slot >= 0) { float *gb = g_ptg.grad + g_ptg.layout[slot].offset; gb[0] += ga.x; gb[1] += ga.y; gb[2] += ga.z; }
+            }
         }
     }
     *rng_io = rng;
@@ -1807,6 +1842,15 @@ static int64_t emitter_grad_offset(const OScene *sc, uint32_t e) {       /* orc_
    image IS the RGB accumulator because W = 0), grad_out the concatenated parameter-gradient buffer (orc_scene_param_layout); only
    the MI355_PARAM_EMITTER_RADIANCE slots are written (+=). */
 ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp, const float *grad_image, float *grad_out, int n_threads) {
+    const int all_params = !(rp->flags & MI355_FLAG_EMITTER_GRADS_ONLY);
+    mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
+    int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1));
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) bsdf_slot[i] = -1;
+    for (uint32_t i = 0; i < sc->n_textures; ++i) tex_slot[i] = -1;
+    for (int i = 0; i < np; ++i) {
+        if (layout[i].kind == MI355_PARAM_BSDF_REFLECTANCE) bsdf_slot[layout[i].index] = i;
+        else if (layout[i].kind == MI355_PARAM_TEXTURE_DATA) tex_slot[layout[i].index] = i;
+    }
     uint32_t passes = rp->passes ? rp->passes : 1u;
     if (rp->spp % passes || sc->n_emitters == 0) return 0;
     uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * (rp->spp / passes);
@@ -1818,19 +1862,24 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
 #endif
     size_t na = 3 * (size_t) sc->n_emitters;
     double *accs = (double *) calloc(na * (size_t) n_threads, sizeof(double));
+    float *grads = all_params ? (float *) calloc((size_t) total * (size_t) n_threads, sizeof(float)) : NULL;
     #pragma omp parallel num_threads(n_threads)
     {
 #ifdef _OPENMP
         double *acc = accs + na * (size_t) omp_get_thread_num();
+        float *gl = grads ? grads + total * (size_t) omp_get_thread_num() : NULL;
 #else
-        double *acc = accs;
+        double *acc = accs; float *gl = grads;
 #endif
         Cnt cnt = { 0, 0, 0 };
         g_importance_mode = 1; g_ptg.grad_image = grad_image; g_ptg.acc = acc;
+        g_ptg.grad = gl; g_ptg.layout = layout; g_ptg.bsdf_slot = bsdf_slot; g_ptg.tex_slot = tex_slot;
         #pragma omp for schedule(dynamic, 4096)
         for (int64_t lane = 0; lane < (int64_t) lanes; ++lane) ptracer_lane(sc, rp, (uint32_t) lane, sample_scale, NULL, &cnt);
-        g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL;
+        g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL; g_ptg.grad = NULL;
     }
+    if (grads) { for (int t = 0; t < n_threads; ++t) for (uint64_t i = 0; i < total; ++i) grad_out[i] += grads[total * (size_t) t + i]; free(grads); }
+    free(bsdf_slot); free(tex_slot);
     for (uint32_t e = 0; e < sc->n_emitters; ++e) {
         int64_t off = emitter_grad_offset(sc, e);
         if (off < 0) continue;

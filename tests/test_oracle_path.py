@@ -267,7 +267,7 @@ def test_particle_tracer_reference_golden_gradient(mi, orc, kats):
     gb = o.ptracer_backward(p, np.full((8, 8, 3), 1.0 / 192.0, dtype=np.float32))
     lay, total = o.param_layout()
     off = [l for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE][0][2]
-    assert np.allclose(gb[off:off + 3], k["gradient"], atol=k["atol"]) and (np.delete(gb, [off, off + 1, off + 2]) == 0).all()
+    assert np.allclose(gb[off:off + 3], k["gradient"], atol=k["atol"]) and (np.delete(gb, [off, off + 1, off + 2]) == 0).all()   # (no light path reaches a surface here)
     # the pass structure matters: one pass of 64 gives another (equally valid) estimate, off by more than the tolerance
     one, _ = o.ptracer_render(o.params(mi.make_integrator(dict(sc.integrator_props, samples_per_pass=64)), k["seed"], k["spp"]))
     assert abs(one.sum() / one.size - k["gradient"]) > 10 * k["atol"] and abs(one.mean() - 1.0) < 0.05
@@ -362,3 +362,39 @@ def test_film_sample_border(mi, orc):
     W_on = w_on.splat_weights(w_on.params(integ, 0, 256)); W_off = w_off.splat_weights(w_off.params(integ, 0, 256))
     assert abs(W_on[0, 0] / W_on[6, 6] - 1) < 0.05 and W_off[0, 0] / W_off[6, 6] < 0.8          # corner: full footprint vs the part of it that lies inside the window
     assert np.allclose(W_on[4:8, 4:8], W_off[4:8, 4:8], rtol=0.1)
+
+
+def test_particle_tracer_albedo_gradients_match_finite_differences(mi, orc):
+    """ptracer render_backward for diffuse albedos and albedo textures (path replay of the light paths): with the roulette off the film
+    is a polynomial in every albedo, so the gradient equals a central finite difference with the same seeds."""
+    rng = np.random.default_rng(3)
+    d = small_cbox(mi, 16)
+    tex0 = rng.uniform(0.2, 0.8, (4, 4, 3)).astype(np.float32)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "data": tex0}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 100})
+    lay, total = o.param_layout()
+    gin = rng.normal(size=(16, 16, 3)).astype(np.float32)
+    p = o.params(integ, 4, 64)
+    g = o.ptracer_backward(p, gin)
+
+    def loss():
+        img, _ = o.ptracer_render(p)
+        return float((img.astype(np.float64) * gin).sum())
+    eps = 1e-2
+    kind, index, off, size = [l for l in lay if l[0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
+    base = np.array(sc.bsdfs[index].reflectance, dtype=np.float32)
+    for c in range(3):
+        e = np.zeros(3, np.float32); e[c] = eps
+        o.set_param(kind, index, base + e); hi = loss(); o.set_param(kind, index, base - e); lo = loss(); o.set_param(kind, index, base)
+        assert abs(g[off + c] - (hi - lo) / (2 * eps)) < 2e-3 * abs(g[off + c]) + 1e-4
+    kind, index, off, size = [l for l in lay if l[0] == mi.abi.PARAM_TEXTURE_DATA][0]
+    for t in (0, 17, 40):
+        e = np.zeros(48, np.float32); e[t] = eps
+        o.set_param(kind, index, tex0.ravel() + e); hi = loss(); o.set_param(kind, index, tex0.ravel() - e); lo = loss(); o.set_param(kind, index, tex0.ravel())
+        assert abs(g[off + t] - (hi - lo) / (2 * eps)) < 5e-3 * abs(g[off + t]) + 1e-4
+    p.flags |= mi.abi.FLAG_EMITTER_GRADS_ONLY                          # radiances only: the other slots stay untouched
+    g1 = o.ptracer_backward(p, gin)
+    eoff = [l for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE][0][2]
+    assert np.allclose(g1[eoff:eoff + 3], g[eoff:eoff + 3]) and (np.delete(g1, [eoff, eoff + 1, eoff + 2]) == 0).all()
