@@ -306,6 +306,17 @@ int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
 int mi355_render_forward(mi355_scene *scene, const mi355_render_params *p,
                          const float *d_tangent_params, float *d_film_rgbw, void *stream);
 
+/* Forward-mode derivative of the LIGHT-TRACED film (MI355_INTEGRATOR_PTRACER) with respect to the vertex positions of one mesh --
+   what the fork's lens-design notebooks differentiate through Dr.Jit's AD (notebooks/scripts/lens_design/lens.py:505-565: lens
+   surfaces are meshes whose vertex_positions depend on the lens scalars; design_problem.py:403-428: rendered with `ptracer`; the
+   reference path is Integrator::render_forward, integrator.cpp:44-63, over ptracer.cpp).  d_vertex_tangent = d(position)/d(theta) of
+   every vertex of `shape` (3 floats per vertex, the mesh's own vertex order).  The derivative film d(RGB)/d(theta) is ACCUMULATED
+   into d_film_rgbw (W untouched), so that mi355_film_develop of it is the gradient image.  A dual-number walk of the same light
+   paths and sampler streams (mitsuba3-camera_amd/csrc/mi355_geo_forward.h lists what is and is not differentiated); reverse mode over
+   a handful of lens scalars = one call per scalar.  Perspective sensor; the mesh must not carry an emitter. */
+int mi355_ptracer_forward_geometry(mi355_scene *scene, const mi355_render_params *p, uint32_t shape,
+                                   const float *d_vertex_tangent, float *d_film_rgbw, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("mi355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("mi355_debug_lane_radiance", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_ptracer_forward_geometry", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_render_forward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_set_splat_capacity", C.c_int, [C.c_void_p, C.c_uint32]),

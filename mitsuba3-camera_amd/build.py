@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "mi355_engine.hip")]
-HDR = [os.path.join(HERE, "csrc", "mi355_device.h"), os.path.join(ROOT, "include", "mi355.h")]
+HDR = [os.path.join(HERE, "csrc", "mi355_device.h"), os.path.join(HERE, "csrc", "mi355_geo_forward.h"), os.path.join(ROOT, "include", "mi355.h")]
 LIB = os.path.join(HERE, "libmi355.so")
 
 # -ffp-contract=off: only the fmaf() written in the source fuse (same rule as the CPU oracle and as

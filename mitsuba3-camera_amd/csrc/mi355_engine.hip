@@ -23,6 +23,7 @@
 //   k_debug_intersect           Scene::ray_intersect_preliminary / ray_test on caller rays
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
 #include "mi355_device.h"
+#include "mi355_geo_forward.h"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -784,6 +785,22 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
         }
     }
     flush_counters(s_cnt, cnt, g_counters);
+}
+
+// Forward-mode derivative of the light-traced film with respect to the vertex positions of one mesh (mi355_geo_forward.h): the lanes
+// and sampler streams of k_ptracer, dual numbers alongside; the derivative film is accumulated with plain float atomics.
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool on = i < a.n_local;
+    const uint32_t ii = on ? i : 0u;
+    const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
+    Pcg32 rng; sampler_seed(rng, a.seed, lane);
+    for (uint32_t pass = 0; pass < a.passes; ++pass)
+        ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk);
 }
 
 // ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------
@@ -1765,6 +1782,26 @@ extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
     s->n_gen += a.n_local; s->n_splat += a.n_local;
+    return MI355_OK;
+}
+extern "C" int mi355_ptracer_forward_geometry(mi355_scene *s, const mi355_render_params *p, uint32_t shape, const float *d_vertex_tangent,
+                                              float *d_film_rgbw, void *stream) {
+    if (!s || !p || !d_vertex_tangent || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_INVALID, "mi355_ptracer_forward_geometry runs the particle tracer: set integrator = MI355_INTEGRATOR_PTRACER");
+    if (shape >= s->shapes.size() || s->shapes[shape].type != MI355_SHAPE_MESH) return fail(MI355_ERR_INVALID, "the differentiated shape must be a mesh");
+    if (s->shapes[shape].emitter >= 0) return fail(MI355_ERR_UNSUPPORTED, "the differentiated mesh must not carry an emitter");
+    for (const DEmitter &e : s->emitters) if (e.shape == shape) return fail(MI355_ERR_UNSUPPORTED, "the differentiated mesh must not carry an emitter");
+    if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "vertex forward mode is built for the perspective sensor");
+    RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0 || s->emitters.empty()) return MI355_OK;
+    hipStream_t st = (hipStream_t) stream;
+    const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
+    const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    GeoTangent gt = { shape, d_vertex_tangent };
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
+    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
+    HIP_TRY(hipGetLastError());
     return MI355_OK;
 }
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,

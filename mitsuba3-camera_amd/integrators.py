@@ -316,7 +316,28 @@ class ParticleTracerIntegrator(Integrator):
         return super().render(scene, sensor, seed, spp, develop, evaluate, shard, group)
 
     def render_forward(self, *a, **k):
-        raise PluginError("ptracer: render_forward is not built (render_backward for the emitter radiances is)")
+        raise PluginError("ptracer: render_forward over the colour parameters is not built (render_backward is; for mesh vertices see render_forward_geometry)")
+
+    def render_forward_geometry(self, scene, shape, vertex_tangent, sensor=0, seed=0, spp=0):
+        """Forward-mode derivative of the light-traced image with respect to the vertex positions of the mesh `shape` (its id in the scene
+        dictionary, or its index): `vertex_tangent` (V x 3) = d(position)/d(theta).  What the fork's lens-design notebooks obtain from
+        Dr.Jit's AD through `ptracer` (lens.py:505-565, design_problem.py:403-428).  Returns the gradient image (H x W x 3)."""
+        torch = _torch()
+        be = self.backend
+        dev = be.device(scene)
+        f = scene.sensor.film
+        spp = self._resolve_spp(scene, spp)
+        index = shape if isinstance(shape, int) else [i for i, sh in enumerate(scene.shapes) if sh.id == shape][0]
+        nv = scene.shapes[index].vertex_positions.shape[0] if scene.shapes[index].vertex_positions is not None else 0
+        vt = torch.as_tensor(vertex_tangent, dtype=torch.float32, device=dev).contiguous()
+        if tuple(vt.shape) != (nv, 3):
+            raise ValueError("vertex_tangent must have shape (%d, 3)" % nv)
+        film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
+        p = self._params(scene, seed, spp)
+        abi.check(abi.lib().mi355_ptracer_forward_geometry(scene.handle(), C.byref(p), index, C.c_void_p(vt.data_ptr()), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
+        img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
+        be.develop(scene, film, img)
+        return img
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
         """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp: gradients of every differentiable parameter of this build

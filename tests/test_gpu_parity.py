@@ -1066,6 +1066,96 @@ def test_tune_picks_a_variant_without_changing_the_image(mi, torch_cuda, veach64
     assert set(integ.tune(veach64, spp=16)) == {"repack"} and integ.regen is False        # regeneration needs >= 128 spp
 
 
+def _geo_floor_scene(mi, offset, res=32):
+    """A large diffuse floor MESH moving along its normal: neither the camera nor the light sees a silhouette of it."""
+    T = mi.ScalarTransform4f
+    quad = np.array([[-4, 0, 4], [4, 0, 4], [4, 0, -4], [-4, 0, -4]], dtype=np.float32) + np.array([0, offset, 0], dtype=np.float32)
+    return {"type": "scene",
+            "sensor": {"type": "perspective", "fov": 35.0, "to_world": T.look_at([0.4, 2.5, 1.5], [0, 0, 0], [0, 1, 0]),
+                       "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}}},
+            "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.6, 0.4]}},
+            "quad": {"type": "mesh", "vertex_positions": quad, "faces": np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32), "bsdf": {"type": "ref", "id": "white"}},
+            "light": {"type": "rectangle", "to_world": T.look_at([1.9, 1.3, -0.3], [0, 0, 0], [0, 1, 0]) @ T.scale(0.3),
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [20.0, 20.0, 20.0]}}}}
+
+
+def _geo_lens_scene(mi, scale, material, res=32, rfilter="gaussian", sub=2):
+    """The arrangement of the fork's lens-design notebooks in small: a collimated `directionalarea` beam from a disk, a refracting (or
+    mirroring) MESH with smooth shading normals whose size is the design variable, a diffuse screen watched by a perspective camera."""
+    T = mi.ScalarTransform4f
+    v, f = _icosphere(sub)
+    pos = (v * 0.5 * scale).astype(np.float32) + np.array([-0.3, 0, 0], dtype=np.float32)
+    d = {"type": "scene",
+         "sensor": {"type": "perspective", "fov": 45.0, "to_world": T.look_at([0.2, 0.5, 3.2], [0.6, 0, 0], [0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": rfilter}}},
+         "glass": {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}, "mirror": {"type": "conductor"},
+         "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}},
+         "beam": {"type": "disk", "to_world": T.translate([-1.6, 0, 0]) @ T.rotate([0, 1, 0], 90.0) @ T.scale(0.3), "bsdf": {"type": "ref", "id": "white"},
+                  "emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": [6.0, 5.0, 4.0]}}},
+         "lens": {"type": "mesh", "vertex_positions": pos, "faces": f.astype(np.uint32), "vertex_normals": v.astype(np.float32), "bsdf": {"type": "ref", "id": material}},
+         "screen": {"type": "rectangle", "to_world": T.translate([1.4, 0, 0]) @ T.rotate([0, 1, 0], -90.0) @ T.scale(1.2), "bsdf": {"type": "ref", "id": "white"}}}
+    return d
+
+
+def _geo_mirror_scene(mi, angle, res=32):
+    """A collimated beam on a large flat MIRROR mesh at 45 degrees that turns about the z axis by `angle` (radians): the mirrored spot
+    sweeps over a ceiling screen.  (A curved mirror MESH with interpolated normals is not used here on purpose: the shading-normal
+    correction of the throughput is a sawtooth over the facets whose in-facet slope the interior derivative -- this pass, and AD --
+    picks up while its jumps at the facet edges cancel it in a finite difference.)"""
+    T = mi.ScalarTransform4f
+    u = np.array([1.0, 1.0, 0.0]) / np.sqrt(2); w = np.array([0, 0, 1.0])
+    quad = np.stack([-2 * u - 2 * w, -2 * u + 2 * w, 2 * u + 2 * w, 2 * u - 2 * w])
+    ca, sa = np.cos(angle), np.sin(angle)
+    rot = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]])
+    quad = (quad @ rot.T).astype(np.float32)
+    return {"type": "scene",
+            "sensor": {"type": "perspective", "fov": 45.0, "to_world": T.look_at([0.0, 0.2, 2.8], [0.0, 2.0, 0], [0, 1, 0]),
+                       "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}}},
+            "mirror": {"type": "conductor", "eta": {"type": "rgb", "value": [0.143, 0.375, 1.442]}, "k": {"type": "rgb", "value": [3.983, 2.386, 1.603]}}, "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}},
+            "beam": {"type": "disk", "to_world": T.translate([-1.6, 0.0, 0]) @ T.rotate([0, 1, 0], 90.0) @ T.scale(0.3), "bsdf": {"type": "ref", "id": "white"},
+                     "emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": [6.0, 5.0, 4.0]}}},
+            "m": {"type": "mesh", "vertex_positions": quad, "faces": np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32), "bsdf": {"type": "ref", "id": "mirror"}},
+            "screen": {"type": "rectangle", "to_world": T.translate([0.0, 2.0, 0]) @ T.rotate([1, 0, 0], 90.0) @ T.scale(2.0), "bsdf": {"type": "ref", "id": "white"}}}
+
+
+@pytest.mark.parametrize("case", ["diffuse-floor", "glass-lens", "glass-lens-tent", "turning-mirror"])
+def test_particle_tracer_vertex_forward_mode(mi, torch_cuda, case):
+    """mi355_ptracer_forward_geometry (mi355_geo_forward.h): the derivative of the light-traced image with respect to mesh vertex
+    positions -- what the fork's lens-design notebooks take from Dr.Jit's AD -- against the reference's own check for gradients, a
+    central finite difference of the primal image with the same seeds (test_ad_integrators.py:742-786, :942-962).  The scenes keep
+    every silhouette of the moving mesh out of sight of the camera and of the light, because neither AD nor this pass differentiates
+    visibility; the film's 4-pixel border is left out for the same reason (splats entering the frame are a boundary term)."""
+    torch = torch_cuda
+    integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 100})
+    eps, spp = 2e-3, 256
+    if case == "diffuse-floor":
+        make = lambda t: _geo_floor_scene(mi, t); base, shape = 0.0, "quad"
+        tangent = np.tile(np.array([0, 1, 0], dtype=np.float32), (4, 1))
+    elif case == "turning-mirror":      # d(vertex)/d(angle) = z x position; a gold mirror, so that the Fresnel weight varies with the angle too
+        make = lambda t: _geo_mirror_scene(mi, t); base, shape = 0.0, "m"
+        q0 = _geo_mirror_scene(mi, 0.0)["m"]["vertex_positions"]
+        tangent = np.stack([-q0[:, 1], q0[:, 0], np.zeros(4, dtype=np.float32)], axis=1).astype(np.float32)
+    else:
+        rfilter = "tent" if case.endswith("tent") else "gaussian"
+        make = lambda t: _geo_lens_scene(mi, t, "glass", rfilter=rfilter); base, shape = 1.0, "lens"
+        tangent = (_icosphere(2)[0] * 0.5).astype(np.float32)               # d(vertex) / d(scale)
+    scene = mi.load_dict(make(base))
+    g = integ.render_forward_geometry(scene, shape, tangent, seed=1, spp=spp).cpu().numpy().astype(np.float64)
+    hi = integ.render(mi.load_dict(make(base + eps)), seed=1, spp=spp).cpu().numpy().astype(np.float64)
+    lo = integ.render(mi.load_dict(make(base - eps)), seed=1, spp=spp).cpu().numpy().astype(np.float64)
+    fd = (hi - lo) / (2 * eps)
+    g, fd = g[4:-4, 4:-4], fd[4:-4, 4:-4]
+    assert np.isfinite(g).all() and np.abs(fd).max() > 0
+    rel = np.sqrt(((g - fd) ** 2).sum() / (fd ** 2).sum())
+    corr = (g * fd).sum() / np.sqrt((g ** 2).sum() * (fd ** 2).sum())
+    assert rel < 0.08 and corr > 0.995, (rel, corr)
+    # a zero tangent gives a zero derivative; a lens sensor, a non-mesh or an emitting shape are refused
+    z = integ.render_forward_geometry(scene, shape, np.zeros_like(tangent), seed=1, spp=16).cpu().numpy()
+    assert (z == 0).all()
+    with pytest.raises(mi.Mi355Error):
+        integ.render_forward_geometry(scene, "light" if case == "diffuse-floor" else "screen", np.zeros((0, 3), dtype=np.float32), seed=1, spp=4)
+
+
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
     pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the
