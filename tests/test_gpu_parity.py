@@ -7,6 +7,7 @@ lane on the CPU, once vectorised on the device, compare.  Tolerances:
   * images / gradients: 1e-3 relative to the image maximum (the BASELINE tolerance for radiance and gradients).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1306,3 +1307,13 @@ def test_inverse_rendering_loop(mi, torch_cuda):
     spec = importlib.util.spec_from_file_location("optimize_albedo", path); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     losses, errs = m.main(iterations=30, res=48, spp=16, verbose=False)
     assert errs[-1] < 0.25 * errs[0] and min(losses[-5:]) < 0.7 * losses[0]      # the loss floor is Monte Carlo noise
+
+
+def test_lens_focusing_loop(mi, torch_cuda):
+    """examples/focus_lens.py: the notebooks' design loop with one scalar -- light-traced image, spot-size loss, image gradient from the
+    vertex forward mode, gradient descent: the spot shrinks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("focus_lens", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "focus_lens.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    losses, x = mod.main(iterations=20, res=48, spp=32, verbose=False)
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.6 * np.mean(losses[:3]), (losses[:3], losses[-3:], x)
