@@ -306,16 +306,26 @@ int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
 int mi355_render_forward(mi355_scene *scene, const mi355_render_params *p,
                          const float *d_tangent_params, float *d_film_rgbw, void *stream);
 
-/* Forward-mode derivative of the LIGHT-TRACED film (MI355_INTEGRATOR_PTRACER) with respect to the vertex positions of one mesh --
+/* Forward-mode derivative of the LIGHT-TRACED film (MI355_INTEGRATOR_PTRACER) with respect to one design scalar theta of a lens --
    what the fork's lens-design notebooks differentiate through Dr.Jit's AD (notebooks/scripts/lens_design/lens.py:505-565: lens
-   surfaces are meshes whose vertex_positions depend on the lens scalars; design_problem.py:403-428: rendered with `ptracer`; the
-   reference path is Integrator::render_forward, integrator.cpp:44-63, over ptracer.cpp).  d_vertex_tangent = d(position)/d(theta) of
-   every vertex of `shape` (3 floats per vertex, the mesh's own vertex order).  The derivative film d(RGB)/d(theta) is ACCUMULATED
-   into d_film_rgbw (W untouched), so that mi355_film_develop of it is the gradient image.  A dual-number walk of the same light
-   paths and sampler streams (mitsuba3-camera_amd/csrc/mi355_geo_forward.h lists what is and is not differentiated); reverse mode over
-   a handful of lens scalars = one call per scalar.  Perspective sensor; the mesh must not carry an emitter. */
-int mi355_ptracer_forward_geometry(mi355_scene *scene, const mi355_render_params *p, uint32_t shape,
-                                   const float *d_vertex_tangent, float *d_film_rgbw, void *stream);
+   surfaces are meshes whose vertex_positions depend on the lens scalars, materials carry IOR parameters; design_problem.py:403-428:
+   rendered with `ptracer`; the reference path is Integrator::render_forward, integrator.cpp:44-63, over ptracer.cpp).
+   The tangent of theta may have two parts, either of which can be absent:
+     - geometry: d(position)/d(theta) of every vertex of the mesh `shape` (3 floats per vertex, the mesh's own vertex order);
+     - material: d(int_ior)/d(theta) and d(ext_ior)/d(theta) of the dielectric `bsdf` (the refracted direction depends on their ratio).
+   The derivative film d(RGB)/d(theta) is ACCUMULATED into d_film_rgbw (W untouched), so that mi355_film_develop of it is the
+   gradient image.  A dual-number walk of the same light paths and sampler streams (mitsuba3-camera_amd/csrc/mi355_geo_forward.h lists
+   what is and is not differentiated); reverse mode over a handful of lens scalars = one call per scalar.  Perspective sensor; the
+   mesh must not carry an emitter. */
+#define MI355_NONE 0xffffffffu
+typedef struct mi355_design_tangent {
+    uint32_t shape;                     /* mesh whose vertices move, or MI355_NONE */
+    const float *d_vertex_tangent;      /* DEVICE, 3 floats per vertex of `shape` (NULL iff shape == MI355_NONE) */
+    uint32_t bsdf;                      /* dielectric whose IORs change, or MI355_NONE */
+    float    d_int_ior, d_ext_ior;
+} mi355_design_tangent;
+int mi355_ptracer_forward_design(mi355_scene *scene, const mi355_render_params *p, const mi355_design_tangent *tangent,
+                                 float *d_film_rgbw, void *stream);
 
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);

@@ -82,6 +82,13 @@ class RenderParams(C.Structure):
                 ("pixel_tile", C.c_uint32), ("pixel_tile_stride", C.c_uint32), ("passes", C.c_uint32)]
 
 
+class DesignTangent(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("d_vertex_tangent", C.c_void_p), ("bsdf", C.c_uint32), ("d_int_ior", C.c_float), ("d_ext_ior", C.c_float)]
+
+
+NONE = 0xffffffff
+
+
 class Counters(C.Structure):
     _fields_ = [("n_gen", C.c_uint64), ("n_isect", C.c_uint64), ("n_shade", C.c_uint64),
                 ("n_shadow", C.c_uint64), ("n_splat", C.c_uint64),
@@ -110,7 +117,7 @@ SYMBOLS = [
     ("mi355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("mi355_debug_lane_radiance", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
-    ("mi355_ptracer_forward_geometry", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355_ptracer_forward_design", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(DesignTangent), C.c_void_p, C.c_void_p]),
     ("mi355_render_forward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_set_splat_capacity", C.c_int, [C.c_void_p, C.c_uint32]),

@@ -1062,6 +1062,7 @@ struct mi355_scene {
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
     std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil, area_cdf;
+    std::vector<float> ext_iors;                                            // per bsdf (the design forward mode turns IOR tangents into a tangent of rel_eta)
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
@@ -1313,6 +1314,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         o.alpha_u = b.alpha_u; o.alpha_v = b.alpha_v; o.distribution = b.distribution; o.sample_visible = b.sample_visible;
         memcpy(o.eta, b.eta, 12); memcpy(o.k, b.k, 12); memcpy(o.transmittance, b.transmittance, 12);
         o.rel_eta = b.type == MI355_BSDF_DIELECTRIC ? b.int_ior / b.ext_ior : 1.f;
+        s->ext_iors.push_back(b.type == MI355_BSDF_DIELECTRIC ? b.ext_ior : 1.f);
         if (b.type != MI355_BSDF_DIFFUSE) ds.features |= 1u;
         s->bsdfs.push_back(o);
     }
@@ -1784,21 +1786,28 @@ extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p
     s->n_gen += a.n_local; s->n_splat += a.n_local;
     return MI355_OK;
 }
-extern "C" int mi355_ptracer_forward_geometry(mi355_scene *s, const mi355_render_params *p, uint32_t shape, const float *d_vertex_tangent,
-                                              float *d_film_rgbw, void *stream) {
-    if (!s || !p || !d_vertex_tangent || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
-    if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_INVALID, "mi355_ptracer_forward_geometry runs the particle tracer: set integrator = MI355_INTEGRATOR_PTRACER");
-    if (shape >= s->shapes.size() || s->shapes[shape].type != MI355_SHAPE_MESH) return fail(MI355_ERR_INVALID, "the differentiated shape must be a mesh");
-    if (s->shapes[shape].emitter >= 0) return fail(MI355_ERR_UNSUPPORTED, "the differentiated mesh must not carry an emitter");
-    for (const DEmitter &e : s->emitters) if (e.shape == shape) return fail(MI355_ERR_UNSUPPORTED, "the differentiated mesh must not carry an emitter");
-    if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "vertex forward mode is built for the perspective sensor");
+extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_params *p, const mi355_design_tangent *t, float *d_film_rgbw, void *stream) {
+    if (!s || !p || !t || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_INVALID, "mi355_ptracer_forward_design runs the particle tracer: set integrator = MI355_INTEGRATOR_PTRACER");
+    if (t->shape != MI355_NONE) {
+        if (!t->d_vertex_tangent) return fail(MI355_ERR_INVALID, "vertex tangent missing");
+        if (t->shape >= s->shapes.size() || s->shapes[t->shape].type != MI355_SHAPE_MESH) return fail(MI355_ERR_INVALID, "the differentiated shape must be a mesh");
+        for (const DEmitter &e : s->emitters) if (e.shape == t->shape) return fail(MI355_ERR_UNSUPPORTED, "the differentiated mesh must not carry an emitter");
+    }
+    float d_rel = 0.f;
+    if (t->bsdf != MI355_NONE) {
+        if (t->bsdf >= s->bsdfs.size() || s->bsdfs[t->bsdf].type != MI355_BSDF_DIELECTRIC) return fail(MI355_ERR_INVALID, "the differentiated bsdf must be a dielectric");
+        const float ext = s->ext_iors[t->bsdf], rel = s->bsdfs[t->bsdf].rel_eta;   // rel_eta = int_ior / ext_ior
+        d_rel = t->d_int_ior / ext - rel * t->d_ext_ior / ext;
+    }
+    if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "the design forward mode is built for the perspective sensor");
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0 || s->emitters.empty()) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
     const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
     const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
-    GeoTangent gt = { shape, d_vertex_tangent };
+    GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel };
     if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
     else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
     HIP_TRY(hipGetLastError());

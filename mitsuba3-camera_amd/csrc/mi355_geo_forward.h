@@ -1,4 +1,4 @@
-// mi355_geo_forward.h -- forward-mode derivative of the particle tracer's film with respect to MESH VERTEX POSITIONS.
+// mi355_geo_forward.h -- forward-mode derivative of the particle tracer's film with respect to MESH VERTEX POSITIONS and dielectric IORs.
 //
 // What the fork's lens-design notebooks differentiate (notebooks/scripts/lens_design/lens.py:505-565: lens surfaces are meshes whose
 // vertex_positions are functions of the lens scalars; design_problem.py:403-428: rendered with `ptracer`) goes through Dr.Jit's AD in
@@ -65,7 +65,8 @@ MI_DEV Df dfilter_eval(const DScene &sc, Df x) {
     return DF(fabsf(x.v) <= 0.5f ? 1.f : 0.f);                             // box: not differentiable in the position (derivative 0)
 }
 
-struct GeoTangent { uint32_t shape; const float *vtan; };                  // d(vertex position)/d(theta) of every vertex of `shape` (3 floats each)
+// d(vertex position)/d(theta) of every vertex of `shape` (3 floats each); d(int_ior / ext_ior)/d(theta) of the dielectric `bsdf`
+struct GeoTangent { uint32_t shape; const float *vtan; uint32_t bsdf; float d_rel_eta; };
 
 // Dual hit record at a primal hit (hit, si): point, geometric normal, shading normal, tangent frame, all as functions of the dual ray.
 struct DualHit { D3 p, ng, ns, sh_s, sh_t; };
@@ -78,7 +79,7 @@ MI_DEV DualHit dual_hit(const DScene &sc, const GeoTangent &gt, const Hit &hit, 
         const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + hit.prim);
         const uint32_t l0 = fi[0], l1 = fi[1], l2 = fi[2];
         const uint32_t i0 = sh.vtx_offset + l0, i1 = sh.vtx_offset + l1, i2 = sh.vtx_offset + l2;
-        const bool moving = hit.shape == gt.shape;
+        const bool moving = hit.shape == gt.shape && gt.vtan != nullptr;
         D3 p0 = D3vd(ld3(sc.positions + 3 * (size_t) i0), moving ? ld3(gt.vtan + 3 * (size_t) l0) : V3(0.f, 0.f, 0.f));
         D3 p1 = D3vd(ld3(sc.positions + 3 * (size_t) i1), moving ? ld3(gt.vtan + 3 * (size_t) l1) : V3(0.f, 0.f, 0.f));
         D3 p2 = D3vd(ld3(sc.positions + 3 * (size_t) i2), moving ? ld3(gt.vtan + 3 * (size_t) l2) : V3(0.f, 0.f, 0.f));
@@ -247,7 +248,9 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
             if (bs.delta) {
                 if (bs.wo.z * si.wi.z > 0.f) wo = d + dh.ns * (wi.z * 2.f);   // reflection: d + 2 (wi . n) n
                 else {                                                      // refraction (dielectric.cpp:246-371, fresnel.h:25-81): eta_ti d + n (eta_ti cos_i + cos_t)
-                    const float rel = bsdf.rel_eta, eta_ti = si.wi.z > 0.f ? 1.f / rel : rel;
+                    const float rel = bsdf.rel_eta;
+                    const float drel = sc.shapes[hit.shape].bsdf == gt.bsdf ? gt.d_rel_eta : 0.f;   // the IOR ratio is the design scalar's material part
+                    Df eta_ti = si.wi.z > 0.f ? DF(1.f / rel, -drel / (rel * rel)) : DF(rel, drel);
                     Df ct2 = DF(1.f) - (DF(1.f) - wi.z * wi.z) * (eta_ti * eta_ti);
                     Df cos_t = dsqrt(ct2); if (si.wi.z > 0.f) cos_t = -cos_t;  // mulsign(sqrt, -cos_theta_i)
                     wo = d * eta_ti + dh.ns * (wi.z * eta_ti + cos_t);

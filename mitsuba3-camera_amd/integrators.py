@@ -318,26 +318,38 @@ class ParticleTracerIntegrator(Integrator):
     def render_forward(self, *a, **k):
         raise PluginError("ptracer: render_forward over the colour parameters is not built (render_backward is; for mesh vertices see render_forward_geometry)")
 
-    def render_forward_geometry(self, scene, shape, vertex_tangent, sensor=0, seed=0, spp=0):
-        """Forward-mode derivative of the light-traced image with respect to the vertex positions of the mesh `shape` (its id in the scene
-        dictionary, or its index): `vertex_tangent` (V x 3) = d(position)/d(theta).  What the fork's lens-design notebooks obtain from
-        Dr.Jit's AD through `ptracer` (lens.py:505-565, design_problem.py:403-428).  Returns the gradient image (H x W x 3)."""
+    def render_forward_design(self, scene, shape=None, vertex_tangent=None, bsdf=None, d_int_ior=0.0, d_ext_ior=0.0, sensor=0, seed=0, spp=0):
+        """Forward-mode derivative of the light-traced image with respect to ONE design scalar of a lens -- what the fork's lens-design
+        notebooks obtain from Dr.Jit's AD through `ptracer` (lens.py:505-565, design_problem.py:403-428).  The scalar's tangent can have a
+        geometric part (`shape`: id or index of a mesh, `vertex_tangent`: V x 3 = d(position)/d(theta)) and a material part (`bsdf`: id or
+        index of a dielectric, `d_int_ior` / `d_ext_ior`).  Returns the gradient image (H x W x 3)."""
         torch = _torch()
         be = self.backend
         dev = be.device(scene)
         f = scene.sensor.film
         spp = self._resolve_spp(scene, spp)
-        index = shape if isinstance(shape, int) else [i for i, sh in enumerate(scene.shapes) if sh.id == shape][0]
-        nv = scene.shapes[index].vertex_positions.shape[0] if scene.shapes[index].vertex_positions is not None else 0
-        vt = torch.as_tensor(vertex_tangent, dtype=torch.float32, device=dev).contiguous()
-        if tuple(vt.shape) != (nv, 3):
-            raise ValueError("vertex_tangent must have shape (%d, 3)" % nv)
+        t = abi.DesignTangent(); t.shape = abi.NONE; t.bsdf = abi.NONE; t.d_vertex_tangent = None
+        vt = None
+        if shape is not None:
+            index = shape if isinstance(shape, int) else [i for i, sh in enumerate(scene.shapes) if sh.id == shape][0]
+            nv = scene.shapes[index].vertex_positions.shape[0] if scene.shapes[index].vertex_positions is not None else 0
+            vt = torch.as_tensor(vertex_tangent, dtype=torch.float32, device=dev).contiguous()
+            if tuple(vt.shape) != (nv, 3):
+                raise ValueError("vertex_tangent must have shape (%d, 3)" % nv)
+            t.shape = index; t.d_vertex_tangent = vt.data_ptr()
+        if bsdf is not None:
+            t.bsdf = bsdf if isinstance(bsdf, int) else [i for i, b in enumerate(scene.bsdfs) if b.id == bsdf][0]
+            t.d_int_ior = float(d_int_ior); t.d_ext_ior = float(d_ext_ior)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
         p = self._params(scene, seed, spp)
-        abi.check(abi.lib().mi355_ptracer_forward_geometry(scene.handle(), C.byref(p), index, C.c_void_p(vt.data_ptr()), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
+        abi.check(abi.lib().mi355_ptracer_forward_design(scene.handle(), C.byref(p), C.byref(t), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
         img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
         be.develop(scene, film, img)
         return img
+
+    def render_forward_geometry(self, scene, shape, vertex_tangent, sensor=0, seed=0, spp=0):
+        """render_forward_design with a vertex tangent only."""
+        return self.render_forward_design(scene, shape=shape, vertex_tangent=vertex_tangent, sensor=sensor, seed=seed, spp=spp)
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
         """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp: gradients of every differentiable parameter of this build

@@ -1080,7 +1080,7 @@ def _geo_floor_scene(mi, offset, res=32):
                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [20.0, 20.0, 20.0]}}}}
 
 
-def _geo_lens_scene(mi, scale, material, res=32, rfilter="gaussian", sub=2):
+def _geo_lens_scene(mi, scale, material, res=32, rfilter="gaussian", sub=2, ior=1.5):
     """The arrangement of the fork's lens-design notebooks in small: a collimated `directionalarea` beam from a disk, a refracting (or
     mirroring) MESH with smooth shading normals whose size is the design variable, a diffuse screen watched by a perspective camera."""
     T = mi.ScalarTransform4f
@@ -1089,7 +1089,7 @@ def _geo_lens_scene(mi, scale, material, res=32, rfilter="gaussian", sub=2):
     d = {"type": "scene",
          "sensor": {"type": "perspective", "fov": 45.0, "to_world": T.look_at([0.2, 0.5, 3.2], [0.6, 0, 0], [0, 1, 0]),
                     "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": rfilter}}},
-         "glass": {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}, "mirror": {"type": "conductor"},
+         "glass": {"type": "dielectric", "int_ior": ior, "ext_ior": 1.0}, "mirror": {"type": "conductor"},
          "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}},
          "beam": {"type": "disk", "to_world": T.translate([-1.6, 0, 0]) @ T.rotate([0, 1, 0], 90.0) @ T.scale(0.3), "bsdf": {"type": "ref", "id": "white"},
                   "emitter": {"type": "directionalarea", "radiance": {"type": "rgb", "value": [6.0, 5.0, 4.0]}}},
@@ -1307,6 +1307,26 @@ def test_inverse_rendering_loop(mi, torch_cuda):
     spec = importlib.util.spec_from_file_location("optimize_albedo", path); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     losses, errs = m.main(iterations=30, res=48, spp=16, verbose=False)
     assert errs[-1] < 0.25 * errs[0] and min(losses[-5:]) < 0.7 * losses[0]      # the loss floor is Monte Carlo noise
+
+
+def test_particle_tracer_ior_forward_mode(mi, torch_cuda):
+    """The material part of a design tangent: d(image)/d(int_ior) of the lens glass, and a combined tangent (scale and IOR together),
+    against finite differences of the primal image -- the notebooks optimise IOR / Abbe numbers next to the surface shapes."""
+    integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 100})
+    eps, spp = 2e-3, 256
+    tangent = (_icosphere(2)[0] * 0.5).astype(np.float32)
+    scene = mi.load_dict(_geo_lens_scene(mi, 1.0, "glass"))
+    for name, kw, make in (("ior", dict(bsdf="glass", d_int_ior=1.0), lambda t: _geo_lens_scene(mi, 1.0, "glass", ior=1.5 + t)),
+                           ("both", dict(shape="lens", vertex_tangent=tangent, bsdf="glass", d_int_ior=-0.5), lambda t: _geo_lens_scene(mi, 1.0 + t, "glass", ior=1.5 - 0.5 * t))):
+        g = integ.render_forward_design(scene, seed=1, spp=spp, **kw).cpu().numpy().astype(np.float64)
+        hi = integ.render(mi.load_dict(make(eps)), seed=1, spp=spp).cpu().numpy().astype(np.float64)
+        lo = integ.render(mi.load_dict(make(-eps)), seed=1, spp=spp).cpu().numpy().astype(np.float64)
+        fd = (hi - lo) / (2 * eps)
+        g, fd = g[4:-4, 4:-4], fd[4:-4, 4:-4]
+        rel = np.sqrt(((g - fd) ** 2).sum() / (fd ** 2).sum()); corr = (g * fd).sum() / np.sqrt((g ** 2).sum() * (fd ** 2).sum())
+        assert np.abs(fd).max() > 0 and rel < 0.08 and corr > 0.995, (name, rel, corr)
+    with pytest.raises(mi.Mi355Error):
+        integ.render_forward_design(scene, bsdf="white", d_int_ior=1.0, seed=1, spp=4)       # not a dielectric
 
 
 def test_lens_focusing_loop(mi, torch_cuda):
