@@ -278,6 +278,19 @@ def main():
             pt[rf] = {"value": round(npix * args.prb_spp * n_pt / dtp / 1e6, 2), "unit": "Msamples/s (light paths)", "ms_per_step": round(dtp / n_pt * 1e3, 3),
                       "kernel_ms": round(kp["kernel_ms"] / max(kp["kernel_launches"], 1), 3),
                       "connections_per_lane": round(kp["n_shadow"] / max(kp["n_gen"], 1), 3), "finite": bool(torch.isfinite(imgp).all().item())}
+            if rf == "gaussian" and world == 1:      # the derivative passes of the light tracer on the same scene (timings only)
+                def timed(fn, n=3):
+                    fn(); torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize(dev); return round((time.perf_counter() - t0) / n * 1e3, 3)
+                gin = torch.ones((args.res, args.res, 3), dtype=torch.float32, device=dev)
+                pa = mi.traverse(scp); pr = mi.traverse(scp); pr.keep(r".*\.emitter\.radiance\.value")
+                cube = [i for i, sh in enumerate(scp.shapes) if sh.id == "small-box"][0]
+                vt = torch.zeros((scp.shapes[cube].vertex_positions.shape[0], 3), dtype=torch.float32, device=dev); vt[:, 1] = 1.0
+                pt[rf]["render_backward_all_params_ms"] = timed(lambda: ip.render_backward(scp, pa, gin, seed=0, spp=args.prb_spp))
+                pt[rf]["render_backward_radiance_ms"] = timed(lambda: ip.render_backward(scp, pr, gin, seed=0, spp=args.prb_spp))
+                pt[rf]["render_forward_design_ms"] = timed(lambda: ip.render_forward_design(scp, shape=cube, vertex_tangent=vt, seed=0, spp=args.prb_spp))
             scp.release()
 
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
