@@ -1290,6 +1290,29 @@ def test_render_op_autograd(mi, orc, torch_cuda, cbox32):
     assert img2.mean() < img.mean()
 
 
+def test_render_op_autograd_with_the_particle_tracer(mi, orc, torch_cuda):
+    """mi.render with integrator = ptracer: the same differentiable op, its backward goes through the light tracer's path replay."""
+    torch = torch_cuda
+    scene = mi.load_dict(small_cbox(mi, 32))
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 3})
+    params = mi.traverse(scene)
+    keys = ["green.reflectance.value", "light.emitter.radiance.value"]
+    leaves = {}
+    for k in keys:
+        leaves[k] = params[k].clone().requires_grad_(True); params[k] = leaves[k]
+    img = mi.render(scene, params, integrator=integ, seed=1, spp=8)
+    (img ** 2).mean().backward()
+    o = orc.OracleScene(scene, mi.abi)
+    gin = (2.0 * img.detach() / img.numel()).cpu().numpy()
+    g_ref = o.ptracer_backward(o.params(integ, mi.sample_tea_32(1, 1)[0], 8), gin)
+    lay, _ = o.param_layout()
+    offs = {"green.reflectance.value": [o_ for k, i, o_, s in lay if k == 0 and scene.bsdfs[i].id == "green"][0],
+            "light.emitter.radiance.value": [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_EMITTER_RADIANCE][0]}
+    for k in keys:
+        got = leaves[k].grad.cpu().numpy(); ref = g_ref[offs[k]:offs[k] + 3]
+        assert np.abs(ref).max() > 0 and np.allclose(got, ref, rtol=1e-2, atol=1e-3 * np.abs(ref).max()), (k, got, ref)
+
+
 def test_errors_are_loud(mi, torch_cuda, cbox32):
     p = mi.PathIntegrator()._params(cbox32, 0, 0)
     film = torch_cuda.zeros((32, 32, 4), device="cuda")
