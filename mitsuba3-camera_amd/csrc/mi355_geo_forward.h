@@ -13,7 +13,8 @@
 // Not differentiated, as in the reference's AD: visibility, the discrete choices (which triangle, which lobe, roulette survival).
 // Stated limits of this version: perspective sensor; emitters must not sit on the moving mesh; a rough-conductor vertex keeps its
 // sampled local direction and weight fixed (their dependence on the local incident direction is ignored); on spheres and disks the tangent frame
-// of a DIFFUSE vertex is taken as locally constant (exact for the refractive vertices of a lens, which need no frame).
+// of a DIFFUSE vertex is taken as locally constant (exact for the refractive vertices of a lens, which need no frame); an albedo
+// texture is looked up at the primal uv (its spatial gradient times d(uv) is not carried).
 // Checked against central finite differences of the primal film (tests/test_gpu_parity.py: test_particle_tracer_vertex_forward_mode):
 // a diffuse floor mesh sliding along its normal, the notebooks' arrangement in small (collimated disk source, refracting mesh with
 // smooth shading normals that is scaled, diffuse screen; Gaussian and tent filter) and a gold flat mirror mesh that turns -- relative
