@@ -1143,6 +1143,17 @@ struct Counters3 { uint32_t isect, shade, shadow; };
 #define PROF(c, k)
 #endif
 
+// Every kernel of this engine takes the DScene BY VALUE AS ITS FIRST ARGUMENT, i.e. it sits at offset 0 of the kernel-argument segment.
+// MI_SCENE_RELOAD(name) re-derives a reference to it through a pointer the optimiser cannot see through.  Placed at the top of a bounce
+// loop's body it stops the compiler from fetching every scene constant once, before the loop, and carrying ~150 of them through it in
+// SGPRs it does not have: the spills go through VGPR lanes (v_writelane / v_readlane) and each costs a VALU issue slot, the scarce
+// resource of these kernels.  Re-fetching is a scalar load that hits the constant cache.  Measured on the forward kernel: 151 -> 30 spill
+// moves, 9.81 -> 9.08 ms (Cornell box, 512^2 x 256 spp).
+#define MI_SCENE_RELOAD(name) \
+    const __attribute__((address_space(4))) DScene *name##_k = (const __attribute__((address_space(4))) DScene *) __builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(name##_k)); \
+    const DScene &name = *(const DScene *) name##_k
+
 // -------------------------------------------------------------------------------------------
 // PathIntegrator::sample, src/integrators/path.cpp:95-287
 // -------------------------------------------------------------------------------------------
@@ -1229,6 +1240,7 @@ MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_dept
     PathState st; path_init(st, ray, rng);
     bool valid_ray = false;                                                // no environment emitter, path.cpp:115
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        MI_SCENE_RELOAD(scb); const DScene &sc = scb;                       // scene constants are re-fetched per bounce, not carried in spilled SGPRs
         bool hit_any;
         active = path_step<FULL>(sc, st, it, max_depth, rr_depth, active, stk, hit_any, cnt);
         valid_ray = valid_ray || hit_any;
@@ -1263,6 +1275,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
     v3 prev_p = V3(0.f, 0.f, 0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     v3 fwd_acc = V3(0.f, 0.f, 0.f);                                          // FWD: the lane's dL
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        MI_SCENE_RELOAD(scb); const DScene &sc = scb;                       // scene constants are re-fetched per bounce, not carried in spilled SGPRs
         Hit hit = scene_intersect<FULL>(sc, ray, active, stk);
         cnt.isect += wave_count(active);
         bool si_valid = active && hit.t != MI_INF;
@@ -1650,8 +1663,10 @@ template <bool FULL>
 MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                           bool active, uint32_t *stk, v3 dL, GradSink1 sink, v3 &L_out, Counters3 &cnt) {
     Prb1State st; prb1_init(st, ray, rng, dL);
-    for (uint32_t it = 0; it < max_depth && __any(active); ++it)
-        active = prb1_step<FULL>(sc, st, it, max_depth, rr_depth, hide_emitters, active, stk, sink, threadIdx.x, cnt);
+    for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
+        MI_SCENE_RELOAD(scb);
+        active = prb1_step<FULL>(scb, st, it, max_depth, rr_depth, hide_emitters, active, stk, sink, threadIdx.x, cnt);
+    }
     rng = st.rng; L_out = st.P;
 }
 
@@ -1964,6 +1979,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
     active = active && hit.t != MI_INF;
     if (max_depth >= 0) active = active && depth < max_depth;
     while (__any(active)) {
+        MI_SCENE_RELOAD(scb); const DScene &sc = scb;                       // scene constants are re-fetched per bounce, not carried in spilled SGPRs
         cnt.shade += wave_count(active);
         bool cast = false, next_active = false;
         Ray next_ray = ray;
@@ -1972,13 +1988,16 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             const DBsdf &bsdf = sc.bsdfs[sc.shapes[hit.shape].bsdf];
             float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-            bool seen = sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
+            bool seen;
+            { MI_SCENE_RELOAD(sc1); seen = sensor_sample_direction<FULL>(sc1, si.p, ssx, ssy, uv, ds_p, sensor_weight); }   // (camera matrices: live here only)
             v3 dv = V3(0.f, 0.f, 0.f);
-            cast = connect_sensor<FULL, GRAD>(sc, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink, queue,
-                                              walk == 1, (GRAD && S) ? &dv : nullptr);
+            { MI_SCENE_RELOAD(sc2);
+              cast = connect_sensor<FULL, GRAD>(sc2, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink, queue,
+                                                walk == 1, (GRAD && S) ? &dv : nullptr); }
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
             TexTaps taps;
-            v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, (GRAD && S && walk == 2) ? &taps : nullptr) : ld3(bsdf.reflectance);
+            MI_SCENE_RELOAD(sc3);
+            v3 refl = bsdf.texture >= 0 ? texture_eval(sc3, sc3.textures[bsdf.texture], si.uv, (GRAD && S && walk == 2) ? &taps : nullptr) : ld3(bsdf.reflectance);
             if (GRAD && S) {
                 if (walk == 1) *S = *S + dv;
                 else {

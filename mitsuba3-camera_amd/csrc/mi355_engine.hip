@@ -370,8 +370,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
         alive = false;
         if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
             bool hit_any;
-            if (INTEGRATOR == MI355_INTEGRATOR_PATH) alive = path_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
-            else alive = prb_primal_step<FULL>(sc, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            MI_SCENE_RELOAD(scb);                                           // re-derived every bounce (mi355_device.h)
+            if (INTEGRATOR == MI355_INTEGRATOR_PATH) alive = path_step<FULL>(scb, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
+            else alive = prb_primal_step<FULL>(scb, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
             valid_ray = valid_ray || hit_any;
         }
         if (mine && !alive) {                                               // path over: park its radiance in its original slot
@@ -437,9 +438,10 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
     }
     __syncthreads();
     float values[4] = { fin[tid] * cam_w, fin[BLOCK + tid] * cam_w, fin[2 * BLOCK + tid] * cam_w, 1.f };   // integrator.cpp:461, 477-486
-    Splat sp = splat_weights(sc, pos_x, pos_y);
+    MI_SCENE_RELOAD(scl);                                                   // the splat's filter table / crop window: fetched here, not before the loop
+    Splat sp = splat_weights(scl, pos_x, pos_y);
     __syncthreads();
-    film_splat<4>(sc, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+    film_splat<4>(scl, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
     flush_counters(s_cnt, cnt, g_counters);
 }
 

@@ -197,6 +197,7 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
     active = active && hit.t != MI_INF;
     if (max_depth >= 0) active = active && depth < max_depth;
     while (__any(active)) {
+        MI_SCENE_RELOAD(scb); const DScene &sc = scb;
         bool next_active = false;
         Ray next_ray = ray;
         if (active) {
