@@ -211,8 +211,10 @@ typedef struct mi355_render_params {
     /* Passes of the JIT render loops (`samples_per_pass`, integrator.cpp:565-573 and :700-726): the sampler is seeded ONCE for a
        wavefront of  pixels * spp / passes  streams and every stream draws `passes` consecutive samples, so the stream grid is
        spp / passes  per pixel (global stream id = pixel * (spp / passes) + s; spp_begin / spp_count then count streams).
-       0 or 1 = one pass.  Honoured by MI355_INTEGRATOR_PTRACER (whose reference test fixture renders in 4 passes); the path / prb
-       integrators reject passes > 1 (MI355_ERR_UNSUPPORTED). */
+       0 or 1 = one pass.  Honoured by MI355_INTEGRATOR_PTRACER (whose reference test fixture renders in 4 passes) and by
+       MI355_INTEGRATOR_PATH with the perspective sensor (SamplingIntegrator::render, integrator.cpp:283, :319-329; every lane draws the
+       six numbers of every loop iteration it enters, path.cpp:196, :212-213, :272, so that the next pass starts where the reference's
+       does).  prb.py renders in one pass: MI355_ERR_UNSUPPORTED. */
     uint32_t passes;
 } mi355_render_params;
 

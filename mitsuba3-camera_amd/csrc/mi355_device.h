@@ -1234,15 +1234,20 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     cnt.shadow += wave_count(shadow_req);
     return alive;
 }
+// `keep_stream`: the sampler stream is continued by a further pass (samples_per_pass), so it must end where the reference's does.  Every
+// sampler call inside the loop of path.cpp:142-281 is UNMASKED and the loop masks by `active` alone, so a lane draws its six numbers
+// (next_2d, next_1d, next_2d, next_1d: :196, :212-213, :272) in EVERY iteration it enters -- also in the one where its ray leaves the
+// scene or reaches max_depth, where path_step (rightly, for a single pass) draws nothing.
 template <bool FULL>
 MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
-                        bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt) {
+                        bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt, bool keep_stream = false) {
     PathState st; path_init(st, ray, rng);
     bool valid_ray = false;                                                // no environment emitter, path.cpp:115
     for (uint32_t it = 0; it < max_depth && __any(active); ++it) {
         MI_SCENE_RELOAD(scb); const DScene &sc = scb;                       // scene constants are re-fetched per bounce, not carried in spilled SGPRs
-        bool hit_any;
+        bool hit_any; const bool entered = active;
         active = path_step<FULL>(sc, st, it, max_depth, rr_depth, active, stk, hit_any, cnt);
+        if (keep_stream && entered && !(hit_any && it + 1 < max_depth)) for (int k = 0; k < 6; ++k) (void) next_1d(st.rng);
         valid_ray = valid_ray || hit_any;
     }
     rng = st.rng;

@@ -179,6 +179,20 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
     PROF_START(cnt);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
     float pos_x, pos_y; Ray ray;
+    // samples_per_pass (path integrator, film output): one stream per lane, `passes` samples from it (integrator.cpp:283, :319-329);
+    // all but the last are traced and splatted here, the last one by the code below
+    if (INTEGRATOR == MI355_INTEGRATOR_PATH && OUT == OUT_FILM) for (uint32_t pass = 1; pass < a.passes; ++pass) {
+        MI_SCENE_RELOAD(scp);
+        float cw = camera_ray<FULL>(scp, rng, li.px, li.py, pos_x, pos_y, ray);
+        v3 c; bool v;
+        path_sample<FULL>(scp, rng, ray, a.max_depth, a.rr_depth, li.act && cw > 0.f, stk, c, v, cnt, true);
+        c = c * cw;
+        __syncthreads();
+        Splat sp = splat_weights(scp, pos_x, pos_y);
+        float values[4] = { c.x, c.y, c.z, 1.f };
+        film_splat<4>(scp, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+        __syncthreads();
+    }
     float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray);
     bool trace = li.act && cam_w > 0.f;                                    // rays blocked inside the lens carry weight 0
     PROF(cnt, 6);
@@ -1609,7 +1623,9 @@ static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderA
     if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
     // samples_per_pass (integrator.cpp:565-573, :700-726): spp / passes sampler streams per pixel, `passes` samples from each
     const uint32_t passes = p->passes ? p->passes : 1u;
-    if (passes > 1u && p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_UNSUPPORTED, "passes > 1 (samples_per_pass) is built for the particle tracer only");
+    if (passes > 1u && p->integrator == MI355_INTEGRATOR_PRB) return fail(MI355_ERR_UNSUPPORTED, "passes > 1 (samples_per_pass): prb.py renders in one pass; built for `path` and `ptracer`");
+    if (passes > 1u && p->integrator == MI355_INTEGRATOR_PATH && s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE)
+        return fail(MI355_ERR_UNSUPPORTED, "passes > 1 with the realisticlens sensor: a ray blocked in the barrel is still walked by the reference and its draws cannot be reproduced");
     if (p->spp % passes) return fail(MI355_ERR_INVALID, "spp must be a multiple of passes");
     const uint32_t streams = p->spp / passes;
     if ((uint64_t) npix * streams > 0xffffffffull)
@@ -1724,6 +1740,10 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     // (bit 31 stands for every bounce >= 31 and must stay set: the count exchange is also the loop's exit test when max_depth = -1)
     a.compact_mask = p->mode == MI355_MODE_WAVEFRONT ? 0xffffffffu : 0xfffffffcu;
     a.compact_adaptive = p->mode == MI355_MODE_WAVEFRONT ? 0u : 1u;
+    if (p->integrator == MI355_INTEGRATOR_PATH && a.passes > 1u) {          // samples_per_pass: the static kernel walks the passes of a stream
+        if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+        else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
+    } else
     if (p->integrator == MI355_INTEGRATOR_PRB && p->mode == MI355_MODE_STATIC) {
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
@@ -1743,7 +1763,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.end())) return rc;
-    s->n_gen += a.n_local; s->n_splat += a.n_local;
+    s->n_gen += (uint64_t) a.n_local * a.passes; s->n_splat += (uint64_t) a.n_local * a.passes;
     return MI355_OK;
 }
 extern "C" int mi355_film_develop(mi355_scene *s, const float *d_film_rgbw, float *d_image_rgb, void *stream) {
@@ -1914,6 +1934,7 @@ extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
 extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_params *p, uint32_t lane_begin, uint32_t count, float *d_out, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_out) return fail(MI355_ERR_INVALID, "null output");
+    if (a.passes > 1u) return fail(MI355_ERR_UNSUPPORTED, "per-lane output is defined for single-pass jobs");
     uint64_t total = (uint64_t) s->ds.grid_w * s->ds.grid_h * p->spp;
     if ((uint64_t) lane_begin + count > total) return fail(MI355_ERR_INVALID, "lane range outside the job");
     HIP_TRY(hipSetDevice(s->device));

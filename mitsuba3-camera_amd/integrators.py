@@ -149,6 +149,13 @@ class Integrator:
                 raise PluginError("sample_count (%d) must be a multiple of samples_per_pass (%d)." % (int(spp), per))
             p.passes = int(spp) // per
         gw, gh = self.lane_grid(f); npix = gw * gh
+        # more than 2^32 samples in one wavefront: the reference splits the job into passes by itself (integrator.cpp:247-265, :681-698)
+        per_pass = int(spp) // max(int(p.passes), 1)
+        if npix * per_pass > 0xffffffff and self.integrator_id != abi.INTEGRATOR_PRB:
+            per_pass //= (npix * per_pass + 0xffffffff - 1) // 0xffffffff
+            while per_pass > 1 and int(spp) % per_pass:
+                per_pass -= 1
+            p.passes = int(spp) // max(per_pass, 1)
         if shard is not None:
             p.pixel_begin, p.pixel_count = shard[0], shard[1]
             if len(shard) == 4:

@@ -1253,6 +1253,10 @@ static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample
  * ---------------------------------------------------------------------------------------- */
 typedef struct { uint64_t isect, shade, shadow; } Cnt;
 
+/* keep_stream (samples_per_pass): every sampler call in the loop of path.cpp:142-281 is unmasked and the loop masks by `active` alone, so a
+   lane draws six numbers in EVERY iteration it enters -- also in the one that leaves the scene (:196, :212-213, :272) */
+static int g_path_keep_stream = 0;
+#pragma omp threadprivate(g_path_keep_stream)
 static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_params *rp, v3 *result_out, int *valid_out, Cnt *cnt) {
     uint32_t max_depth = (uint32_t) rp->max_depth, rr_depth = (uint32_t) rp->rr_depth;
     v3 throughput = V3(1, 1, 1), result = V3(0, 0, 0); float eta = 1.f; uint32_t depth = 0;
@@ -1277,7 +1281,7 @@ static void path_sample(OScene *sc, pcg32 *rng, Ray ray, const mi355_render_para
             result = fma3(throughput, scale3(le, mis_bsdf), result);
         }
         int active_next = (depth + 1 < max_depth) && si_valid;          /* path.cpp:177 */
-        if (!si_valid) { break; }                                       /* nothing below can affect the result */
+        if (!si_valid) { if (g_path_keep_stream) for (int k = 0; k < 6; ++k) (void) pcg32_float(rng); break; }   /* nothing below can affect the result */
         cnt->shade++;
         const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
         v3 refl = bsdf_reflectance(sc, bsdf, &si);
@@ -1895,7 +1899,8 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
 static void shard_bounds(const OScene *sc, const mi355_render_params *rp, uint32_t *p0, uint32_t *pn, uint32_t *s0, uint32_t *sn) {
     uint32_t npix = (sc->sensor.crop_width + 2u * sc->border) * (sc->sensor.crop_height + 2u * sc->border);
     *p0 = rp->pixel_begin; *pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin;
-    *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : rp->spp - rp->spp_begin;
+    uint32_t streams = rp->spp / (rp->passes ? rp->passes : 1u);         /* sampler streams per pixel (mi355.h: passes) */
+    *s0 = rp->spp_begin; *sn = rp->spp_count ? rp->spp_count : streams - rp->spp_begin;
 }
 static inline uint32_t shard_pixel(const mi355_render_params *rp, uint32_t q) {     /* mi355.h: pixel_tile */
     if (rp->pixel_tile == 0u) return rp->pixel_begin + q;
@@ -1953,12 +1958,26 @@ ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp
         Cnt cnt = { 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
         for (int64_t q = 0; q < (int64_t) pn; ++q) {
+            const uint32_t passes = rp->passes ? rp->passes : 1u, streams = rp->spp / passes;
             for (uint32_t s = s0; s < s0 + sn; ++s) {
-                uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;
-                v3 rgb; int valid; v2 pos;
-                trace_lane(sc, rp, lane, &rgb, &valid, &pos, &cnt);
-                float vals[4] = { rgb.x, rgb.y, rgb.z, 1.f };           /* integrator.cpp:477-486 (no alpha) */
-                film_put(sc, film, 4, pos, vals);
+                uint32_t lane = shard_pixel(rp, (uint32_t) q) * streams + s;
+                if (passes == 1u) {
+                    v3 rgb; int valid; v2 pos;
+                    trace_lane(sc, rp, lane, &rgb, &valid, &pos, &cnt);
+                    float vals[4] = { rgb.x, rgb.y, rgb.z, 1.f };       /* integrator.cpp:477-486 (no alpha) */
+                    film_put(sc, film, 4, pos, vals);
+                    continue;
+                }
+                /* samples_per_pass (integrator.cpp:283, :319-329): one seeding, `passes` samples from the same stream */
+                pcg32 rng; sampler_seed(&rng, rp->seed, lane);
+                for (uint32_t pass = 0; pass < passes; ++pass) {
+                    v2 pos; Ray ray; float w = camera_ray(sc, &rng, lane, streams, &pos, &ray);
+                    v3 rgb = V3(0, 0, 0); int valid = 0;
+                    g_path_keep_stream = 1; path_sample(sc, &rng, ray, rp, &rgb, &valid, &cnt); g_path_keep_stream = 0;
+                    rgb = scale3(rgb, w);
+                    float vals[4] = { rgb.x, rgb.y, rgb.z, 1.f };
+                    film_put(sc, film, 4, pos, vals);
+                }
             }
         }
         ci += cnt.isect; cs += cnt.shade; csh += cnt.shadow;
@@ -1966,7 +1985,7 @@ ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp
     for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
     free(films);
     sc->c_isect += ci; sc->c_shade += cs; sc->c_shadow += csh;
-    return (uint64_t) pn * sn;
+    return (uint64_t) pn * sn * (rp->passes ? rp->passes : 1u);
 }
 
 /* parameter layout shared with the engine's definition (include/mi355.h: mi355_scene_param_layout):

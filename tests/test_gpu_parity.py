@@ -647,6 +647,38 @@ def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
             mi.ParticleTracerIntegrator({}).render_forward(scene, params)
 
 
+@pytest.mark.parametrize("scene_name", ["cbox", "veach"])
+def test_path_samples_per_pass_matches_oracle(mi, orc, torch_cuda, scene_name):
+    """samples_per_pass for the path integrator on the device (the static kernel walks the passes of a stream and burns the draws of the
+    iterations whose body it skips): film against the oracle's, first pass == single-pass render, shards add up, prb refuses."""
+    torch = torch_cuda
+    scene = mi.load_dict(small_cbox(mi, 32) if scene_name == "cbox" else mi.veach_mis_scene(32))
+    o = orc.OracleScene(scene, mi.abi)
+    props = {"max_depth": 6, "rr_depth": 3, "samples_per_pass": 16}
+    integ = mi.PathIntegrator(props)
+    film = integ.render(scene, seed=4, spp=64, develop=False)
+    ref, lanes = o.render(o.params(integ, 4, 64), develop=False)
+    assert lanes == 32 * 32 * 64
+    f = film.cpu().numpy()
+    scale = np.percentile(ref[..., :3], 99)
+    if scene_name == "veach":
+        assert np.percentile(np.abs(f - ref), 99) < 5e-3 * scale * 64 and abs(f[..., :3].sum() / ref[..., :3].sum() - 1) < 5e-3
+    else:
+        assert np.abs(f - ref).max() < 1e-3 * np.abs(ref).max()
+    one = mi.PathIntegrator(dict(props, samples_per_pass=-1)).render(scene, seed=4, spp=16, develop=False).cpu().numpy()
+    rest = f - one
+    # the first pass IS the single-pass render of the same streams: what remains are three more passes' worth of (non-negative) splats
+    assert abs(rest[..., 3].sum() / f[..., 3].sum() - 0.75) < 0.01 and rest[..., 3].min() > 0 and rest[..., :3].min() > -1e-3 * scale
+    acc = torch.zeros_like(film)
+    for r in range(2):
+        p = integ._params(scene, 4, 64, shard=mi.shard_tiles(32, 32, r, 2, rows=8))
+        mi.abi.check(mi.abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, film, rtol=1e-3, atol=1e-3 * float(scale))
+    with pytest.raises(mi.Mi355Error):
+        mi.PRBIntegrator(props).render(scene, seed=4, spp=64)
+
+
 def test_film_sample_border_matches_oracle(mi, orc, torch_cuda):
     """Film::sample_border on the device: lanes over the grown grid (all forward kernels and the adjoint) against the oracle."""
     torch = torch_cuda
@@ -837,9 +869,9 @@ def test_particle_tracer_gradient_reference_test06(mi, orc, torch_cuda, kats):
     o = orc.OracleScene(scene, mi.abi)
     ref, _ = o.ptracer_render(o.params(integrator, 3, 64))
     assert np.allclose(img, ref, rtol=1e-4, atol=1e-6)
-    # the path / prb integrators refuse a multi-pass request instead of rendering something else
+    # prb.py renders in one pass: a multi-pass request is refused instead of rendering something else
     with pytest.raises(mi.Mi355Error):
-        mi.PathIntegrator({"max_depth": 4, "samples_per_pass": 16}).render(scene, seed=3, spp=64)
+        mi.PRBIntegrator({"max_depth": 4, "samples_per_pass": 16}).render(scene, seed=3, spp=64)
 
 
 def test_particle_tracer_reference_test01_to_05(mi, orc, torch_cuda):

@@ -261,3 +261,12 @@ def test_two_rank_sharding_over_gloo(mi, orc, tmp_path):
         assert np.allclose(np.load(tmp_path / ("img%d.npy" % r)), img_ref, rtol=1e-5, atol=1e-6)
         assert np.allclose(np.load(tmp_path / ("g%d.npy" % r)), g_ref, rtol=1e-4, atol=1e-6)
     assert np.abs(g_ref).max() > 0
+
+
+def test_huge_jobs_are_split_into_passes(mi):
+    """W * H * spp above 2^32: the reference divides the job into passes on its own (integrator.cpp:247-265); so does the host mirror."""
+    sc = mi.load_dict({"type": "scene", "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 4096, "height": 4096}},
+                       "r": {"type": "rectangle"}})
+    p = mi.PathIntegrator({"max_depth": 3})._params(sc, 0, 1024)
+    assert p.passes >= 5 and 1024 % p.passes == 0 and 4096 * 4096 * (1024 // p.passes) <= 0xffffffff
+    assert mi.PathIntegrator({"max_depth": 3})._params(sc, 0, 64).passes in (0, 1)

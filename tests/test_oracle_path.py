@@ -398,3 +398,24 @@ def test_particle_tracer_albedo_gradients_match_finite_differences(mi, orc):
     g1 = o.ptracer_backward(p, gin)
     eoff = [l for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE][0][2]
     assert np.allclose(g1[eoff:eoff + 3], g[eoff:eoff + 3]) and (np.delete(g1, [eoff, eoff + 1, eoff + 2]) == 0).all()
+
+
+def test_path_samples_per_pass(mi, orc):
+    """samples_per_pass for the path integrator (SamplingIntegrator::render, integrator.cpp:283, :319-329): one stream per pixel and
+    pass-sample, `passes` samples from it.  The first pass of a multi-pass render is the single-pass render of the same streams, and the
+    whole is an unbiased image; prb (one pass in prb.py) refuses."""
+    sc = mi.load_dict(small_cbox(mi, 16, rfilter={"type": "box"})); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.PathIntegrator({"max_depth": 5, "rr_depth": 3, "samples_per_pass": 4})
+    p = o.params(integ, 2, 16); assert p.passes == 4
+    multi, lanes = o.render(p, develop=False)
+    assert lanes == 16 * 16 * 16
+    one, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 5, "rr_depth": 3}), 2, 4), develop=False)      # the same 4 streams per pixel, first sample only
+    assert (multi[..., 3] == 16).all() and (one[..., 3] == 4).all()
+    # pass 1 of the multi-pass film = the single-pass film; passes 2-4 continue the streams with fresh numbers
+    rest = multi - one
+    assert (rest[..., 3] == 12).all() and np.isfinite(rest).all() and rest[..., :3].min() >= -1e-4
+    ref, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 5, "rr_depth": 3}), 9, 4096))
+    big, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 5, "rr_depth": 3, "samples_per_pass": 256}), 2, 1024), develop=False)
+    first, _ = o.render(o.params(mi.PathIntegrator({"max_depth": 5, "rr_depth": 3}), 2, 256), develop=False)
+    later = (big - first)[..., :3] / 768                                # passes 2-4 alone: the continued streams are as good as fresh ones
+    assert abs(later.mean() / ref.mean() - 1) < 0.025 and abs((big[..., :3] / 1024).mean() / ref.mean() - 1) < 0.02
