@@ -1222,8 +1222,10 @@ def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     p = integ._params(scene, 0, 4, shard=(256, 0))                       # empty shard: nothing to do, not an error
     mi.abi.check(mi.abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), None))
     torch.cuda.synchronize(); assert float(film.abs().max()) == 0.0
-    with pytest.raises(mi.Mi355Error):
-        integ.render(scene, seed=0, spp=1 << 25)                          # 256 * 2^25 = 2^33 lanes
+    p = integ._params(scene, 0, 1 << 25)                                  # 256 * 2^25 = 2^33 samples: split into passes as the reference does
+    assert p.passes >= 2 and 256 * ((1 << 25) // p.passes) <= 0xffffffff
+    p.passes = 0                                                          # ... and one wavefront of that size is refused by the C ABI
+    assert mi.abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), None) == mi.abi.ERR_INVALID
 
 
 def test_full_size_properties(mi, torch_cuda):
