@@ -1,5 +1,5 @@
 import sys, importlib, numpy as np, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mi = importlib.import_module("mitsuba3-camera_amd")
 for name, d in (("cbox1024", (lambda d: (d["sensor"]["film"].update(width=1024, height=1024), d)[1])(mi.cornell_box())), ("veach512", mi.veach_mis_scene(512))):

@@ -1,5 +1,5 @@
 import sys, importlib, time, ctypes as C
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mi = importlib.import_module("mitsuba3-camera_amd")
 sc = mi.load_dict(mi.veach_mis_scene(1024))

@@ -1,6 +1,6 @@
 """Section profile (build with -DMI_PROF, MI355_LIB=that build): wave cycles per section of path_step on the Veach scene."""
 import sys, importlib
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mi = importlib.import_module("mitsuba3-camera_amd")
 for name, sc in (("veach", mi.load_dict(mi.veach_mis_scene(1024))), ("cbox", mi.load_dict((lambda d: (d["sensor"]["film"].update(width=512, height=512), d)[1])(mi.cornell_box())))):
     integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); integ.mode = mi.abi.MODE_STATIC; integ.timing = True
