@@ -93,7 +93,8 @@ class HipBackend:
 
     def backward(self, scene, p, grad_in, weight, grads):
         abi.check(abi.lib().mi355_render_backward(scene.handle(), C.byref(p), C.c_void_p(grad_in.data_ptr()),
-                                                  C.c_void_p(weight.data_ptr()), C.c_void_p(grads.data_ptr()), _stream_ptr(grads.device)))
+                                                  C.c_void_p(weight.data_ptr()) if weight is not None else None,
+                                                  C.c_void_p(grads.data_ptr()), _stream_ptr(grads.device)))
 
     def param_total(self, scene):
         return scene_param_total(scene)
@@ -364,9 +365,7 @@ class ParticleTracerIntegrator(Integrator):
         value for the radiance (test_ptracer.py:204-225) is reproduced.  When `params` holds radiance keys only (params.keep), the
         cheaper single-walk kernel runs.  Gradients with respect to geometry / IORs are not built."""
         torch = _torch()
-        if params is None:
-            raise PluginError("ptracer.render_backward needs the SceneParameters that receive the gradients")
-        radiance_only = all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
+        radiance_only = params is not None and all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
         be = self.backend
         dev = be.device(scene)
         f = scene.sensor.film
@@ -378,12 +377,11 @@ class ParticleTracerIntegrator(Integrator):
         p = self._params(scene, seed, spp, shard=band)
         if radiance_only:
             p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
-        grads = params.grad_buffer(dev)
+        grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(be.param_total(scene), 1), dtype=torch.float32, device=dev)
         multi = shard is not None and shard[1] > 1
         local = torch.zeros_like(grads) if multi else grads
         if band is None or band[1] > 0:
-            abi.check(abi.lib().mi355_render_backward(scene.handle(), C.byref(p), C.c_void_p(grad_in.data_ptr()), None,
-                                                      C.c_void_p(local.data_ptr()), _stream_ptr(dev)))
+            be.backward(scene, p, grad_in, None, local)                    # (the normalised splat has no weight image)
         if multi:
             import torch.distributed as dist
             dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)

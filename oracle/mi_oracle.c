@@ -1800,13 +1800,28 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
     }
     *rng_io = rng;
 }
+/* The shard of the particle tracer's lane grid (film pixels x sampler streams per pixel) a call covers: mi355_render_params's pixel /
+   tile / spp fields over the FILM grid, exactly as the engine's make_args reads them. */
+static inline uint32_t shard_pixel(const mi355_render_params *rp, uint32_t q);
+static uint64_t pt_shard_lanes(const OScene *sc, const mi355_render_params *rp) {
+    uint32_t passes = rp->passes ? rp->passes : 1u, streams = rp->spp / passes, npix = sc->sensor.film_width * sc->sensor.film_height;
+    uint32_t pn = rp->pixel_count ? rp->pixel_count : npix - rp->pixel_begin, sn = rp->spp_count ? rp->spp_count : streams - rp->spp_begin;
+    if (rp->pixel_begin >= npix && rp->pixel_count == 0) return 0;
+    return (uint64_t) pn * sn;
+}
+static uint32_t pt_shard_lane(const OScene *sc, const mi355_render_params *rp, uint64_t i) {
+    uint32_t passes = rp->passes ? rp->passes : 1u, streams = rp->spp / passes;
+    uint32_t sn = rp->spp_count ? rp->spp_count : streams - rp->spp_begin;
+    (void) sc;
+    return shard_pixel(rp, (uint32_t) (i / sn)) * streams + rp->spp_begin + (uint32_t) (i % sn);
+}
 /* AdjointIntegrator::render: lanes = FILM size * spp (not crop), sample_scale = prod(crop) / (spp * prod(film)).  The
    accumulator is RGBW with W untouched = 0, so orc_film_develop divides by 1 (hdrfilm.cpp:396-400). */
 ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
     size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
     uint32_t passes = rp->passes ? rp->passes : 1u;
     if (rp->spp % passes) return 0;
-    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * (rp->spp / passes);
+    uint64_t lanes = pt_shard_lanes(sc, rp);
     if (sc->n_emitters == 0) return 0;                                                              /* integrator.cpp:590-600 */
     float sample_scale = (float) (sc->sensor.crop_width * sc->sensor.crop_height) / (float) ((uint64_t) rp->spp * sc->sensor.film_width * sc->sensor.film_height);
 #ifdef _OPENMP
@@ -1826,7 +1841,7 @@ ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *r
         Cnt cnt = { 0, 0, 0 };
         g_importance_mode = 1;
         #pragma omp for schedule(dynamic, 4096)
-        for (int64_t lane = 0; lane < (int64_t) lanes; ++lane) ptracer_lane(sc, rp, (uint32_t) lane, sample_scale, film, &cnt);
+        for (int64_t i = 0; i < (int64_t) lanes; ++i) ptracer_lane(sc, rp, pt_shard_lane(sc, rp, (uint64_t) i), sample_scale, film, &cnt);
         g_importance_mode = 0;
         ci += cnt.isect; cs += cnt.shade; csh += cnt.shadow;
     }
@@ -1857,7 +1872,7 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
     }
     uint32_t passes = rp->passes ? rp->passes : 1u;
     if (rp->spp % passes || sc->n_emitters == 0) return 0;
-    uint64_t lanes = (uint64_t) sc->sensor.film_width * sc->sensor.film_height * (rp->spp / passes);
+    uint64_t lanes = pt_shard_lanes(sc, rp);
     float sample_scale = (float) (sc->sensor.crop_width * sc->sensor.crop_height) / (float) ((uint64_t) rp->spp * sc->sensor.film_width * sc->sensor.film_height);
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -1879,7 +1894,7 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
         g_importance_mode = 1; g_ptg.grad_image = grad_image; g_ptg.acc = acc;
         g_ptg.grad = gl; g_ptg.layout = layout; g_ptg.bsdf_slot = bsdf_slot; g_ptg.tex_slot = tex_slot;
         #pragma omp for schedule(dynamic, 4096)
-        for (int64_t lane = 0; lane < (int64_t) lanes; ++lane) ptracer_lane(sc, rp, (uint32_t) lane, sample_scale, NULL, &cnt);
+        for (int64_t i = 0; i < (int64_t) lanes; ++i) ptracer_lane(sc, rp, pt_shard_lane(sc, rp, (uint64_t) i), sample_scale, NULL, &cnt);
         g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL; g_ptg.grad = NULL;
     }
     if (grads) { for (int t = 0; t < n_threads; ++t) for (uint64_t i = 0; i < total; ++i) grad_out[i] += grads[total * (size_t) t + i]; free(grads); }

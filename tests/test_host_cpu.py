@@ -233,10 +233,13 @@ def _worker(rank, world, port, out_dir):
         """Stands in for the HIP back-end so that the sharding + collectives of integrators.py run on CPU."""
         name = "oracle-test"
         def device(self, scene): return torch.device("cpu")
-        def accumulate(self, scene, p, film): film += torch.from_numpy(o.render(p, threads=2, develop=False)[0])
+        def accumulate(self, scene, p, film):
+            film += torch.from_numpy((o.ptracer_render if p.integrator == mi.abi.INTEGRATOR_PTRACER else o.render)(p, threads=2, develop=False)[0])
         def develop(self, scene, film, img): img.copy_(torch.from_numpy(o.develop(film.numpy())))
         def splat_weights(self, scene, p, weight): weight += torch.from_numpy(o.splat_weights(p))
-        def backward(self, scene, p, grad_in, weight, grads): grads += torch.from_numpy(o.render_backward(p, grad_in.numpy(), weight.numpy(), threads=2))
+        def backward(self, scene, p, grad_in, weight, grads):
+            if p.integrator == mi.abi.INTEGRATOR_PTRACER: grads += torch.from_numpy(o.ptracer_backward(p, grad_in.numpy(), threads=2))
+            else: grads += torch.from_numpy(o.render_backward(p, grad_in.numpy(), weight.numpy(), threads=2))
         def param_total(self, scene): return o.param_layout()[1]
         def synchronize(self, device): pass
 
@@ -245,7 +248,14 @@ def _worker(rank, world, port, out_dir):
     gin = np.random.default_rng(5).normal(size=(32, 32, 3)).astype(np.float32)
     g = integ.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4, shard=(rank, world))
     np.save(os.path.join(out_dir, "img%d.npy" % rank), img.numpy()); np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
+    pt = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 3}); pt.backend = OracleBackend()     # the light tracer shards over the FILM grid
+    pimg = pt.render(scene, seed=3, spp=4, shard=(rank, world))
+    pg = pt.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4, shard=(rank, world))
+    np.save(os.path.join(out_dir, "pimg%d.npy" % rank), pimg.numpy()); np.save(os.path.join(out_dir, "pg%d.npy" % rank), pg.numpy())
     if rank == 0:
+        wpt = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 3}); wpt.backend = OracleBackend()
+        np.save(os.path.join(out_dir, "pimg_ref.npy"), wpt.render(scene, seed=3, spp=4).numpy())
+        np.save(os.path.join(out_dir, "pg_ref.npy"), wpt.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4).numpy())
         whole = mi.PRBIntegrator({"max_depth": 4}); whole.backend = OracleBackend()
         np.save(os.path.join(out_dir, "img_ref.npy"), whole.render(scene, seed=3, spp=4).numpy())
         np.save(os.path.join(out_dir, "g_ref.npy"), whole.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4).numpy())
@@ -260,6 +270,11 @@ def test_two_rank_sharding_over_gloo(mi, orc, tmp_path):
     for r in range(2):
         assert np.allclose(np.load(tmp_path / ("img%d.npy" % r)), img_ref, rtol=1e-5, atol=1e-6)
         assert np.allclose(np.load(tmp_path / ("g%d.npy" % r)), g_ref, rtol=1e-4, atol=1e-6)
+    pimg_ref = np.load(tmp_path / "pimg_ref.npy"); pg_ref = np.load(tmp_path / "pg_ref.npy")
+    assert pimg_ref.max() > 0 and np.abs(pg_ref).max() > 0
+    for r in range(2):          # particle tracer: film shards and gradient shards add up to the whole on every rank
+        assert np.allclose(np.load(tmp_path / ("pimg%d.npy" % r)), pimg_ref, rtol=1e-4, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / ("pg%d.npy" % r)), pg_ref, rtol=1e-3, atol=1e-5 * np.abs(pg_ref).max())
     assert np.abs(g_ref).max() > 0
 
 
