@@ -809,8 +809,8 @@ def test_particle_tracer_matches_oracle(mi, orc, torch_cuda, case):
         path = mi.PathIntegrator(props).render(scene, seed=1, spp=1024).cpu().numpy()
         pt = integ.render(scene, seed=1, spp=1024).cpu().numpy()
         assert abs(pt.mean() / path.mean() - 1) < 0.015
-        with pytest.raises(mi.PluginError):
-            integ.render_backward(scene, None, None)
+        g0 = integ.render_backward(scene, None, torch.zeros((32, 32, 3)), seed=1, spp=4)      # no SceneParameters: a fresh gradient buffer
+        assert g0.numel() == o.param_layout()[1] and float(g0.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("rfilter", [{"type": "gaussian"}, {"type": "tent"}, {"type": "gaussian", "stddev": 0.3}])
