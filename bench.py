@@ -212,6 +212,16 @@ def main():
         c3 = prb_i.counters(scene3, reset=True)
         if dist is not None:
             tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
+        fwd_ms = None
+        if world == 1:                     # Integrator::render_forward on the same scene (timing only): tangent 1 on every parameter
+            for k_ in params.keys():
+                params.set_tangent(k_, 1.0)
+            prb_i.render_forward(scene3, params, seed=0, spp=args.prb_spp); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n_prb):
+                prb_i.render_forward(scene3, params, seed=i, spp=args.prb_spp)
+            torch.cuda.synchronize(dev); fwd_ms = round((time.perf_counter() - t0) / n_prb * 1e3, 3)
+            prb_i.counters(scene3, reset=True)
         g = params.grad("tex.reflectance.data") if not args.prb_plain else params.grad_buffer(dev)
         prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
@@ -223,7 +233,7 @@ def main():
                    # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
                    ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
                    + 8 * params.grad_buffer(dev).numel()),
-               "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
+               "render_forward_ms": fwd_ms, "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
         scene3.release()
 
     # ---- optional: config C4 (FULL kernels: glossy / specular BSDFs, spheres), tile-sharded like the headline leg ----
