@@ -677,9 +677,6 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     // Walking them with a stride that is coprime to their number puts different pixels into the lanes of one LDS atomic
     // instruction, which would otherwise serialise on the shared table entry (PMC: LDS unit 50 % busy before this).
     const uint32_t stride = n_rec_tex % 61u ? 61u : (n_rec_tex % 67u ? 67u : 1u);
-#ifdef MI_EXP_SKIP_TEX_FLUSH                                                 // timing experiment only
-    if (false)
-#endif
     for (uint32_t e = threadIdx.x; e < n_rec_tex * 4u; e += BLOCK) {
         const uint32_t rec = (uint32_t) (((uint64_t) (e >> 2) * stride) % n_rec_tex), tap = e & 3u;
         const uint32_t g = q_granules - 3u * (rec + 1u);
@@ -1884,9 +1881,6 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         const uint32_t lds_budget = (full ? 40960u : 163840u / MI_MIN_WAVES_1P);
         if (static_lds + small_bytes + 256u + 64u * 16u > lds_budget) return fail(MI355_ERR_UNSUPPORTED, "no LDS left for the gradient record queue");
         uint32_t q_granules = (lds_budget - 256u - static_lds - small_bytes) / 16u;
-#ifdef MI_EXP_QCAP                                                          // experiment: how small may the queue be?
-        if (const char *qc = getenv("MI355_Q_GRANULES")) q_granules = std::min(q_granules, (uint32_t) atoi(qc));
-#endif
         const uint32_t dyn_bytes = small_bytes + q_granules * 16u;
 #define LAUNCH_1P(F, B) hipLaunchKernelGGL((k_prb_backward_1p<F, B>), grid, block, dyn_bytes, st, s->ds, a, (const float4 *) s->d_gw, d_grad_params, s->d_small_map, n_small, s->d_counters, redo, q_granules, copy_shift)
         if (full) { if (bvh) LAUNCH_1P(true, true); else LAUNCH_1P(true, false); }
