@@ -128,6 +128,14 @@ class Integrator:
     def aov_names(self):
         return []
 
+    def cancel(self):
+        """Integrator::cancel (integrator.h:293-297, integrator.cpp:90-92).  A render is one kernel launch here, so there is nothing to
+        interrupt half-way; the flag is honoured between the launches of host-side loops (tune(), optimisation examples)."""
+        self._stop = True
+
+    def should_stop(self):
+        return getattr(self, "_stop", False)
+
     def lane_grid(self, film):
         """Pixel grid the lanes are laid over: lane = pixel * spp + s -- the crop window of a sampling integrator, grown by the
         filter's border on every side when the film samples its border (integrator.cpp:133-134)."""
