@@ -181,6 +181,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "peak_measured_copy": None if copy_gbs is None else round(copy_gbs, 1),
                 "frac_of_measured_copy": None if copy_gbs is None else round(achieved / copy_gbs, 4),
+                "note": "achieved = algorithmic bytes of the SoA wavefront formulation (SURVEY.md 8d) / kernel time; the fused kernel keeps them in registers and is VALU-issue bound (DESIGN.md 4, profiles/r01_n_pmc_summary.txt), so frac can exceed 1 while the measured HBM traffic stays at `traffic`",
                 "kernel": KERNEL_NAME, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg),
                 "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}
