@@ -755,9 +755,10 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
     }
 }
 
-// Particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per light sample; a.n_local lanes of the shard, global
-// lane id = pixel * spp + s over the FILM grid.  Every connection splats normalised filter weights with plain float atomics --
-// the positions are scattered over the film, there is nothing to pre-reduce per wave.
+// Particle tracer (ptracer.cpp under AdjointIntegrator::render): one lane per sampler stream (a.passes light samples each); a.n_local
+// lanes of the shard, global lane id = pixel * (spp / passes) + s over the FILM grid.  A connection's normalised splat is appended to
+// the record queue (`queue.cap` != 0; film_put_deferred) and resolved by the k_splat_* kernels below, or -- queue full, or
+// MI355_FLAG_DIRECT_SPLAT -- added to the film with plain float atomics.
 // GRAD (render_backward): the same lanes, but every connection GATHERS dL/dimage at its splat taps.  Radiance gradients need one walk;
 // with `all_params` every sample is walked twice from the same sampler state (see PtGradSink) for the albedo / texture gradients.
 // The small-parameter accumulators live in dynamic LDS: (n_small << copy_shift) floats.
