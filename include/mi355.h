@@ -2,8 +2,8 @@
  * mi355.h -- C ABI of the MI355X-native path-tracing / Path-Replay-Backprop engine.
  *
  * This is the drop-in boundary for ONE hot path of Mitsuba 3 (gitmon/mitsuba3-camera):
- * the body of Integrator::render / render_backward for the `path` and `prb`
- * integrators on surface-only RGB scenes.  A Mitsuba-side shim
+ * the body of Integrator::render / render_forward / render_backward for the `path`, `prb`
+ * and `ptracer` integrators on surface-only RGB scenes.  A Mitsuba-side shim
  * flattens Scene/Shape/BSDF/Emitter/Sensor objects into the POD records below and
  * forwards to these entry points.  All paths cited are relative to the reference tree.
  *
@@ -18,6 +18,11 @@
  *   Scene::ray_intersect / ray_test                       src/render/scene.cpp:181-210
  *   Film::prepare / put_block / develop (hdrfilm, RGBW)   src/films/hdrfilm.cpp:245-409
  *   SceneParameters.update -> parameters_changed          src/python/python/util.py:185-232
+ *   Integrator::render_forward(scene,params,..)           include/mitsuba/render/integrator.h:104-190,
+ *                                                         src/python/python/ad/integrators/common.py:498-629
+ *   ParticleTracerIntegrator::sample under                src/integrators/ptracer.cpp:77-371,
+ *     AdjointIntegrator::render (+ render_backward)       src/render/integrator.cpp:545-745, :65-84
+ *   Film::sample_border, samples_per_pass                 src/render/film.cpp:32, src/render/integrator.cpp:133-150,319-329
  *
  * Conventions
  *   - plain C, no torch / HIP types in any signature; `void *stream` is a hipStream_t
