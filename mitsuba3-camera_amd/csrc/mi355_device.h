@@ -1777,27 +1777,6 @@ MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, 
         p = fma3s(local, radius, center); n = (sh.flags & DSHAPE_FLIP) ? -local : local; pdf = sh.inv_area;
     }
 }
-// ImageBlock::put with normalize = true (imageblock.cpp:460-474): per-sample weights divided by their sum; RGB only, the weight
-// channel is never touched (ptracer.cpp:366-368).  Splat positions are scattered over the film: plain float atomics.
-MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, float pos_y, v3 rgb) {
-    Splat sp = splat_weights(sc, pos_x, pos_y);
-    float sx = 0.f, sy = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI_MAX_TAPS; ++i) { sx += i < sp.count ? sp.wx[i] : 0.f; sy += i < sp.count ? sp.wy[i] : 0.f; }
-    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
-    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
-#pragma unroll
-    for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
-            int32_t x = sp.x0 + tx, y = sp.y0 + ty;
-            if (ty >= sp.count || tx >= sp.count || x < 0 || y < 0 || x >= W || y >= H) continue;
-            float w = sp.wy[ty] * (sp.wx[tx] * factor);
-            if (w == 0.f) continue;                                         // (adding 0 changes nothing: skip the memory-side atomics)
-            float *px = film + ((size_t) y * W + x) * 4;
-            atomicAdd(px, rgb.x * w); atomicAdd(px + 1, rgb.y * w); atomicAdd(px + 2, rgb.z * w);
-        }
-}
 // Deferred splat of the particle tracer (reconstruction filters with more than one tap): a connection's 5 x 5 normalised taps cost
 // 75 memory-side float atomics scattered over the film -- the atomic units, not the tracing, then set the pace (Cornell box 512^2 x
 // 64 spp: 234 ms against 15 ms with a box filter).  Instead the connection is APPENDED as one 20-byte record (film position, colour)
@@ -1819,6 +1798,31 @@ MI_DEV uint32_t splat_tile_of(const DScene &sc, const SplatQueue &q, float pos_x
     cx = min(max(cx, 0), (int32_t) sc.crop_w - 1); cy = min(max(cy, 0), (int32_t) sc.crop_h - 1);
     return (uint32_t) (cy / MI_SPLAT_TILE) * q.tiles_x + (uint32_t) (cx / MI_SPLAT_TILE);
 }
+// ImageBlock::put with normalize = true (imageblock.cpp:460-474): per-sample weights divided by their sum; RGB only, the weight channel is
+// never touched (ptracer.cpp:366-368).  The direct splat -- the overflow path of the record queue, MI355_FLAG_DIRECT_SPLAT, films too
+// large for the tile sort.  The taps are walked by ROLLED loops that re-evaluate the filter per tap: it is bound by the memory-side
+// atomics anyway, and unrolled its 25 taps sat in the middle of the tracing loop and cost it a thousand SGPR spill moves.
+MI_DEV void film_put_normalized(const DScene &sc, float *film, float pos_x, float pos_y, v3 rgb) {
+    const bool box = sc.rfilter == MI355_RFILTER_BOX;
+    const int n = box ? 0 : (int) ceilf(sc.filter_radius - .5f), count = 2 * n + 1;
+    const int32_t pix = (int32_t) floorf(pos_x) - n, piy = (int32_t) floorf(pos_y) - n;
+    const float rx0 = (float) pix + .5f - pos_x, ry0 = (float) piy + .5f - pos_y;
+    float sx = 0.f, sy = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < count; ++i) { sx += box ? 1.f : filter_eval(sc, rx0 + (float) i); sy += box ? 1.f : filter_eval(sc, ry0 + (float) i); }
+    float factor = sx * sy; factor = factor != 0.f ? 1.f / factor : 0.f;
+    const int W = (int) sc.crop_w, H = (int) sc.crop_h;
+#pragma unroll 1
+    for (int t = 0; t < count * count; ++t) {
+        const int ty = t / count, tx = t - ty * count;
+        const int32_t x = pix + tx - (int32_t) sc.crop_x, y = piy + ty - (int32_t) sc.crop_y;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        const float w = (box ? 1.f : filter_eval(sc, ry0 + (float) ty)) * ((box ? 1.f : filter_eval(sc, rx0 + (float) tx)) * factor);
+        if (w == 0.f) continue;
+        float *px = film + ((size_t) y * W + x) * 4;
+        atomicAdd(px, rgb.x * w); atomicAdd(px + 1, rgb.y * w); atomicAdd(px + 2, rgb.z * w);
+    }
+}
 // Called by every lane of the (possibly partial) wave that reached the connection; `put` = this lane has something to splat.
 MI_DEV void film_put_deferred(const DScene &sc, const SplatQueue &q, float *film, float pos_x, float pos_y, v3 rgb, bool put) {
     if (put) {                                                              // nothing of it inside the crop window?
@@ -1838,7 +1842,7 @@ MI_DEV void film_put_deferred(const DScene &sc, const SplatQueue &q, float *film
     if (local < q.seg_cap && base <= 0xffffffffu - 64u) {
         const uint32_t idx = seg * q.seg_cap + local;
         q.rec_a[idx] = make_float4(pos_x, pos_y, rgb.x, rgb.y); q.rec_b[idx] = rgb.z;
-    } else film_put_normalized(sc, film, pos_x, pos_y, rgb);               // queue full: the slow way, same result
+    } else film_put_normalized(sc, film, pos_x, pos_y, rgb);        // queue full: the slow way, same result
 }
 // Adjoint of the normalised splat: the film is linear in the splatted colour, so dL/d(colour) = sum over taps of w * dL/dfilm.
 MI_DEV v3 film_gather_normalized(const DScene &sc, const float *grad_rgb, float pos_x, float pos_y) {
