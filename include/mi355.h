@@ -35,6 +35,12 @@
  *     Mitsuba's Transform4f::matrix.
  *   - all arithmetic is fp32; indices u32; RNG state u64 (TEA-seeded PCG32 per lane,
  *     src/render/sampler.cpp:116-135).
+ *   - ONE call in flight per scene handle: a handle owns scratch buffers (the grad_in / W image, redo flags, the particle
+ *     tracer's record queue and path tape, event slots, counters) that every entry point re-uses, so two calls on one handle must be
+ *     ordered -- same stream, or the first one synchronised -- exactly as Integrator::render is called from one thread
+ *     (SURVEY.md 8b "Threading").  Different handles are independent.
+ *   - every `d_` buffer must be ordinary (coarse-grained) device memory -- hipMalloc, or a torch CUDA tensor: the library is
+ *     built with -munsafe-fp-atomics (hardware float atomics), which are undefined on fine-grained / managed / host-pinned memory.
  */
 #ifndef MI355_H
 #define MI355_H
@@ -46,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 6u
+#define MI355_ABI_VERSION 7u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -177,6 +183,10 @@ typedef struct mi355_scene_desc {
 #define MI355_FLAG_EMITTER_GRADS_ONLY 16u /* render_backward with MI355_INTEGRATOR_PTRACER: only the MI355_PARAM_EMITTER_RADIANCE slots are
                                           wanted -- one walk per light path instead of the two that albedo / texture gradients need */
 
+#define MI355_FLAG_GEOMETRY_GRADS 64u  /* render_backward with MI355_INTEGRATOR_PTRACER: ALSO fill the MI355_PARAM_VERTEX_POSITIONS and MI355_PARAM_BSDF_IOR
+                                          slots -- the reverse-mode geometry / IOR adjoint of the light paths (one extra walk per light path with a
+                                          path tape in HBM; DESIGN.md "geometry adjoint").  Perspective sensor, finite max_depth <= 32 */
+
 #define MI355_FLAG_DIRECT_SPLAT   32u  /* particle tracer: splat every connection with direct float atomics instead of the default deferred,
                                           tile-sorted splat (same film up to summation order; a debugging / comparison switch -- Gaussian
                                           filter 234.6 ms against 7.1 ms on the Cornell box 512^2 x 64 spp) */
@@ -232,10 +242,21 @@ typedef struct mi355_counters {
                                            two-pass kernel redid (0 on the benchmark scenes) */
 } mi355_counters;
 
-/* One differentiable parameter (ParamFlags::Differentiable in traverse()). */
+/* One differentiable parameter (ParamFlags::Differentiable in traverse()).  The gradient buffer concatenates, in this order: the
+   constant diffuse reflectances, the textures, the emitter radiances, the vertex positions of every mesh, the IOR pairs of every
+   dielectric.  path / prb write the first three groups (prb.py detaches the intersection, so its geometry gradient is zero); the
+   particle tracer writes all of them when MI355_FLAG_GEOMETRY_GRADS is set. */
 enum { MI355_PARAM_BSDF_REFLECTANCE = 0,   /* 3 floats      diffuse.cpp:97-99 / srgb.cpp:70-72 */
        MI355_PARAM_TEXTURE_DATA     = 1,   /* H*W*C floats  bitmap.cpp:308-311 */
-       MI355_PARAM_EMITTER_RADIANCE = 2 }; /* 3 floats      area.cpp:78-81 */
+       MI355_PARAM_EMITTER_RADIANCE = 2,   /* 3 floats      area.cpp:78-81 */
+       MI355_PARAM_VERTEX_POSITIONS = 3,   /* 3*vertex_count floats, index = shape: `vertex_positions` of a mesh, world space (mesh.cpp:1602-1611,
+                                              mesh.h:523).  Setting it is Mesh::parameters_changed (mesh.cpp:96-163) + Scene::parameters_changed
+                                              (scene.cpp:481-529): bounding boxes and the acceleration structure are REFITTED on the device (topology
+                                              kept), and a mesh that has vertex normals gets them recomputed from the new positions
+                                              (recompute_vertex_normals, mesh.cpp:321-413, angle-weighted) -- from then on its shading normals are
+                                              functions of the positions for the derivative passes as well, as under Dr.Jit's AD */
+       MI355_PARAM_BSDF_IOR         = 4 }; /* 2 floats (int_ior, ext_ior), index = bsdf: a `dielectric`'s indices (dielectric.cpp:236-239), or a
+                                              `dispersive` material's indices at 589.3 nm (dispersive_dielectric.cpp:236-239, :411-432 in RGB builds) */
 
 typedef struct mi355_param_info {
     uint32_t kind;                      /* MI355_PARAM_* */
@@ -255,7 +276,8 @@ uint32_t    mi355_abi_version(void);
 int mi355_scene_create(const mi355_scene_desc *desc, int device, mi355_scene **out);
 int mi355_scene_destroy(mi355_scene *scene);
 
-/* SceneParameters.update for one parameter (util.py:185-232).  `values` is HOST memory. */
+/* SceneParameters.update for one parameter (util.py:185-232).  `values` is HOST memory.  Geometry updates
+   (MI355_PARAM_VERTEX_POSITIONS) only mark the replica dirty; the refit runs once, on the stream of the next call that traces rays. */
 int mi355_scene_set_param(mi355_scene *scene, uint32_t kind, uint32_t index,
                           const float *values, uint64_t count);
 /* Same, `d_values` is DEVICE memory (optimiser state that already lives in HBM). */
@@ -278,7 +300,8 @@ int mi355_render_accumulate(mi355_scene *scene, const mi355_render_params *p,
 /* HDRFilm::develop (hdrfilm.cpp:304-409): rgb / (W==0 ? 1 : W) -> crop_h x crop_w x 3 (DEVICE). */
 int mi355_film_develop(mi355_scene *scene, const float *d_film_rgbw, float *d_image_rgb, void *stream);
 
-/* clear + accumulate + develop in one call: what Integrator::render returns. */
+/* clear + accumulate + develop in one call: what Integrator::render returns.  d_image_rgb may be NULL: Integrator::render with
+   develop = false (integrator.h:74-120) -- the film is accumulated and left undeveloped in d_film_rgbw. */
 int mi355_render(mi355_scene *scene, const mi355_render_params *p,
                  float *d_film_rgbw, float *d_image_rgb, void *stream);
 
@@ -299,7 +322,10 @@ int mi355_prb_splat_weights(mi355_scene *scene, const mi355_render_params *p,
    Emitter radiances, constant diffuse reflectances and reflectance textures -- every parameter of mi355_scene_param_layout -- receive
    their gradients (path replay: two walks per light path; MI355_FLAG_EMITTER_GRADS_ONLY: radiances only, one walk).  d_weight is
    unused and may be NULL: the normalised splat has no weight channel.  The roulette probability is treated as detached (path.cpp:272
-   does so explicitly, ptracer.cpp:277 does not; identical while depth <= rr_depth).  Geometry / IOR gradients are not built. */
+   does so explicitly, ptracer.cpp:277 does not; identical while depth <= rr_depth).  With MI355_FLAG_GEOMETRY_GRADS the vertex positions
+   of every mesh and the IORs of every dielectric receive their gradients too (what notebooks/scripts/lens_design/design_problem.py:508-549
+   back-propagates through): a hand-written reverse mode of ptracer.cpp:200-371 over a recorded path, mitsuba3-camera_amd/csrc/
+   mi355_geo_adjoint.h.  Visibility and discrete choices are not differentiated, as in AD. */
 int mi355_render_backward(mi355_scene *scene, const mi355_render_params *p,
                           const float *d_grad_in, const float *d_weight,
                           float *d_grad_params, void *stream);

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -20,10 +20,10 @@ SENSOR_PERSPECTIVE, SENSOR_REALISTICLENS = 0, 1
 RFILTER_BOX, RFILTER_GAUSSIAN, RFILTER_TENT = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
-FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY, FLAG_DIRECT_SPLAT = 1, 2, 4, 8, 16, 32
+FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY, FLAG_DIRECT_SPLAT, FLAG_GEOMETRY_GRADS = 1, 2, 4, 8, 16, 32, 64
 MODE_FUSED, MODE_WAVEFRONT, MODE_STATIC = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_PRB, INTEGRATOR_PTRACER = 0, 1, 2
-PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE = 0, 1, 2
+PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE, PARAM_VERTEX_POSITIONS, PARAM_BSDF_IOR = 0, 1, 2, 3, 4
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

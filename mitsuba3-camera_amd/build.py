@@ -10,14 +10,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "mi355_engine.hip")]
-HDR = [os.path.join(HERE, "csrc", "mi355_device.h"), os.path.join(HERE, "csrc", "mi355_geo_forward.h"), os.path.join(ROOT, "include", "mi355.h")]
+HDR = [os.path.join(HERE, "csrc", h) for h in ("mi355_device.h", "mi355_geo_forward.h", "mi355_geo_adjoint.h", "mi355_geo_backward.h")] + [os.path.join(ROOT, "include", "mi355.h")]
 LIB = os.path.join(HERE, "libmi355.so")
 
 # -ffp-contract=off: only the fmaf() written in the source fuse (same rule as the CPU oracle and as
 # Dr.Jit's explicit fmadd), so lanes agree with the reference arithmetic instead of with the optimiser.
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off", "-munsafe-fp-atomics", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    "-ffp-contract=off", "-munsafe-fp-atomics", "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function",
 ]
 

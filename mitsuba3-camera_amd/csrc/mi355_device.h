@@ -31,6 +31,8 @@
 #define DSHAPE_FLIP      1u
 #define DSHAPE_HAS_NRM   2u
 #define DSHAPE_HAS_UV    4u
+#define DSHAPE_NRM_DEP   8u          // the vertex normals were recomputed from the positions by a parameter update (Mesh::parameters_changed ->
+                                     // recompute_vertex_normals, mesh.cpp:138-139): the derivative passes treat them as functions of the positions
 
 struct DShape {                      // 176 B, read through the scalar cache
     uint32_t type, bsdf; int32_t emitter; uint32_t flags;
@@ -42,7 +44,7 @@ struct DShape {                      // 176 B, read through the scalar cache
     int32_t  bvh_root;               // -1: scan the triangles linearly
     float bbox_min[3], bbox_max[3];
     uint32_t cdf_offset;             // mesh: into DScene::area_cdf (inclusive prefix sums of the face areas, ORIGINAL face order)
-    uint32_t pad[1];
+    uint32_t grad_offset;            // mesh: offset of its MI355_PARAM_VERTEX_POSITIONS block in the gradient buffer (0xffffffff: none)
 };
 struct DTri { float p0[3], e1[3], e2[3]; };               // mesh.h:438: e1 = p1-p0, e2 = p2-p0 precomputed (same arithmetic)
 // Flat, wave-uniform primitive: a parallelogram frame P0 + s*Es + t*Et, stored as the affine map world -> (s, t, h)
@@ -80,7 +82,9 @@ struct DBsdf {                       // 96 B
     float eta[3], k[3];
     float rel_eta;                                                      // dielectric: int_ior / ext_ior (dielectric.cpp:222)
     float transmittance[3];
-    uint32_t pad[4];
+    float ext_ior;                                                      // dielectric: the denominator of rel_eta (IOR gradients / updates)
+    int32_t ior_grad_offset;                                            // offset of the (int_ior, ext_ior) pair in the gradient buffer, or -1
+    uint32_t pad[2];
 };
 struct DSphere { float center[3]; float radius; uint32_t shape; uint32_t pad[3]; };   // sphere.cpp:158-159
 struct DEmitter { uint32_t type; float radiance[3]; uint32_t shape; int32_t grad_slot; uint32_t pad[2]; };
@@ -353,7 +357,7 @@ MI_DEV bool prim_test(P pr, const Ray &ray, float tlim, float &t, float &s, floa
     float dh = fmaf(m[10], ray.d.z, fmaf(m[9], ray.d.y, m[8] * ray.d.x));
     t = -oh * rcp_(dh);
     s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
-    return (t >= 0.f) & (t < tlim) & (fminf(s, u) >= pr->lo) & (fmaxf(s, u) <= 1.f) & (s + u <= pr->smax);
+    return ((int) (t >= 0.f) & (int) (t < tlim) & (int) (fminf(s, u) >= pr->lo) & (int) (fmaxf(s, u) <= 1.f) & (int) (s + u <= pr->smax)) != 0;   // branch-free on purpose
 }
 MI_DEV float excl_limit(float maxt) { return maxt >= MI_LARGEST ? MI_INF : __uint_as_float(__float_as_uint(maxt) + 1u); }
 

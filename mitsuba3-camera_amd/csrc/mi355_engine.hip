@@ -24,6 +24,7 @@
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
 #include "mi355_device.h"
 #include "mi355_geo_forward.h"
+#include "mi355_geo_backward.h"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -963,6 +964,101 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
     }
 }
 
+// ---- geometry / IOR adjoint of the particle tracer (mi355_geo_backward.h) -----------------------------------------------------------
+// Lanes [lane_first, lane_first + n_chunk) of the shard: forward walk onto the HBM path tape, backward sweep into the gradient buffer.
+// Dynamic LDS: 2 floats per bsdf for the IOR adjoints (n_ior_lds = 2 * n_bsdfs, or 0 -> global atomics).
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
+                                                               GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds) {
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    extern __shared__ float s_ior_dyn[];
+    for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) s_ior_dyn[k] = 0.f;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;                    // slot on the tape
+    const uint32_t i = lane_first + t;
+    const bool on = t < n_chunk && i < a.n_local;
+    const uint32_t ii = on ? i : 0u;
+    const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
+    Pcg32 rng; sampler_seed(rng, a.seed, lane);
+    const GeoBwdSink sink = { grad_rgb, d_grad, d_nrm_adj, n_ior_lds ? s_ior_dyn : nullptr };
+    for (uint32_t pass = 0; pass < a.passes; ++pass)
+        ptracer_sample_geo_bwd<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, stk, tape,
+                                     min(t, tape.stride - 1u), sink);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) {
+        const float v = s_ior_dyn[k];
+        if (v != 0.f) { const int32_t off = sc.bsdfs[k >> 1].ior_grad_offset; if (off >= 0) atomicAdd(d_grad + off + (k & 1u), v); }
+    }
+}
+// Mesh::recompute_vertex_normals for one mesh: one thread per vertex (gather over its incident faces).  With `vtan` the kernel writes the
+// TANGENT of the normals instead (forward design mode) and leaves the normals alone.
+__global__ __launch_bounds__(256) void k_vertex_normals(const float *positions, const uint32_t *faces, const uint32_t *adj_off, const uint32_t *adj, uint32_t vtx_offset,
+                                                        uint32_t tri_offset, uint32_t n_vertices, float *normals, float *nrm_len, const float *vtan, float *ntan) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= n_vertices) return;
+    v3 n, dn; float len;
+    vertex_normal_gather(positions, faces, adj_off, adj, vtx_offset, tri_offset, vtx_offset + v, n, len, vtan, vtan ? &dn : nullptr);
+    if (vtan) { ntan[3 * (size_t) v] = dn.x; ntan[3 * (size_t) v + 1] = dn.y; ntan[3 * (size_t) v + 2] = dn.z; return; }
+    float *o = normals + 3 * (size_t) (vtx_offset + v);
+    o[0] = n.x; o[1] = n.y; o[2] = n.z; nrm_len[vtx_offset + v] = len;
+}
+// Adjoint of the same computation, one thread per face: the adjoints of the (normalised) vertex normals of its corners go through the
+// normalisation (stored lengths) and through face_normal_terms into the position gradients of the mesh.
+__global__ __launch_bounds__(256) void k_vertex_normals_bwd(const float *positions, const float *normals, const float *nrm_len, const uint32_t *faces, uint32_t vtx_offset,
+                                                            uint32_t tri_offset, uint32_t n_faces, const float *nrm_adj, float *grad_pos) {
+    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+    if (f >= n_faces) return;
+    const uint32_t *fi = faces + 3 * (size_t) (tri_offset + f);
+    gv3 v[3], aN[3]; bool any = false;
+    for (int c = 0; c < 3; ++c) {
+        const size_t g = vtx_offset + fi[c];
+        v[c] = G3(ld3(positions + 3 * g));
+        const gv3 an = G3(ld3(nrm_adj + 3 * g)), nn = G3(ld3(normals + 3 * g)); const float len = nrm_len[g];
+        aN[c] = len != 0.f ? ga::normalize_adj(nn, len, an) : ga::mk<float>(0.f, 0.f, 0.f);
+        any = any || aN[c].x != 0.f || aN[c].y != 0.f || aN[c].z != 0.f;
+    }
+    if (!any) return;
+    gv3 av[3]; ga::face_normal_terms_adj(v[0], v[1], v[2], aN, av);
+    for (int c = 0; c < 3; ++c) {
+        if (!(av[c].x == av[c].x && av[c].y == av[c].y && av[c].z == av[c].z)) continue;   // degenerate face
+        float *g = grad_pos + 3 * (size_t) fi[c];
+        atomicAdd(g, av[c].x); atomicAdd(g + 1, av[c].y); atomicAdd(g + 2, av[c].z);
+    }
+}
+// Scene::parameters_changed for one mesh traversed through a BVH: triangles in traversal order from the new positions ...
+__global__ __launch_bounds__(256) void k_mesh_tris(const float *positions, const uint32_t *faces, const uint32_t *tri_face, uint32_t vtx_offset, uint32_t tri_offset,
+                                                   uint32_t n_faces, DTri *tris) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_faces) return;
+    const uint32_t *fi = faces + 3 * (size_t) (tri_offset + tri_face[tri_offset + k]);
+    const v3 a = ld3(positions + 3 * (size_t) (vtx_offset + fi[0])), b = ld3(positions + 3 * (size_t) (vtx_offset + fi[1])), c = ld3(positions + 3 * (size_t) (vtx_offset + fi[2]));
+    DTri t; t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.e1[0] = b.x - a.x; t.e1[1] = b.y - a.y; t.e1[2] = b.z - a.z; t.e2[0] = c.x - a.x; t.e2[1] = c.y - a.y; t.e2[2] = c.z - a.z;
+    tris[tri_offset + k] = t;
+}
+// ... and the node boxes refitted bottom-up, one launch per tree level (deepest first); topology and leaf contents are kept.
+__global__ __launch_bounds__(256) void k_bvh_refit_level(DBvhNode *nodes, const uint2 *level_nodes, uint32_t n, const DTri *tris) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t node = level_nodes[i].x, tri_offset = level_nodes[i].y;
+    DBvhNode nd = nodes[node];
+    float lo[3] = { MI_INF, MI_INF, MI_INF }, hi[3] = { -MI_INF, -MI_INF, -MI_INF };
+    if (nd.count) {
+        for (uint32_t k = 0; k < nd.count; ++k) {
+            const DTri t = tris[tri_offset + nd.left + k];
+            for (int c = 0; c < 3; ++c) {
+                const float a = t.p0[c], b = t.p0[c] + t.e1[c], d = t.p0[c] + t.e2[c];
+                lo[c] = fminf(lo[c], fminf(a, fminf(b, d))); hi[c] = fmaxf(hi[c], fmaxf(a, fmaxf(b, d)));
+            }
+        }
+    } else {
+        const DBvhNode l = nodes[nd.left], r = nodes[nd.left + 1];
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(l.lo[c], r.lo[c]); hi[c] = fmaxf(l.hi[c], r.hi[c]); }
+    }
+    for (int c = 0; c < 3; ++c) { nodes[node].lo[c] = lo[c]; nodes[node].hi[c] = hi[c]; }
+}
+
 // HDRFilm::develop, hdrfilm.cpp:304-409
 __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1077,6 +1173,15 @@ struct mi355_scene {
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
     std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil, area_cdf;
     std::vector<float> ext_iors;                                            // per bsdf (the design forward mode turns IOR tangents into a tangent of rel_eta)
+    // geometry updates (MI355_PARAM_VERTEX_POSITIONS): what Mesh::parameters_changed / Scene::parameters_changed need
+    std::vector<uint32_t> vcount;                                           // per shape: vertex count (meshes)
+    std::vector<uint32_t> vadj_off, vadj;                                   // CSR over ALL mesh vertices: incident (local face * 4 + corner), ascending faces
+    std::vector<uint2> bvh_levels; std::vector<uint32_t> bvh_level_off;     // BVH nodes (node, owning shape's tri_offset) grouped by depth, root level first
+    std::vector<char> dirty; bool geom_dirty = false;                       // per shape: positions changed since the last refit
+    uint32_t *d_vadj_off = nullptr, *d_vadj = nullptr; float *d_nrm_len = nullptr, *d_nrm_adj = nullptr; uint2 *d_bvh_levels = nullptr;
+    float *d_tape = nullptr; size_t tape_floats = 0;                        // path tape of the geometry adjoint
+    float *d_ntan = nullptr; size_t ntan_floats = 0;                        // forward design mode: tangent of the vertex normals
+    size_t cap_prims = 0, cap_fins = 0, cap_boxes = 0;                      // device capacities of the flat tables (they are rebuilt when a small mesh moves)
     std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
@@ -1328,6 +1433,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         o.alpha_u = b.alpha_u; o.alpha_v = b.alpha_v; o.distribution = b.distribution; o.sample_visible = b.sample_visible;
         memcpy(o.eta, b.eta, 12); memcpy(o.k, b.k, 12); memcpy(o.transmittance, b.transmittance, 12);
         o.rel_eta = b.type == MI355_BSDF_DIELECTRIC ? b.int_ior / b.ext_ior : 1.f;
+        o.ext_ior = b.type == MI355_BSDF_DIELECTRIC ? b.ext_ior : 1.f; o.ior_grad_offset = -1;
         s->ext_iors.push_back(b.type == MI355_BSDF_DIELECTRIC ? b.ext_ior : 1.f);
         if (b.type != MI355_BSDF_DIFFUSE) ds.features |= 1u;
         s->bsdfs.push_back(o);
@@ -1344,7 +1450,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         const mi355_shape_desc &sd = d->shapes[i];
         if (sd.bsdf >= d->n_bsdfs) return fail(MI355_ERR_INVALID, "shape references a missing bsdf");
         if (sd.emitter >= (int32_t) d->n_emitters) return fail(MI355_ERR_INVALID, "shape references a missing emitter");
-        DShape o; memset(&o, 0, sizeof(o)); o.type = sd.type; o.bsdf = sd.bsdf; o.emitter = sd.emitter; o.bvh_root = -1;
+        DShape o; memset(&o, 0, sizeof(o)); o.type = sd.type; o.bsdf = sd.bsdf; o.emitter = sd.emitter; o.bvh_root = -1; o.grad_offset = 0xffffffffu;
+        s->vcount.push_back(sd.type == MI355_SHAPE_MESH ? sd.vertex_count : 0u);
         // DirectionalArea::eval is zero and its pdf_direction is zero (directionalarea.cpp:126-136,165-168): a path that HITS such a shape
         // sees a plain surface, so the shape record carries no emitter; the emitter table (NEE pick, ptracer) still lists it
         if (sd.emitter >= 0 && d->emitters[sd.emitter].type == MI355_EMITTER_DIRECTIONALAREA) o.emitter = -1;
@@ -1448,8 +1555,53 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         for (int k = 0; k < 3; ++k) s->small_map.push_back((uint32_t) (off + k));
         off += 3;
     }
+    for (uint32_t i = 0; i < s->shapes.size(); ++i) if (s->shapes[i].type == MI355_SHAPE_MESH) {      // `vertex_positions`, mesh.cpp:1602-1611
+        mi355_param_info pi = { MI355_PARAM_VERTEX_POSITIONS, i, off, 3ull * s->vcount[i] }; s->layout.push_back(pi);
+        if (off <= 0xfffffff0ull) s->shapes[i].grad_offset = (uint32_t) off;
+        off += 3ull * s->vcount[i];
+    }
+    for (uint32_t i = 0; i < s->bsdfs.size(); ++i) if (s->bsdfs[i].type == MI355_BSDF_DIELECTRIC) {   // int_ior, ext_ior: dielectric.cpp:236-239
+        mi355_param_info pi = { MI355_PARAM_BSDF_IOR, i, off, 2 }; s->layout.push_back(pi);
+        if (off <= 0x7ffffff0ull) s->bsdfs[i].ior_grad_offset = (int32_t) off;
+        off += 2;
+    }
     s->grad_total = off;
-    if (off > 0xffffffffull) return fail(MI355_ERR_UNSUPPORTED, "more than 2^32 differentiable floats");
+    if (off > 0x7fffffffull) return fail(MI355_ERR_UNSUPPORTED, "more than 2^31 differentiable floats");
+    {   // vertex -> incident (face, corner) lists for recompute_vertex_normals (meshes that carry vertex normals)
+        const size_t nv_total = s->positions.size() / 3;
+        std::vector<uint32_t> deg(nv_total + 1, 0u);
+        for (uint32_t i = 0; i < s->shapes.size(); ++i) {
+            const DShape &sh = s->shapes[i];
+            if (sh.type != MI355_SHAPE_MESH || !(sh.flags & DSHAPE_HAS_NRM)) continue;
+            for (uint32_t f = 0; f < sh.tri_count; ++f) for (int c = 0; c < 3; ++c) deg[sh.vtx_offset + s->faces[3 * (size_t) (sh.tri_offset + f) + c] + 1]++;
+        }
+        for (size_t v = 0; v < nv_total; ++v) deg[v + 1] += deg[v];
+        s->vadj_off = deg; s->vadj.assign(deg[nv_total], 0u);
+        std::vector<uint32_t> cur(deg.begin(), deg.end() - 1);
+        for (uint32_t i = 0; i < s->shapes.size(); ++i) {
+            const DShape &sh = s->shapes[i];
+            if (sh.type != MI355_SHAPE_MESH || !(sh.flags & DSHAPE_HAS_NRM)) continue;
+            for (uint32_t f = 0; f < sh.tri_count; ++f) for (uint32_t c = 0; c < 3; ++c) s->vadj[cur[sh.vtx_offset + s->faces[3 * (size_t) (sh.tri_offset + f) + c]]++] = f * 4u + c;
+        }
+    }
+    {   // BVH nodes by depth (refit order) and the depth check of the traversal stack
+        std::vector<std::vector<uint2>> lv;
+        for (uint32_t si : s->bvh_shapes) {
+            const DShape &sh = s->shapes[si];
+            std::vector<std::pair<uint32_t, uint32_t>> todo; todo.push_back({ (uint32_t) sh.bvh_root, 0u });
+            while (!todo.empty()) {
+                auto [node, depth] = todo.back(); todo.pop_back();
+                if (lv.size() <= depth) lv.resize(depth + 1);
+                lv[depth].push_back(make_uint2(node, sh.tri_offset));
+                if (!s->bvh[node].count) { todo.push_back({ s->bvh[node].left, depth + 1 }); todo.push_back({ s->bvh[node].left + 1, depth + 1 }); }
+            }
+        }
+        // the traversal keeps one pending sibling per level below the root: MI_BVH_STACK of them
+        if (lv.size() > (size_t) MI_BVH_STACK + 1) return fail(MI355_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (MI_BVH_STACK): mesh too large for this build");
+        s->bvh_level_off.assign(1, 0u);
+        for (auto &l : lv) { s->bvh_levels.insert(s->bvh_levels.end(), l.begin(), l.end()); s->bvh_level_off.push_back((uint32_t) s->bvh_levels.size()); }
+    }
+    s->dirty.assign(s->shapes.size(), 0);
     if (s->small_map.size() > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant differentiable parameters for the LDS reducer");
     // sensor / film
     int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
@@ -1533,6 +1685,15 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         ds.pupil = s->d_pupil;
     }
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
+    if ((rc = upload(&s->d_vadj_off, s->vadj_off))) return rc;
+    if ((rc = upload(&s->d_vadj, s->vadj))) return rc;
+    if ((rc = upload(&s->d_bvh_levels, s->bvh_levels))) return rc;
+    {
+        const size_t nv_total = std::max<size_t>(s->positions.size() / 3, 1);
+        HIP_TRY(hipMalloc((void **) &s->d_nrm_len, nv_total * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_nrm_adj, nv_total * 3 * sizeof(float)));
+        HIP_TRY(hipMemset(s->d_nrm_len, 0, nv_total * sizeof(float)));
+    }
+    s->cap_prims = std::max<size_t>(s->prims.size(), 1); s->cap_fins = std::max<size_t>(s->fins.size(), 1); s->cap_boxes = std::max<size_t>(s->boxes.size(), 1);
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
     if ((rc = upload(&s->d_textures, s->textures))) return rc;
@@ -1567,10 +1728,130 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
                      s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf,
-                     s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_tile_u32 };
+                     s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_tile_u32,
+                     s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
+}
+
+// ---- geometry updates: Mesh::parameters_changed (mesh.cpp:96-163) + Scene::parameters_changed (scene.cpp:481-529) ------------------------
+static mi355_shape_desc host_mesh_desc(const mi355_scene *s, uint32_t i) {   // a mesh's buffers as the host mirror holds them
+    mi355_shape_desc sd; memset(&sd, 0, sizeof(sd));
+    const DShape &sh = s->shapes[i];
+    sd.type = MI355_SHAPE_MESH; sd.vertex_count = s->vcount[i]; sd.face_count = sh.tri_count;
+    sd.vertex_positions = s->positions.data() + 3 * (size_t) sh.vtx_offset; sd.faces = s->faces.data() + 3 * (size_t) sh.tri_offset;
+    return sd;
+}
+static void push_plane_prim(mi355_scene *s, uint32_t i) {                   // rectangle.cpp:457-465 / disk.cpp:392-416: local = to_object * ray
+    const DShape &o = s->shapes[i];
+    DPrim pr; memset(&pr, 0, sizeof(pr)); memcpy(pr.m, o.to_object, 48);
+    pr.lo = -1.f; pr.smax = 2.f; pr.shape = i; pr.fin = o.type == MI355_SHAPE_DISK ? MI_DISK_FIN : 0xffffffffu;
+    s->prims.push_back(pr);
+}
+template <typename T> static int reupload(T **dst, size_t *cap, const std::vector<T> &src) {
+    if (src.size() > *cap) { if (*dst) HIP_TRY(hipFree(*dst)); *dst = nullptr; *cap = 0; HIP_TRY(hipMalloc((void **) dst, src.size() * sizeof(T))); *cap = src.size(); }
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+// the flat primitive tables (rectangles, disks, meshes of <= MI_FLAT_MAX triangles, boxes) from the host mirror, in shape order
+static int rebuild_flat_tables(mi355_scene *s) {
+    s->prims.clear(); s->fins.clear(); s->boxes.clear();
+    for (uint32_t i = 0; i < s->shapes.size(); ++i) {
+        const DShape &sh = s->shapes[i];
+        if (sh.type == MI355_SHAPE_RECTANGLE || sh.type == MI355_SHAPE_DISK) push_plane_prim(s, i);
+        else if (sh.type == MI355_SHAPE_MESH && sh.bvh_root < 0) {
+            const mi355_shape_desc sd = host_mesh_desc(s, i);
+            const size_t fins_before = s->fins.size();
+            if (!try_make_box(s, i, sd)) { s->fins.resize(fins_before); flatten_mesh(s, i, sd); }
+        }
+    }
+    int rc;
+    if ((rc = reupload(&s->d_prims, &s->cap_prims, s->prims))) return rc;
+    if ((rc = reupload(&s->d_fins, &s->cap_fins, s->fins))) return rc;
+    if ((rc = reupload(&s->d_boxes, &s->cap_boxes, s->boxes))) return rc;
+    s->ds.prims = s->d_prims; s->ds.fins = s->d_fins; s->ds.boxes = s->d_boxes;
+    s->ds.n_prims = (uint32_t) s->prims.size(); s->ds.n_boxes = (uint32_t) s->boxes.size();
+    return MI355_OK;
+}
+// Runs (once) before any call that traces rays: vertex normals, triangles, BVH boxes, flat tables, emitter tables of every mesh whose
+// positions changed.  Work is issued on `st`, the stream of the call that needs it.
+static int ensure_geometry(mi355_scene *s, hipStream_t st) {
+    if (!s->geom_dirty) return MI355_OK;
+    bool refit = false, reflatten = false, shapes_changed = false, cdf_changed = false;
+    for (uint32_t i = 0; i < s->shapes.size(); ++i) {
+        if (!s->dirty[i]) continue;
+        DShape &sh = s->shapes[i];
+        const uint32_t nv = s->vcount[i];
+        if (sh.flags & DSHAPE_HAS_NRM) {                                    // recompute_vertex_normals, mesh.cpp:138-139
+            hipLaunchKernelGGL(k_vertex_normals, dim3((nv + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const uint32_t *) s->d_faces, (const uint32_t *) s->d_vadj_off,
+                               (const uint32_t *) s->d_vadj, sh.vtx_offset, sh.tri_offset, nv, s->d_normals, s->d_nrm_len, (const float *) nullptr, (float *) nullptr);
+            HIP_TRY(hipGetLastError());
+            if (!(sh.flags & DSHAPE_NRM_DEP)) { sh.flags |= DSHAPE_NRM_DEP; shapes_changed = true; }
+            HIP_TRY(hipMemcpyAsync(s->normals.data() + 3 * (size_t) sh.vtx_offset, s->d_normals + 3 * (size_t) sh.vtx_offset, 3 * (size_t) nv * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
+        if (sh.bvh_root >= 0) {
+            hipLaunchKernelGGL(k_mesh_tris, dim3((sh.tri_count + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const uint32_t *) s->d_faces, (const uint32_t *) s->d_tri_face,
+                               sh.vtx_offset, sh.tri_offset, sh.tri_count, s->d_tris);
+            HIP_TRY(hipGetLastError());
+            refit = true;
+        } else reflatten = true;
+        {   // recompute_bbox (mesh.cpp:415-428); build_pmf when the mesh is sampled (mesh.cpp:141-142, :430-470): float prefix sums of the face areas
+            const float *P = s->positions.data() + 3 * (size_t) sh.vtx_offset;
+            for (int k = 0; k < 3; ++k) { sh.bbox_min[k] = INFINITY; sh.bbox_max[k] = -INFINITY; }
+            for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { sh.bbox_min[k] = std::min(sh.bbox_min[k], P[3 * v + k]); sh.bbox_max[k] = std::max(sh.bbox_max[k], P[3 * v + k]); }
+            float area = 0.f;
+            for (uint32_t f = 0; f < sh.tri_count; ++f) {
+                const uint32_t *fi = s->faces.data() + 3 * (size_t) (sh.tri_offset + f);
+                const float *a = P + 3 * (size_t) fi[0], *b = P + 3 * (size_t) fi[1], *c = P + 3 * (size_t) fi[2];
+                h3 cr = hcross(hsub(H3(b[0], b[1], b[2]), H3(a[0], a[1], a[2])), hsub(H3(c[0], c[1], c[2]), H3(a[0], a[1], a[2])));
+                area += 0.5f * sqrtf(hdot(cr, cr));
+                s->area_cdf[sh.cdf_offset + f] = area;
+            }
+            sh.inv_area = 1.f / area; shapes_changed = true; cdf_changed = cdf_changed || sh.emitter >= 0;
+            for (const DEmitter &e : s->emitters) if (e.shape == i) cdf_changed = true;
+        }
+        s->dirty[i] = 0;
+    }
+    if (refit)                                                              // bottom-up, one launch per level
+        for (size_t l = s->bvh_level_off.size() - 1; l-- > 0;) {
+            const uint32_t b = s->bvh_level_off[l], n = s->bvh_level_off[l + 1] - b;
+            if (n) hipLaunchKernelGGL(k_bvh_refit_level, dim3((n + 255u) / 256u), dim3(256), 0, st, s->d_bvh, (const uint2 *) (s->d_bvh_levels + b), n, (const DTri *) s->d_tris);
+        }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));                                      // the host copies below must not overtake kernels that still read the old tables
+    int rc;
+    if (reflatten && (rc = rebuild_flat_tables(s))) return rc;
+    if (shapes_changed) HIP_TRY(hipMemcpy(s->d_shapes, s->shapes.data(), s->shapes.size() * sizeof(DShape), hipMemcpyHostToDevice));
+    if (cdf_changed && !s->area_cdf.empty()) HIP_TRY(hipMemcpy(s->d_area_cdf, s->area_cdf.data(), s->area_cdf.size() * sizeof(float), hipMemcpyHostToDevice));
+    s->geom_dirty = false;
+    return MI355_OK;
+}
+static int set_geometry_param(mi355_scene *s, uint32_t kind, uint32_t index, const float *values, uint64_t count, bool device_src, hipStream_t st) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (kind == MI355_PARAM_VERTEX_POSITIONS) {
+        if (index >= s->shapes.size() || s->shapes[index].type != MI355_SHAPE_MESH) return fail(MI355_ERR_INVALID, "vertex_positions: not a mesh");
+        if (count != 3ull * s->vcount[index]) return fail(MI355_ERR_INVALID, "vertex_positions update must keep the vertex count (topology changes need a new scene)");
+        const DShape &sh = s->shapes[index];
+        float *h = s->positions.data() + 3 * (size_t) sh.vtx_offset, *d = s->d_positions + 3 * (size_t) sh.vtx_offset;
+        if (device_src) {
+            HIP_TRY(hipMemcpyAsync(d, values, count * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h, values, count * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        } else { memcpy(h, values, count * 4); HIP_TRY(hipMemcpy(d, values, count * 4, hipMemcpyHostToDevice)); }
+        for (uint64_t k = 0; k < count; ++k) if (!std::isfinite(h[k])) return fail(MI355_ERR_INVALID, "vertex_positions contains a non-finite value");
+        s->dirty[index] = 1; s->geom_dirty = true;
+        return MI355_OK;
+    }
+    // MI355_PARAM_BSDF_IOR
+    if (index >= s->bsdfs.size() || s->bsdfs[index].type != MI355_BSDF_DIELECTRIC || count != 2) return fail(MI355_ERR_INVALID, "bad IOR update (2 floats of a dielectric)");
+    float v[2];
+    if (device_src) { HIP_TRY(hipMemcpyAsync(v, values, 8, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); } else memcpy(v, values, 8);
+    if (!(v[0] > 0.f && v[1] > 0.f)) return fail(MI355_ERR_INVALID, "indices of refraction must be positive");
+    DBsdf &b = s->bsdfs[index];
+    b.rel_eta = v[0] / v[1]; b.ext_ior = v[1]; s->ext_iors[index] = v[1];  // dielectric.cpp:222
+    HIP_TRY(hipMemcpy(s->d_bsdfs + index, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
+    return MI355_OK;
 }
 
 static int param_target(mi355_scene *s, uint32_t kind, uint32_t index, uint64_t count, float **host, float **dev) {
@@ -1592,6 +1873,7 @@ static int param_target(mi355_scene *s, uint32_t kind, uint32_t index, uint64_t 
 }
 extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t index, const float *values, uint64_t count) {
     if (!s || !values) return fail(MI355_ERR_INVALID, "null argument");
+    if (kind == MI355_PARAM_VERTEX_POSITIONS || kind == MI355_PARAM_BSDF_IOR) return set_geometry_param(s, kind, index, values, count, false, nullptr);
     float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     memcpy(h, values, count * 4);
@@ -1600,6 +1882,7 @@ extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t ind
 }
 extern "C" int mi355_scene_set_param_device(mi355_scene *s, uint32_t kind, uint32_t index, const float *d_values, uint64_t count, void *stream) {
     if (!s || !d_values) return fail(MI355_ERR_INVALID, "null argument");
+    if (kind == MI355_PARAM_VERTEX_POSITIONS || kind == MI355_PARAM_BSDF_IOR) return set_geometry_param(s, kind, index, d_values, count, true, (hipStream_t) stream);
     float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpyAsync(d, d_values, count * 4, hipMemcpyDeviceToDevice, (hipStream_t) stream));
@@ -1682,6 +1965,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    if ((rc = ensure_geometry(s, st))) return rc;
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
@@ -1796,6 +2080,7 @@ extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
+    if ((rc = ensure_geometry(s, st))) return rc;
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
@@ -1825,9 +2110,24 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0 || s->emitters.empty()) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
+    if ((rc = ensure_geometry(s, st))) return rc;
     const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
     const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
-    GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel };
+    const float *ntan = nullptr;
+    if (t->shape != MI355_NONE && (s->shapes[t->shape].flags & DSHAPE_NRM_DEP)) {
+        // the mesh's vertex normals are functions of its positions (they were recomputed by a parameter update): their tangent goes with it
+        const DShape &sh = s->shapes[t->shape]; const uint32_t nv = s->vcount[t->shape];
+        if (s->ntan_floats < 3 * (size_t) nv) {
+            if (s->d_ntan) HIP_TRY(hipFree(s->d_ntan));
+            s->d_ntan = nullptr; s->ntan_floats = 0;
+            HIP_TRY(hipMalloc((void **) &s->d_ntan, 3 * (size_t) nv * sizeof(float))); s->ntan_floats = 3 * (size_t) nv;
+        }
+        hipLaunchKernelGGL(k_vertex_normals, dim3((nv + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const uint32_t *) s->d_faces, (const uint32_t *) s->d_vadj_off,
+                           (const uint32_t *) s->d_vadj, sh.vtx_offset, sh.tri_offset, nv, (float *) nullptr, (float *) nullptr, t->d_vertex_tangent, s->d_ntan);
+        HIP_TRY(hipGetLastError());
+        ntan = s->d_ntan;
+    }
+    GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel, ntan };
     if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
     else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
     HIP_TRY(hipGetLastError());
@@ -1841,6 +2141,7 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
+    if ((rc = ensure_geometry(s, st))) return rc;
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     if (pt) {                                                               // Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp, radiances only
@@ -1855,6 +2156,37 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
         else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
         HIP_TRY(hipGetLastError());
+        if (p->flags & MI355_FLAG_GEOMETRY_GRADS) {                         // vertex positions and IORs: forward walk onto the path tape, backward sweep
+            if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "geometry gradients are built for the perspective sensor");
+            if (p->max_depth < 0 || p->max_depth > MI_TAPE_MAX_VERTS + 1) return fail(MI355_ERR_UNSUPPORTED, "geometry gradients need a finite max_depth <= 33 (the path tape holds max_depth - 1 vertices)");
+            const uint32_t n_verts = p->max_depth > 1 ? (uint32_t) p->max_depth - 1u : 0u;
+            if (n_verts) {
+                const uint32_t chunk = std::min<uint32_t>(a.n_local, 1u << 22);    // lanes per launch: bounds the tape at 18 dwords x vertices x 4 Mi lanes
+                const size_t need = (size_t) MI_TAPE_FIELDS * n_verts * chunk;
+                if (s->tape_floats < need) {
+                    if (s->d_tape) HIP_TRY(hipFree(s->d_tape));
+                    s->d_tape = nullptr; s->tape_floats = 0;
+                    HIP_TRY(hipMalloc((void **) &s->d_tape, need * sizeof(float))); s->tape_floats = need;
+                }
+                const size_t nv_total = s->positions.size() / 3;
+                HIP_TRY(hipMemsetAsync(s->d_nrm_adj, 0, std::max<size_t>(nv_total, 1) * 3 * sizeof(float), st));
+                const uint32_t n_ior = s->bsdfs.size() <= 2048 ? 2u * (uint32_t) s->bsdfs.size() : 0u;
+                GeoTape tape = { s->d_tape, chunk };
+                for (uint32_t first = 0; first < a.n_local; first += chunk) {
+                    const uint32_t n = std::min<uint32_t>(chunk, a.n_local - first); const dim3 g((n + BLOCK - 1) / BLOCK);
+                    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo_bwd<true>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior);
+                    else hipLaunchKernelGGL(k_ptracer_geo_bwd<false>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior);
+                }
+                HIP_TRY(hipGetLastError());
+                for (uint32_t i = 0; i < s->shapes.size(); ++i) {           // vertex-normal adjoints -> positions, for normals that follow the positions
+                    const DShape &sh = s->shapes[i];
+                    if (sh.type != MI355_SHAPE_MESH || !(sh.flags & DSHAPE_NRM_DEP) || sh.grad_offset == 0xffffffffu) continue;
+                    hipLaunchKernelGGL(k_vertex_normals_bwd, dim3((sh.tri_count + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const float *) s->d_normals, (const float *) s->d_nrm_len,
+                                       (const uint32_t *) s->d_faces, sh.vtx_offset, sh.tri_offset, sh.tri_count, (const float *) s->d_nrm_adj, d_grad_params + sh.grad_offset);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+        }
         return tm.end();
     }
     uint32_t npix = s->ds.crop_w * s->ds.crop_h;
@@ -1936,6 +2268,7 @@ extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_para
     if (!count) return MI355_OK;
     a.n_local = count; a.lane_begin = lane_begin; a.seg = 0;
     dim3 grid((count + BLOCK - 1) / BLOCK), block(BLOCK); hipStream_t st = (hipStream_t) stream;
+    if ((rc = ensure_geometry(s, st))) return rc;
     float *nof = nullptr; unsigned long long *noc = nullptr; const bool full = (s->ds.features != 0u) != 0;
     if (p->integrator == MI355_INTEGRATOR_PRB) {
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_LANES, true>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
@@ -1955,6 +2288,7 @@ extern "C" int mi355_debug_ray_intersect(mi355_scene *s, const float *d_rays, ui
     if (!s || !d_rays || !d_hits) return fail(MI355_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     if (!n) return MI355_OK;
+    { int rc = ensure_geometry(s, (hipStream_t) stream); if (rc) return rc; }
     hipLaunchKernelGGL(k_debug_intersect, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, d_rays, n, d_hits);
     HIP_TRY(hipGetLastError());
     return MI355_OK;

@@ -67,7 +67,7 @@ MI_DEV Df dfilter_eval(const DScene &sc, Df x) {
 }
 
 // d(vertex position)/d(theta) of every vertex of `shape` (3 floats each); d(int_ior / ext_ior)/d(theta) of the dielectric `bsdf`
-struct GeoTangent { uint32_t shape; const float *vtan; uint32_t bsdf; float d_rel_eta; };
+struct GeoTangent { uint32_t shape; const float *vtan; uint32_t bsdf; float d_rel_eta; const float *ntan; };   // ntan: d(vertex normal)/d(theta) when the normals follow the positions (DSHAPE_NRM_DEP), else nullptr
 
 // Dual hit record at a primal hit (hit, si): point, geometric normal, shading normal, tangent frame, all as functions of the dual ray.
 struct DualHit { D3 p, ng, ns, sh_s, sh_t; };
@@ -102,7 +102,10 @@ MI_DEV DualHit dual_hit(const DScene &sc, const GeoTangent &gt, const Hit &hit, 
         }
         if (!have_dpdu) { D3 tt; dcoordinate_system(h.ng, dp_du, tt); have_dpdu = true; }
         if (sh.flags & DSHAPE_HAS_NRM) {
-            D3 n0 = D3c(ld3(sc.normals + 3 * (size_t) i0)), n1 = D3c(ld3(sc.normals + 3 * (size_t) i1)), n2 = D3c(ld3(sc.normals + 3 * (size_t) i2));
+            const bool nmov = moving && gt.ntan != nullptr;
+            D3 n0 = D3vd(ld3(sc.normals + 3 * (size_t) i0), nmov ? ld3(gt.ntan + 3 * (size_t) l0) : V3(0.f, 0.f, 0.f));
+            D3 n1 = D3vd(ld3(sc.normals + 3 * (size_t) i1), nmov ? ld3(gt.ntan + 3 * (size_t) l1) : V3(0.f, 0.f, 0.f));
+            D3 n2 = D3vd(ld3(sc.normals + 3 * (size_t) i2), nmov ? ld3(gt.ntan + 3 * (size_t) l2) : V3(0.f, 0.f, 0.f));
             h.ns = dnormalize(n0 * b0 + n1 * b1 + n2 * b2);
         } else h.ns = h.ng;
         if (sh.flags & DSHAPE_FLIP) { h.ng = -h.ng; h.ns = -h.ns; }

@@ -367,13 +367,16 @@ class ParticleTracerIntegrator(Integrator):
         """render_forward_design with a vertex tangent only."""
         return self.render_forward_design(scene, shape=shape, vertex_tangent=vertex_tangent, sensor=sensor, seed=seed, spp=spp)
 
-    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None):
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None, geometry=None):
         """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp: gradients of every differentiable parameter of this build
         (emitter radiances, diffuse reflectances, reflectance textures) by path replay of the light paths; the reference's own test
         value for the radiance (test_ptracer.py:204-225) is reproduced.  When `params` holds radiance keys only (params.keep), the
-        cheaper single-walk kernel runs.  Gradients with respect to geometry / IORs are not built."""
+        cheaper single-walk kernel runs.  `geometry`: also fill the `vertex_positions` and IOR slots (the reverse-mode geometry adjoint,
+        MI355_FLAG_GEOMETRY_GRADS); None = when one of those parameters asks for a gradient (a tensor with requires_grad)."""
         torch = _torch()
-        radiance_only = params is not None and all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
+        if geometry is None:
+            geometry = params is not None and params.wants_geometry()
+        radiance_only = (not geometry) and params is not None and all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
         be = self.backend
         dev = be.device(scene)
         f = scene.sensor.film
@@ -385,6 +388,8 @@ class ParticleTracerIntegrator(Integrator):
         p = self._params(scene, seed, spp, shard=band)
         if radiance_only:
             p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
+        if geometry:
+            p.flags |= abi.FLAG_GEOMETRY_GRADS
         grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(be.param_total(scene), 1), dtype=torch.float32, device=dev)
         multi = shard is not None and shard[1] > 1
         local = torch.zeros_like(grads) if multi else grads
@@ -432,6 +437,7 @@ class SceneParameters:
         torch = _torch()
         self.scene = scene
         self._entries = {}     # key -> (kind, index, shape)
+        self._comp = {}        # key -> component of a shared engine parameter: 0 / 1 = int_ior / ext_ior of MI355_PARAM_BSDF_IOR, None = no engine slot (V_d)
         self._values = {}
         self._dirty = set()
         self._grads = None
@@ -448,10 +454,30 @@ class SceneParameters:
             self._add("%s.reflectance.data" % t.id, abi.PARAM_TEXTURE_DATA, i, torch.tensor(t.data, device=dev))
         for i, e in enumerate(scene.emitters):
             self._add("%s.emitter.radiance.value" % e.shape.id, abi.PARAM_EMITTER_RADIANCE, i, torch.tensor(e.radiance, device=dev))
+        for i, sh in enumerate(scene.shapes):          # Mesh::traverse, mesh.cpp:1602-1611: `vertex_positions` as a flat array
+            if sh.type == abi.SHAPE_MESH and (abi.PARAM_VERTEX_POSITIONS, i) in self._layout:
+                self._add("%s.vertex_positions" % sh.id, abi.PARAM_VERTEX_POSITIONS, i, torch.tensor(sh.vertex_positions.reshape(-1), device=dev))
+        for i, b in enumerate(scene.bsdfs):
+            if b.type != abi.BSDF_DIELECTRIC or (abi.PARAM_BSDF_IOR, i) not in self._layout:
+                continue
+            if b.dispersive is not None:               # dispersive_dielectric.cpp:236-239
+                for comp, name in ((0, "int_ior_d"), (1, "ext_ior_d"), (None, "int_V_d"), (None, "ext_V_d")):
+                    self._add("%s.%s" % (b.id, name), abi.PARAM_BSDF_IOR, i, torch.tensor([b.dispersive[name]], dtype=torch.float32, device=dev), comp=comp)
+            else:                                      # dielectric.cpp:236-239 exposes eta (non-differentiable); the two indices are this build's parameters
+                self._add("%s.int_ior" % b.id, abi.PARAM_BSDF_IOR, i, torch.tensor([b.int_ior], dtype=torch.float32, device=dev), comp=0)
+                self._add("%s.ext_ior" % b.id, abi.PARAM_BSDF_IOR, i, torch.tensor([b.ext_ior], dtype=torch.float32, device=dev), comp=1)
 
-    def _add(self, key, kind, index, value):
+    def _add(self, key, kind, index, value, comp=-1):
         self._entries[key] = (kind, index, tuple(value.shape))
         self._values[key] = value
+        if comp != -1:
+            self._comp[key] = comp
+
+    def wants_geometry(self):
+        """True when a geometry / IOR parameter of this set carries a gradient request (a tensor with requires_grad), i.e. when the
+        particle tracer's render_backward must run its geometry adjoint too."""
+        return any(self._entries[k][0] in (abi.PARAM_VERTEX_POSITIONS, abi.PARAM_BSDF_IOR) and getattr(self._values[k], "requires_grad", False)
+                   for k in self._entries)
 
     def keep(self, keys):
         """SceneParameters.keep (util.py:234-258): keep the parameters whose key matches one of `keys` (regular expressions, matched
@@ -463,7 +489,7 @@ class SceneParameters:
         wanted = [k for k in self._entries if any(r(k) for r in regexps)]
         for k in list(self._entries):
             if k not in wanted:
-                del self._entries[k]; del self._values[k]; self._dirty.discard(k)
+                del self._entries[k]; del self._values[k]; self._dirty.discard(k); self._comp.pop(k, None)
 
     def keys(self): return self._entries.keys()
     def __contains__(self, k): return k in self._entries
@@ -500,10 +526,25 @@ class SceneParameters:
         """Upload one parameter to the device replica and keep the host description coherent."""
         kind, index, _ = self._entries[key]
         v = tensor.detach().to(torch_float32()).contiguous()
+        if kind == abi.PARAM_BSDF_IOR:                 # two keys (or four, `dispersive`) share the engine's (int_ior, ext_ior) pair
+            b = self.scene.bsdfs[index]; name = key.rsplit(".", 1)[1]; val = float(v.reshape(-1)[0].item())
+            if b.dispersive is not None:
+                b.dispersive[name] = val
+                b.int_ior = float(b.eval_ior(b.dispersive["int_ior_d"], b.dispersive["int_V_d"])); b.ext_ior = float(b.eval_ior(b.dispersive["ext_ior_d"], b.dispersive["ext_V_d"]))
+            elif name == "int_ior":
+                b.int_ior = val
+            else:
+                b.ext_ior = val
+            pair = np.array([b.int_ior, b.ext_ior], dtype=np.float32)
+            abi.check(abi.lib().mi355_scene_set_param(self.scene.handle(), kind, index, pair.ctypes.data_as(abi.f32p), 2))
+            return
         abi.check(abi.lib().mi355_scene_set_param_device(self.scene.handle(), kind, index, C.c_void_p(v.data_ptr()), v.numel(),
                                                           _stream_ptr(v.device)))
         host = v.cpu().numpy()
-        if kind == abi.PARAM_BSDF_REFLECTANCE:
+        if kind == abi.PARAM_VERTEX_POSITIONS:         # Mesh::parameters_changed: the engine refits and recomputes the normals; the host copy follows lazily
+            sh = self.scene.shapes[index]
+            sh.vertex_positions = np.ascontiguousarray(host.reshape(-1, 3).copy()); sh._normals_stale = sh.vertex_normals is not None
+        elif kind == abi.PARAM_BSDF_REFLECTANCE:
             self.scene.bsdfs[index].reflectance = host.copy()
         elif kind == abi.PARAM_EMITTER_RADIANCE:
             self.scene.emitters[index].radiance = host.copy()
@@ -517,11 +558,19 @@ class SceneParameters:
             self._grads = torch.zeros(max(self._total, 1), dtype=torch.float32, device=device)
         return self._grads
 
+    def _slot(self, key):
+        """(offset, size) of a key inside the concatenated gradient buffer (None for a key without an engine slot)."""
+        kind, index, _ = self._entries[key]
+        off, size = self._layout[(kind, index)]
+        if key in self._comp:
+            return None if self._comp[key] is None else (off + self._comp[key], 1)
+        return off, size
+
     def set_tangent(self, key, value):
         """dr.set_grad(params[key], value) for render_forward: the direction in parameter space along which the image is differentiated."""
         torch = _torch()
         kind, index, shape = self._entries[key]
-        off, size = self._layout[(kind, index)]
+        off, size = self._slot(key)
         if self._tangents is None:
             self._tangents = torch.zeros(max(self._total, 1), dtype=torch.float32, device=self._values[key].device)
         v = torch.as_tensor(value, dtype=torch.float32, device=self._tangents.device)
@@ -542,10 +591,11 @@ class SceneParameters:
 
     def grad(self, key):
         kind, index, shape = self._entries[key]
-        off, size = self._layout[(kind, index)]
         torch = _torch()
-        if self._grads is None:
+        slot = self._slot(key)
+        if self._grads is None or slot is None:        # (an Abbe number has no effect at the nominal 589.3 nm of an RGB build: gradient zero)
             return torch.zeros(shape, device=self._values[key].device)
+        off, size = slot
         return self._grads[off:off + size].reshape(shape)
 
 

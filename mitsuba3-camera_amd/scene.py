@@ -117,6 +117,7 @@ class BSDF:
         self.eta = np.zeros(3, dtype=np.float32); self.k = np.ones(3, dtype=np.float32)
         self.int_ior, self.ext_ior = 1.5046, 1.000277
         self.transmittance = np.ones(3, dtype=np.float32)
+        self.dispersive = None      # `dispersive` plugin: its four parameters (int_ior_d, int_V_d, ext_ior_d, ext_V_d)
 
     def flags_smooth(self):
         return self.type not in (abi.BSDF_DIELECTRIC, abi.BSDF_CONDUCTOR)
@@ -138,6 +139,7 @@ class Shape:
         self.emitter = emitter
         self.flip_normals = flip_normals
         self.vertex_positions = self.vertex_normals = self.vertex_texcoords = self.faces = None
+        self._normals_stale = False      # vertex_positions were updated: the engine recomputed the normals on the device; desc() catches up lazily
 
     def primitive_count(self):
         return 1 if self.type != abi.SHAPE_MESH else int(self.faces.shape[0])
@@ -164,6 +166,30 @@ class Shape:
         else:
             c = self.vertex_positions
         return c.min(axis=0), c.max(axis=0)
+
+
+def compute_vertex_normals(pos, faces):
+    """Mesh::recompute_vertex_normals (mesh.cpp:321-413, the JIT branch :376-413): face normal n = normalize(cross(v1 - v0, v2 - v0)), weighted by
+    the corner angle safe_acos(dot(normalize(v[i+1] - v[i]), normalize(v[i+2] - v[i]))), summed per vertex, normalised; float32.  obj.cpp:401-403
+    and ply.cpp:444-446 call it when the file holds no normals (and face_normals is false); Mesh::parameters_changed (mesh.cpp:138-139) whenever
+    the positions of a mesh with vertex normals change."""
+    f32 = np.float32
+    pos = np.asarray(pos, dtype=f32); faces = np.asarray(faces, dtype=np.int64)
+    v = [pos[faces[:, k]] for k in range(3)]
+
+    def nrm(a):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (a * (f32(1) / np.sqrt((a * a).sum(axis=1, dtype=f32, keepdims=True)))).astype(f32)
+    n = nrm(np.cross(v[1] - v[0], v[2] - v[0]).astype(f32))
+    out = np.zeros_like(pos)
+    ok = np.isfinite(n).all(axis=1)
+    for i in range(3):
+        d0 = nrm(v[(i + 1) % 3] - v[i]); d1 = nrm(v[(i + 2) % 3] - v[i])
+        ang = np.arccos(np.clip((d0 * d1).sum(axis=1, dtype=f32), f32(-1), f32(1))).astype(f32)
+        np.add.at(out, faces[ok, i], (n[ok] * ang[ok, None]).astype(f32))
+    ln = np.sqrt((out * out).sum(axis=1, dtype=f32))
+    res = np.where(ln[:, None] != 0, out / np.where(ln == 0, f32(1), ln)[:, None], np.array([1, 0, 0], dtype=f32)[None, :])
+    return np.ascontiguousarray(res.astype(f32))
 
 
 _CUBE_V = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1],
@@ -430,6 +456,8 @@ class Scene:
                 sh[i].vertex_positions = s.vertex_positions.ctypes.data_as(abi.f32p)
                 sh[i].faces = s.faces.ctypes.data_as(abi.u32p)
                 if s.vertex_normals is not None:
+                    if s._normals_stale:      # Mesh::parameters_changed -> recompute_vertex_normals (mesh.cpp:138-139)
+                        s.vertex_normals = compute_vertex_normals(s.vertex_positions, s.faces); s._normals_stale = False
                     sh[i].vertex_normals = s.vertex_normals.ctypes.data_as(abi.f32p)
                 if s.vertex_texcoords is not None:
                     sh[i].vertex_texcoords = s.vertex_texcoords.ctypes.data_as(abi.f32p)
@@ -554,9 +582,11 @@ def _make_bsdf(scene, props, id):
             return np.float32(a_ + b_ * inv(wl * wl))
         b = BSDF(id, _rgb(props.get("specular_reflectance", 1.0), "dispersive.specular_reflectance", True), type=abi.BSDF_DIELECTRIC)
         b.transmittance = _rgb(props.get("specular_transmittance", 1.0), "dispersive.specular_transmittance", True)
-        # eta = eval_ior(int) * rcp(eval_ior(ext))  (:250): handed over as int_ior / 1
-        b.int_ior = float(eval_ior(props.get("int_ior", 1.5046), props.get("int_V_d", 64.17)) * (np.float32(1) / eval_ior(props.get("ext_ior", 1.0), props.get("ext_V_d", 0.0))))
-        b.ext_ior = 1.0
+        # eta = eval_ior(int) * rcp(eval_ior(ext))  (:250): the two indices at 589.3 nm are handed over separately (they are parameters, :236-239)
+        b.dispersive = {"int_ior_d": float(props.get("int_ior", 1.5046)), "int_V_d": float(props.get("int_V_d", 64.17)),
+                        "ext_ior_d": float(props.get("ext_ior", 1.0)), "ext_V_d": float(props.get("ext_V_d", 0.0))}
+        b.eval_ior = eval_ior
+        b.int_ior = float(eval_ior(b.dispersive["int_ior_d"], b.dispersive["int_V_d"])); b.ext_ior = float(eval_ior(b.dispersive["ext_ior_d"], b.dispersive["ext_V_d"]))
         scene.bsdfs.append(b)
         return b
     if t == "dielectric":
@@ -667,11 +697,13 @@ def load_dict(d):
             pos, nrm, uv, faces = (_load_obj if vt == "obj" else _load_ply)(v["filename"])
             m, it = tw.matrix, tw.inverse_transpose
             shape.vertex_positions = np.ascontiguousarray((pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+            shape.faces = np.ascontiguousarray(faces)
             if nrm is not None and not v.get("face_normals", False):
                 n = (nrm @ it[:3, :3].T).astype(np.float32)
                 shape.vertex_normals = np.ascontiguousarray((n / np.sqrt((n * n).sum(axis=1, keepdims=True))).astype(np.float32))
+            elif not v.get("face_normals", False):          # obj.cpp:401-403 / ply.cpp:444-446: no normals in the file -> computed
+                shape.vertex_normals = compute_vertex_normals(shape.vertex_positions, shape.faces)
             shape.vertex_texcoords = None if uv is None else np.ascontiguousarray(uv)
-            shape.faces = np.ascontiguousarray(faces)
         elif vt == "mesh":     # extension: buffers as mi.Mesh exposes them through traverse() (mesh.h:523-527)
             m, it = tw.matrix, tw.inverse_transpose
             pos = np.asarray(v["vertex_positions"], dtype=np.float32).reshape(-1, 3)
@@ -679,6 +711,9 @@ def load_dict(d):
             if v.get("vertex_normals") is not None:
                 n = (np.asarray(v["vertex_normals"], dtype=np.float32).reshape(-1, 3) @ it[:3, :3].T).astype(np.float32)
                 shape.vertex_normals = np.ascontiguousarray((n / np.sqrt((n * n).sum(axis=1, keepdims=True))).astype(np.float32))
+            elif v.get("compute_vertex_normals", False):      # what the ply / obj loaders do for a file without normals
+                faces_ = np.asarray(v["faces"], dtype=np.uint32).reshape(-1, 3)
+                shape.vertex_normals = compute_vertex_normals(shape.vertex_positions, faces_)
             if v.get("vertex_texcoords") is not None:
                 shape.vertex_texcoords = np.ascontiguousarray(np.asarray(v["vertex_texcoords"], dtype=np.float32).reshape(-1, 2))
             shape.faces = np.ascontiguousarray(np.asarray(v["faces"], dtype=np.uint32).reshape(-1, 3))

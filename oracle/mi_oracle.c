@@ -282,7 +282,11 @@ typedef struct {
     uint32_t vertex_count, face_count;
     float *pos, *nrm, *uv; uint32_t *faces;
     float *area_cdf;                                      /* Mesh::build_pmf (mesh.cpp:430-470): inclusive float prefix sums of the face areas */
+    float *nrm_len; int nrm_dep;                          /* vertex normals recomputed from the positions by a parameter update (mesh.cpp:138-139): lengths of the sums */
+    struct ONode *bvh; uint32_t *bvh_faces; uint32_t n_nodes;   /* meshes of more than ORC_BVH_MIN faces: a median-split BVH (speed only: same closest hit) */
 } OShape;
+typedef struct ONode { float lo[3], hi[3]; uint32_t left, count; } ONode;
+#define ORC_BVH_MIN 64
 typedef struct { uint32_t w, h, c, filter, wrap; float to_uv[6]; float *data; } OTexture;
 typedef struct {
     uint32_t n_shapes, n_bsdfs, n_emitters, n_textures;
@@ -299,6 +303,8 @@ typedef struct {
 static void *dupmem(const void *p, size_t n) { if (!p || !n) return NULL; void *q = malloc(n); memcpy(q, p, n); return q; }
 
 static void exit_pupil_bounds(OScene *sc, float film_diagonal);
+static void orc_bvh_build(OShape *sh);
+static void recompute_vertex_normals(OShape *sh);
 ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
     if (!d || d->abi_version != MI355_ABI_VERSION) return NULL;
     OScene *s = (OScene *) calloc(1, sizeof(OScene));
@@ -349,6 +355,7 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
                 o->area_cdf[f] = area;
             }
             o->inv_area = 1.f / area;
+            orc_bvh_build(o);
         } else if (sd->type == MI355_SHAPE_SPHERE) {
             /* Sphere::update, sphere.cpp:150-172 (uniform positive scale assumed) */
             o->center = xf_point(o->to_world, V3(0.f, 0.f, 0.f));
@@ -383,7 +390,8 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
 }
 ORC_API void orc_scene_destroy(OScene *s) {
     if (!s) return;
-    for (uint32_t i = 0; i < s->n_shapes; ++i) { free(s->shapes[i].pos); free(s->shapes[i].nrm); free(s->shapes[i].uv); free(s->shapes[i].faces); }
+    for (uint32_t i = 0; i < s->n_shapes; ++i) { free(s->shapes[i].pos); free(s->shapes[i].nrm); free(s->shapes[i].uv); free(s->shapes[i].faces);
+                                                 free(s->shapes[i].area_cdf); free(s->shapes[i].nrm_len); free(s->shapes[i].bvh); free(s->shapes[i].bvh_faces); }
     for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
     free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s->lens); free(s);
 }
@@ -394,6 +402,25 @@ ORC_API int orc_scene_set_param(OScene *s, uint32_t kind, uint32_t index, const 
     if (kind == MI355_PARAM_TEXTURE_DATA && index < s->n_textures) {
         OTexture *t = &s->textures[index]; if (n != (uint64_t) t->w * t->h * t->c) return -1;
         memcpy(t->data, v, 4 * n); return 0;
+    }
+    if (kind == MI355_PARAM_VERTEX_POSITIONS && index < s->n_shapes && s->shapes[index].type == MI355_SHAPE_MESH) {
+        /* Mesh::parameters_changed (mesh.cpp:96-163): bbox / accel follow, vertex normals are recomputed when the mesh has them, the
+           area table is rebuilt */
+        OShape *o = &s->shapes[index]; if (n != 3ull * o->vertex_count) return -1;
+        memcpy(o->pos, v, 4 * n);
+        recompute_vertex_normals(o);
+        float area = 0.f;
+        for (uint32_t f = 0; f < o->face_count; ++f) {
+            const uint32_t *fi = o->faces + 3 * f;
+            v3 p0 = V3(o->pos[3*fi[0]], o->pos[3*fi[0]+1], o->pos[3*fi[0]+2]), p1 = V3(o->pos[3*fi[1]], o->pos[3*fi[1]+1], o->pos[3*fi[1]+2]), p2 = V3(o->pos[3*fi[2]], o->pos[3*fi[2]+1], o->pos[3*fi[2]+2]);
+            area += 0.5f * norm3(cross3(sub3(p1, p0), sub3(p2, p0))); o->area_cdf[f] = area;
+        }
+        o->inv_area = 1.f / area;
+        orc_bvh_build(o);
+        return 0;
+    }
+    if (kind == MI355_PARAM_BSDF_IOR && index < s->n_bsdfs && s->bsdfs[index].type == MI355_BSDF_DIELECTRIC && n == 2) {
+        s->bsdfs[index].int_ior = v[0]; s->bsdfs[index].ext_ior = v[1]; return 0;
     }
     return -1;
 }
@@ -450,6 +477,52 @@ static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t
     return active;
 }
 
+/* Acceleration of the oracle's own closest / any hit queries on large meshes (a median-split BVH; boxes are padded, so no hit
+   is lost -- the result is the linear scan's closest hit, only equal-t ties may resolve to another face). */
+static void orc_bvh_node(OShape *sh, uint32_t node, uint32_t begin, uint32_t end, float (*cent)[3]) {
+    ONode *nd = &sh->bvh[node];
+    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < 3; ++k) { nd->lo[k] = INFINITY; nd->hi[k] = -INFINITY; }
+    for (uint32_t i = begin; i < end; ++i) {
+        const uint32_t *fi = sh->faces + 3 * sh->bvh_faces[i];
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) { float v = sh->pos[3 * fi[j] + k]; if (v < nd->lo[k]) nd->lo[k] = v; if (v > nd->hi[k]) nd->hi[k] = v; }
+        for (int k = 0; k < 3; ++k) { float c = cent[sh->bvh_faces[i]][k]; if (c < clo[k]) clo[k] = c; if (c > chi[k]) chi[k] = c; }
+    }
+    for (int k = 0; k < 3; ++k) { float pad = 1e-5f * (1.f + fabsf(nd->lo[k]) + fabsf(nd->hi[k])); nd->lo[k] -= pad; nd->hi[k] += pad; }
+    uint32_t n = end - begin;
+    if (n <= 4) { nd->left = begin; nd->count = n; return; }
+    int axis = 0; if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1; if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    float split = 0.5f * (clo[axis] + chi[axis]); uint32_t i = begin, j = end;
+    while (i < j) { if (cent[sh->bvh_faces[i]][axis] < split) ++i; else { --j; uint32_t t = sh->bvh_faces[i]; sh->bvh_faces[i] = sh->bvh_faces[j]; sh->bvh_faces[j] = t; } }
+    if (i == begin || i == end) i = begin + n / 2;
+    uint32_t left = sh->n_nodes; sh->n_nodes += 2;
+    nd->left = left; nd->count = 0;
+    orc_bvh_node(sh, left, begin, i, cent); orc_bvh_node(sh, left + 1, i, end, cent);
+}
+static void orc_bvh_build(OShape *sh) {
+    free(sh->bvh); free(sh->bvh_faces); sh->bvh = NULL; sh->bvh_faces = NULL; sh->n_nodes = 0;
+    if (sh->type != MI355_SHAPE_MESH || sh->face_count <= ORC_BVH_MIN) return;
+    sh->bvh = (ONode *) malloc(sizeof(ONode) * 2u * (size_t) sh->face_count); sh->bvh_faces = (uint32_t *) malloc(4u * (size_t) sh->face_count);
+    float (*cent)[3] = (float (*)[3]) malloc(12u * (size_t) sh->face_count);
+    for (uint32_t f = 0; f < sh->face_count; ++f) {
+        sh->bvh_faces[f] = f; const uint32_t *fi = sh->faces + 3 * f;
+        for (int k = 0; k < 3; ++k) cent[f][k] = (sh->pos[3 * fi[0] + k] + sh->pos[3 * fi[1] + k] + sh->pos[3 * fi[2] + k]) * (1.f / 3.f);
+    }
+    sh->n_nodes = 1; orc_bvh_node(sh, 0, 0, sh->face_count, cent);
+    free(cent);
+}
+static inline int orc_box_hit(const ONode *nd, const Ray *ray, float maxt) {
+    float tn = 0.f, tf = maxt;
+    const float o[3] = { ray->o.x, ray->o.y, ray->o.z }, d[3] = { ray->d.x, ray->d.y, ray->d.z };
+    for (int k = 0; k < 3; ++k) {
+        if (d[k] == 0.f) { if (o[k] < nd->lo[k] || o[k] > nd->hi[k]) return 0; continue; }
+        float inv = 1.f / d[k], t0 = (nd->lo[k] - o[k]) * inv, t1 = (nd->hi[k] - o[k]) * inv;
+        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+        if (t0 > tn) tn = t0; if (t1 < tf) tf = t1;
+    }
+    return tn <= tf * 1.0001f + 1e-6f;
+}
+
 /* math::solve_quadratic: include/mitsuba/core/math.h:360-402 */
 static int solve_quadratic(float a, float b, float c, float *x0, float *x1) {
     int linear_case = a == 0.f, valid_linear = linear_case && b != 0.f;
@@ -503,6 +576,19 @@ static PI scene_intersect(OScene *sc, const Ray *ray_in) {
         } else if (sh->type == MI355_SHAPE_SPHERE) {
             float t;
             if (sphere_intersect(sh, &ray, &t) && t < pi.t) { pi.t = t; pi.prim_uv.x = pi.prim_uv.y = 0.f; pi.prim_index = 0; pi.shape_index = i; ray.maxt = t; }
+        } else if (sh->bvh) {
+            uint32_t stack[64]; int sp = 0; stack[sp++] = 0;
+            while (sp) {
+                const ONode *nd = &sh->bvh[stack[--sp]];
+                if (!orc_box_hit(nd, &ray, ray.maxt)) continue;
+                if (!nd->count) { if (sp < 62) { stack[sp++] = nd->left; stack[sp++] = nd->left + 1; } continue; }
+                for (uint32_t q = 0; q < nd->count; ++q) {
+                    const uint32_t f = sh->bvh_faces[nd->left + q]; const uint32_t *fi = sh->faces + 3 * f; float t; v2 uv;
+                    if (moeller_trumbore(&ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv) && (t < pi.t || (t == pi.t && pi.shape_index == i && f < pi.prim_index))) {
+                        pi.t = t; pi.prim_uv = uv; pi.prim_index = f; pi.shape_index = i; ray.maxt = t;
+                    }
+                }
+            }
         } else {
             for (uint32_t f = 0; f < sh->face_count; ++f) {
                 const uint32_t *fi = sh->faces + 3 * f; float t; v2 uv;
@@ -521,6 +607,18 @@ static int scene_ray_test(OScene *sc, const Ray *ray) {
         if (sh->type == MI355_SHAPE_RECTANGLE) { if (rect_intersect(sh, ray, &t, &uv)) return 1; }
         else if (sh->type == MI355_SHAPE_DISK) { if (disk_intersect(sh, ray, &t, &uv)) return 1; }
         else if (sh->type == MI355_SHAPE_SPHERE) { if (sphere_test(sh, ray)) return 1; }
+        else if (sh->bvh) {
+            uint32_t stack[64]; int sp = 0; stack[sp++] = 0;
+            while (sp) {
+                const ONode *nd = &sh->bvh[stack[--sp]];
+                if (!orc_box_hit(nd, ray, ray->maxt)) continue;
+                if (!nd->count) { if (sp < 62) { stack[sp++] = nd->left; stack[sp++] = nd->left + 1; } continue; }
+                for (uint32_t q = 0; q < nd->count; ++q) {
+                    const uint32_t *fi = sh->faces + 3 * sh->bvh_faces[nd->left + q];
+                    if (moeller_trumbore(ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv)) return 1;
+                }
+            }
+        }
         else for (uint32_t f = 0; f < sh->face_count; ++f) {
             const uint32_t *fi = sh->faces + 3 * f;
             if (moeller_trumbore(ray, mesh_vertex(sh, fi[0]), mesh_vertex(sh, fi[1]), mesh_vertex(sh, fi[2]), &t, &uv)) return 1;
@@ -1558,6 +1656,7 @@ typedef struct { const float *grad_image; double *acc;
                  float *grad; const mi355_param_info *layout; const int32_t *bsdf_slot, *tex_slot; v3 last_dv; } PtGrad;
 static __thread PtGrad g_ptg = { NULL, NULL, NULL, NULL, NULL, NULL, { 0.f, 0.f, 0.f } };
 #define PT_MAXV 64
+static __thread int g_geo_conn = 0;                                       /* set by connect_sensor: a diffuse connection reached the film (geometry derivative) */
 static v3 xf_point_proj(const float *m, v3 p) {                        /* Transform4f * Point3f with the homogeneous divide */
     float r[4];
     for (int i = 0; i < 4; ++i) { float v = m[i*4+3]; v = fmaf(m[i*4+0], p.x, v); v = fmaf(m[i*4+1], p.y, v); v = fmaf(m[i*4+2], p.z, v); r[i] = v; }
@@ -1658,6 +1757,7 @@ static void connect_sensor(OScene *sc, const SI *si, const mi355_bsdf_desc *bsdf
         v3 refl = bsdf_reflectance(sc, bsdf, si), val; float pdf;
         bsdf_eval_pdf(bsdf, refl, si->wi, local_d, 1, &val, &pdf);
         surface_weight = scale3(val, correction);
+        g_geo_conn = bsdf->type == MI355_BSDF_DIFFUSE && valid && si->wi.z > 0.f && local_d.z > 0.f;   /* (geometry derivative: a diffuse connection was made) */
     }
     v3 result = scale3(mul3(weight, surface_weight), sample_scale);
     v2 pos = { uv.x + (float) sc->sensor.crop_offset_x, uv.y + (float) sc->sensor.crop_offset_y };
@@ -1678,6 +1778,7 @@ static uint32_t pick_emitter(const OScene *sc, float *sample, float *weight) {  
     *weight = cf; *sample = scaled - (float) index;
     return index;
 }
+#include "mi_oracle_geo.inc"
 static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng_io, float sample_scale, float *film_rgbw, Cnt *cnt);
 /* One sampler stream: seeded once (integrator.cpp:708), then one sample per pass from the SAME stream (:719-727; the independent
    sampler's advance() does not touch the generator).  Masked sampler calls of the reference never advance a masked-out lane, which
@@ -1735,6 +1836,7 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         throughput = scale3(V3(em->radiance[0], em->radiance[1], em->radiance[2]), (1.f / esh->inv_area) * idx_weight);
     }
     int active = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) != 0.f;
+    if (g_geo.on) { g_geo.nv = 0; g_geo.o0 = ray.o; g_geo.d0 = ray.d; g_geo.T0 = throughput; }
     v3 v_dv[PT_MAXV], v_rho[PT_MAXV]; int32_t v_bsdf[PT_MAXV], v_tidx[PT_MAXV][4]; float v_twgt[PT_MAXV][4]; int nv = 0;
     /* ---- trace_light_ray, ptracer.cpp:200-284 */
     float eta = 1.f; int32_t depth = 1;
@@ -1747,10 +1849,11 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         v2 ss; ss.x = pcg32_float(&rng); ss.y = pcg32_float(&rng);
         v2 uv; v3 ds_p, ds_d; float sensor_weight = 0.f;
         int seen = sensor_sample_direction(sc, si.p, ss, &uv, &ds_p, &ds_d, &sensor_weight);
-        g_ptg.last_dv = V3(0.f, 0.f, 0.f);
+        g_ptg.last_dv = V3(0.f, 0.f, 0.f); g_geo_conn = 0;
         connect_sensor(sc, &si, bsdf, seen, uv, ds_p, scale3(throughput, sensor_weight), sample_scale, film_rgbw, cnt, scale3(tu, sensor_weight), ei);
         float s1 = pcg32_float(&rng); v2 s2; s2.x = pcg32_float(&rng); s2.y = pcg32_float(&rng);
         v3 refl = bsdf_reflectance(sc, bsdf, &si); BSample bs; v3 bsdf_val;
+        GeoVtx *gvx = (g_geo.on && g_geo.nv < GEO_MAXV) ? &g_geo.v[g_geo.nv++] : NULL;
         if (g_ptg.grad && nv < PT_MAXV) {
             v_dv[nv] = g_ptg.last_dv; v_rho[nv] = refl; v_bsdf[nv] = (int32_t) sc->shapes[si.shape].bsdf;
             if (bsdf->reflectance_texture >= 0) (void) texture_eval(&sc->textures[bsdf->reflectance_texture], si.uv, v_tidx[nv], v_twgt[nv]);
@@ -1764,6 +1867,13 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         throughput = mul3(throughput, scale3(bsdf_val, correction)); tu = mul3(tu, scale3(bsdf_val, correction));
         eta *= bs.eta;
         active = active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
+        if (gvx) {
+            gvx->shape = (uint32_t) si.shape; gvx->prim = si.prim_index; gvx->t_hit = si.t; gvx->sh_s = si.sh_s; gvx->sh_t = si.sh_t;
+            gvx->lobe = bs.delta ? (bs.wo.z * si.wi.z > 0.f ? 2 : 1) : 0; gvx->conn = g_geo_conn; gvx->cont = active;
+            gvx->l = bs.wo; gvx->W = bsdf_val; gvx->refl = refl; gvx->rr = 1.f;
+            float mag = (1.f + fmaxf(fmaxf(fabsf(si.p.x), fabsf(si.p.y)), fabsf(si.p.z))) * RAY_EPS;
+            gvx->mag = mulsign(mag, dot3(si.n, wo_world));
+        }
         if (!active) break;
         ray = spawn_ray(si.p, si.n, wo_world);
         pi = scene_intersect(sc, &ray); cnt->isect++; si = compute_si(sc, &ray, &pi);
@@ -1774,6 +1884,7 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
             float q = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * (eta * eta), 0.95f);
             active = active && pcg32_float(&rng) < q;       /* next_1d(active): dead lanes still advance their stream -- irrelevant, they are done */
             throughput = scale3(throughput, 1.f / q); tu = scale3(tu, 1.f / q);
+            if (gvx) gvx->rr = 1.f / q;
         }
     }
     if (g_ptg.grad) {                                                   /* suffix sums over the path's connections */
@@ -1798,6 +1909,7 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
             }
         }
     }
+    if (g_geo.on) geo_eval_path(sc, g_ptg.grad_image);
     *rng_io = rng;
 }
 /* The shard of the particle tracer's lane grid (film pixels x sampler streams per pixel) a call covers: mi355_render_params's pixel /
@@ -1882,8 +1994,28 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
     size_t na = 3 * (size_t) sc->n_emitters;
     double *accs = (double *) calloc(na * (size_t) n_threads, sizeof(double));
     float *grads = all_params ? (float *) calloc((size_t) total * (size_t) n_threads, sizeof(float)) : NULL;
+    /* MI355_FLAG_GEOMETRY_GRADS: vertex positions and IORs (mi_oracle_geo.inc) */
+    const int geo = (rp->flags & MI355_FLAG_GEOMETRY_GRADS) != 0;
+    uint64_t *pos_off = (uint64_t *) malloc(8 * (sc->n_shapes + 1)), *nrm_base = (uint64_t *) malloc(8 * (sc->n_shapes + 1)), *ior_off = (uint64_t *) malloc(8 * (sc->n_bsdfs + 1));
+    uint64_t nrm_total = 0;
+    for (uint32_t i = 0; i < sc->n_shapes; ++i) { pos_off[i] = (uint64_t) -1; nrm_base[i] = nrm_total; if (sc->shapes[i].type == MI355_SHAPE_MESH) nrm_total += 3ull * sc->shapes[i].vertex_count; }
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) ior_off[i] = (uint64_t) -1;
+    for (int i = 0; i < np; ++i) {
+        if (layout[i].kind == MI355_PARAM_VERTEX_POSITIONS) pos_off[layout[i].index] = layout[i].offset;
+        else if (layout[i].kind == MI355_PARAM_BSDF_IOR) ior_off[layout[i].index] = layout[i].offset;
+    }
+    double *geo_grad = geo ? (double *) calloc((size_t) total * (size_t) n_threads + 1, sizeof(double)) : NULL;
+    double *geo_nrm = geo ? (double *) calloc((size_t) nrm_total * (size_t) n_threads + 1, sizeof(double)) : NULL;
     #pragma omp parallel num_threads(n_threads)
     {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num();
+#else
+        const int tid = 0;
+#endif
+        memset(&g_geo, 0, sizeof(g_geo));
+        if (geo) { g_geo.on = 1; g_geo.grad = geo_grad + (size_t) total * (size_t) tid; g_geo.nrm_adj = geo_nrm + (size_t) nrm_total * (size_t) tid;
+                   g_geo.pos_off = pos_off; g_geo.ior_off = ior_off; g_geo.nrm_base = nrm_base; g_geo.sample_scale = sample_scale; }
 #ifdef _OPENMP
         double *acc = accs + na * (size_t) omp_get_thread_num();
         float *gl = grads ? grads + total * (size_t) omp_get_thread_num() : NULL;
@@ -1895,8 +2027,21 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
         g_ptg.grad = gl; g_ptg.layout = layout; g_ptg.bsdf_slot = bsdf_slot; g_ptg.tex_slot = tex_slot;
         #pragma omp for schedule(dynamic, 4096)
         for (int64_t i = 0; i < (int64_t) lanes; ++i) ptracer_lane(sc, rp, pt_shard_lane(sc, rp, (uint64_t) i), sample_scale, NULL, &cnt);
-        g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL; g_ptg.grad = NULL;
+        g_importance_mode = 0; g_ptg.grad_image = NULL; g_ptg.acc = NULL; g_ptg.grad = NULL; g_geo.on = 0;
     }
+    if (geo) {
+        for (int t = 1; t < n_threads; ++t) {
+            for (uint64_t i = 0; i < total; ++i) geo_grad[i] += geo_grad[(size_t) total * (size_t) t + i];
+            for (uint64_t i = 0; i < nrm_total; ++i) geo_nrm[i] += geo_nrm[(size_t) nrm_total * (size_t) t + i];
+        }
+        for (uint32_t i = 0; i < sc->n_shapes; ++i) {       /* vertex normals that follow their positions: carry their adjoint on */
+            const OShape *sh = &sc->shapes[i];
+            if (sh->type == MI355_SHAPE_MESH && sh->nrm && sh->nrm_dep && pos_off[i] != (uint64_t) -1) geo_normals_to_positions(sh, geo_nrm + nrm_base[i], geo_grad + pos_off[i]);
+        }
+        for (int i = 0; i < np; ++i) if (layout[i].kind == MI355_PARAM_VERTEX_POSITIONS || layout[i].kind == MI355_PARAM_BSDF_IOR)
+            for (uint64_t k = 0; k < layout[i].size; ++k) grad_out[layout[i].offset + k] += (float) geo_grad[layout[i].offset + k];
+    }
+    free(geo_grad); free(geo_nrm); free(pos_off); free(nrm_base); free(ior_off);
     if (grads) { for (int t = 0; t < n_threads; ++t) for (uint64_t i = 0; i < total; ++i) grad_out[i] += grads[total * (size_t) t + i]; free(grads); }
     free(bsdf_slot); free(tex_slot);
     for (uint32_t e = 0; e < sc->n_emitters; ++e) {
@@ -2004,7 +2149,8 @@ ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp
 }
 
 /* parameter layout shared with the engine's definition (include/mi355.h: mi355_scene_param_layout):
-   bsdf reflectances (constant ones), then textures, then emitter radiances, in index order */
+   bsdf reflectances (constant ones), then textures, then emitter radiances, then the vertex positions of the meshes, then the IOR pairs
+   of the dielectrics, in index order */
 ORC_API int orc_param_layout(const OScene *sc, mi355_param_info *out, uint32_t cap, uint64_t *total) {
     uint32_t n = 0; uint64_t off = 0;
     for (uint32_t i = 0; i < sc->n_bsdfs; ++i) if (sc->bsdfs[i].type == MI355_BSDF_DIFFUSE && sc->bsdfs[i].reflectance_texture < 0) {
@@ -2014,6 +2160,11 @@ ORC_API int orc_param_layout(const OScene *sc, mi355_param_info *out, uint32_t c
         if (n < cap) { out[n].kind = MI355_PARAM_TEXTURE_DATA; out[n].index = i; out[n].offset = off; out[n].size = sz; } n++; off += sz; }
     for (uint32_t i = 0; i < sc->n_emitters; ++i) {
         if (n < cap) { out[n].kind = MI355_PARAM_EMITTER_RADIANCE; out[n].index = i; out[n].offset = off; out[n].size = 3; } n++; off += 3; }
+    for (uint32_t i = 0; i < sc->n_shapes; ++i) if (sc->shapes[i].type == MI355_SHAPE_MESH) {
+        uint64_t sz = 3ull * sc->shapes[i].vertex_count;
+        if (n < cap) { out[n].kind = MI355_PARAM_VERTEX_POSITIONS; out[n].index = i; out[n].offset = off; out[n].size = sz; } n++; off += sz; }
+    for (uint32_t i = 0; i < sc->n_bsdfs; ++i) if (sc->bsdfs[i].type == MI355_BSDF_DIELECTRIC) {
+        if (n < cap) { out[n].kind = MI355_PARAM_BSDF_IOR; out[n].index = i; out[n].offset = off; out[n].size = 2; } n++; off += 2; }
     if (total) *total = off;
     return (int) n;
 }
@@ -2053,7 +2204,7 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
     for (int i = 0; i < np; ++i) {
         if (layout[i].kind == MI355_PARAM_BSDF_REFLECTANCE) bsdf_slot[layout[i].index] = i;
         else if (layout[i].kind == MI355_PARAM_TEXTURE_DATA) tex_slot[layout[i].index] = i;
-        else em_slot[layout[i].index] = i;
+        else if (layout[i].kind == MI355_PARAM_EMITTER_RADIANCE) em_slot[layout[i].index] = i;
     }
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -2101,7 +2252,7 @@ ORC_API uint64_t orc_render_forward(OScene *sc, const mi355_render_params *rp, c
     for (int i = 0; i < np; ++i) {
         if (layout[i].kind == MI355_PARAM_BSDF_REFLECTANCE) bsdf_slot[layout[i].index] = i;
         else if (layout[i].kind == MI355_PARAM_TEXTURE_DATA) tex_slot[layout[i].index] = i;
-        else em_slot[layout[i].index] = i;
+        else if (layout[i].kind == MI355_PARAM_EMITTER_RADIANCE) em_slot[layout[i].index] = i;
     }
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();

@@ -10,9 +10,8 @@ LIB = os.path.join(HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = os.path.join(HERE, "mi_oracle.c")
-    hdr = os.path.join(os.path.dirname(HERE), "include", "mi355.h")
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [os.path.join(HERE, "mi_oracle.c"), os.path.join(HERE, "mi_oracle_geo.inc"), os.path.join(os.path.dirname(HERE), "include", "mi355.h")]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(f) for f in deps):
         return LIB
     r = subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "liboracle.so"], capture_output=True, text=True)
     if r.returncode != 0:

@@ -113,7 +113,10 @@ def test_ply_loader(mi, tmp_path):
         sc = mi.load_dict({"type": "scene", "q": {"type": "ply", "filename": str(p), "to_world": mi.ScalarTransform4f.translate([0, 0, 2])}})
         s = sc.shapes[0]
         assert s.primitive_count() == 2 and s.vertex_positions.shape == (4, 3) and np.allclose(s.vertex_positions[:, 2], 2)
-        assert np.isclose(s.surface_area(), 1.0) and s.vertex_normals is None and np.allclose(s.vertex_texcoords[2], [1, 1])
+        # ply.cpp:444-446: a file without normals gets angle-weighted vertex normals (recompute_vertex_normals) unless face_normals is set
+        assert np.isclose(s.surface_area(), 1.0) and np.allclose(s.vertex_normals, [0, 0, 1], atol=1e-6) and np.allclose(s.vertex_texcoords[2], [1, 1])
+        sf = mi.load_dict({"type": "scene", "q": {"type": "ply", "filename": str(p), "face_normals": True}}).shapes[0]
+        assert sf.vertex_normals is None
     bad = tmp_path / "bad.ply"; bad.write_text("plx\n")
     with pytest.raises(mi.PluginError):
         mi.load_dict({"type": "scene", "q": {"type": "ply", "filename": str(bad)}})

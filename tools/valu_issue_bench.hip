@@ -1,0 +1,87 @@
+// valu_issue_bench.hip -- how many cycles does one SIMD of gfx950 need per wave64 VALU instruction, as a function of the
+// number of waves resident on it?  The denominator of bench.py's "valu_issue" roofline.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o valu_issue_bench tools/valu_issue_bench.hip && ./valu_issue_bench > profiles/r02_valu_issue.json
+//
+// Every wave runs ITERS x 32 independent v_fma_f32 (8 accumulator chains, 4 rounds per trip: a chain's next fma is 8 issues
+// away, well past the 4-cycle dependent latency).  The number of waves per SIMD is pinned through the dynamic LDS size of the
+// 256-thread workgroups (160 KB / k  =>  k workgroups per CU  =>  k waves on each of the 4 SIMDs).  Reported per k:
+//   cyc_per_inst_smemtime   median over waves of (s_memtime delta) / (k * instructions of one wave): SIMD cycles per instruction
+//   cyc_per_inst_wall       kernel wall time (HIP events) * clock / (k * instructions): the same from outside, clock = the value
+//                           returned by hipDeviceGetAttribute(ClockRate); under load the chip may clock lower (DVFS), which makes
+//                           this figure read HIGH -- s_memtime counts shader cycles and is the one to use.
+// Also a transcendental stream (v_rcp_f32) for the 2 : 1 mix weight.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_issue(float *out, int iters, unsigned long long *cyc) {
+    extern __shared__ float pad[];
+    float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float b = 0.999f, c = 1e-3f;
+    if (iters < 0) pad[threadIdx.x] = a0;                                   // keeps the LDS allocation alive
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (OP == 0) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else {
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+int main() {
+    int dev = 0; CHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount, clock_khz = prop.clockRate;
+    const int iters = 1 << 15;                                              // 32768 x 32 = 1 048 576 instructions per wave
+    const double n_inst = (double) iters * 32.0;
+    printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"instructions_per_wave\": %.0f, \"results\": [", prop.name, prop.gcnArchName, cus, clock_khz, n_inst);
+    bool first = true;
+    for (int op = 0; op < 2; ++op)
+        for (int k : { 1, 2, 3, 4, 5, 6, 8 }) {
+            const int blocks = cus * k;
+            const size_t lds = (size_t) (160 * 1024 / k) - (k == 1 ? 0 : 512);   // k workgroups fill the CU's 160 KB
+            float *out; unsigned long long *cyc;
+            CHECK(hipMalloc((void **) &out, (size_t) blocks * 256 * 4)); CHECK(hipMalloc((void **) &cyc, (size_t) blocks * 4 * 8));
+            auto kern = op == 0 ? k_issue<0> : k_issue<1>;
+            CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, out, iters, cyc);   // warm-up
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, out, iters, cyc);
+            CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float ms = 0.f; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<unsigned long long> h((size_t) blocks * 4);
+            CHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());
+            const double med = (double) h[h.size() / 2], lo = (double) h[h.size() / 20], hi = (double) h[h.size() - 1 - h.size() / 20];
+            printf("%s\n  {\"op\": \"%s\", \"waves_per_simd\": %d, \"workgroups\": %d, \"kernel_ms\": %.4f, \"cyc_per_inst_smemtime\": %.3f, \"p05\": %.3f, \"p95\": %.3f, \"cyc_per_inst_wall\": %.3f}",
+                   first ? "" : ",", op == 0 ? "v_fma_f32" : "v_rcp_f32", k, blocks, ms, med / (k * n_inst), lo / (k * n_inst), hi / (k * n_inst),
+                   ms * 1e-3 * clock_khz * 1e3 / (k * n_inst));
+            first = false;
+            CHECK(hipFree(out)); CHECK(hipFree(cyc));
+        }
+    printf("\n]}\n");
+    return 0;
+}
