@@ -16,6 +16,7 @@ from .integrators import (Integrator, PathIntegrator, PRBIntegrator, ParticleTra
                           sample_tea_32, shard_pixels, shard_tiles, shard_of, scene_param_layout)
 
 from .optimizers import Adam, SGD, Optimizer
+from . import lens_design
 from .xml_loader import load_file, parse_file
 
 __all__ = [n for n in dir() if not n.startswith("_")]

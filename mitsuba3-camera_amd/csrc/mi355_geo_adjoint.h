@@ -175,6 +175,38 @@ template <typename F> GA_HD void sphere_hit_adjoint(V<F> c, F r, bool flip, V<F>
     ao = ao + d * ((F) 2 * aB) + oc * ((F) 2 * aC);
 }
 
+// ---- Fresnel reflectance of a dielectric interface with its two partial derivatives ---------------------------------------------
+// SmoothDielectric::sample detaches the lobe choice and carries the Fresnel term's derivative in the weight:
+//     weight = select(selected_r, r_i / detach(r_i), t_i / detach(t_i))       (dielectric.cpp:343-351, dispersive_dielectric.cpp:356-364)
+// -- value 1, gradient d(r_i) / r_i or d(t_i) / t_i -- so the throughput depends on cos(theta_i) and on the IOR ratio through it.
+template <typename F> struct D2 { F v, a, b; };                             // value, d / d cos(theta_i), d / d eta
+template <typename F> GA_HD D2<F> d2(F v, F a = (F) 0, F b = (F) 0) { D2<F> r; r.v = v; r.a = a; r.b = b; return r; }
+template <typename F> GA_HD D2<F> operator+(D2<F> x, D2<F> y) { return d2<F>(x.v + y.v, x.a + y.a, x.b + y.b); }
+template <typename F> GA_HD D2<F> operator-(D2<F> x, D2<F> y) { return d2<F>(x.v - y.v, x.a - y.a, x.b - y.b); }
+template <typename F> GA_HD D2<F> operator*(D2<F> x, D2<F> y) { return d2<F>(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b); }
+template <typename F> GA_HD D2<F> operator/(D2<F> x, D2<F> y) { const F i = (F) 1 / y.v, q = x.v * i; return d2<F>(q, (x.a - q * y.a) * i, (x.b - q * y.b) * i); }
+template <typename F> GA_HD D2<F> d2sqrt(D2<F> x) { const F s = sqrt_(x.v > (F) 0 ? x.v : (F) 0), k = s > (F) 0 ? (F) 0.5 / s : (F) 0; return d2<F>(s, x.a * k, x.b * k); }
+// fresnel(cos_theta_i, eta), include/mitsuba/render/fresnel.h:34-72: r and its partial derivatives
+template <typename F> GA_HD void fresnel_partials(F cos_theta_i, F eta_, F &r, F &dr_dc, F &dr_deta) {
+    const bool outside = cos_theta_i >= (F) 0;
+    const D2<F> c = d2<F>(cos_theta_i, (F) 1, (F) 0), eta = d2<F>(eta_, (F) 0, (F) 1), one = d2<F>((F) 1);
+    const D2<F> eta_it = outside ? eta : one / eta, eta_ti = outside ? one / eta : eta;
+    const D2<F> ct2 = one - (one - c * c) * eta_ti * eta_ti;
+    const D2<F> ca = cos_theta_i < (F) 0 ? d2<F>((F) 0) - c : c, cta = d2sqrt(ct2);
+    const D2<F> a_s = (ca - eta_it * cta) / (ca + eta_it * cta), a_p = (cta - eta_it * ca) / (cta + eta_it * ca);
+    const D2<F> rr = (a_s * a_s + a_p * a_p) * d2<F>((F) 0.5);
+    r = rr.v; dr_dc = rr.a; dr_deta = rr.b;
+    if (eta_ == (F) 1) { r = (F) 0; dr_dc = dr_deta = (F) 0; }
+    else if (ca.v == (F) 0 || !(ct2.v > (F) 0)) { r = (F) 1; dr_dc = dr_deta = (F) 0; }       // grazing incidence / total internal reflection
+}
+// d W / d cos(theta_i) and d W / d eta of the weight W of a dielectric's sampled lobe (`reflect`: the reflected lobe was taken)
+template <typename F> GA_HD void dielectric_weight_partials(F cos_theta_i, F eta, bool reflect, V<F> W, V<F> &dW, V<F> &dWe) {
+    F r, dc, de; fresnel_partials(cos_theta_i, eta, r, dc, de);
+    const F p = reflect ? r : (F) 1 - r, sg = reflect ? (F) 1 : (F) -1;
+    const F kc = p > (F) 0 ? sg * dc / p : (F) 0, ke = p > (F) 0 ? sg * de / p : (F) 0;
+    dW = W * kc; dWe = W * ke;
+}
+
 // ---- transport through one vertex ----------------------------------------------------------------------------------
 enum { LOBE_FRAME = 0,       // a sampled LOCAL direction carried by the shading frame (diffuse; rough conductor: direction and weight kept)
        LOBE_REFRACT = 1,     // dielectric.cpp:246-371, transmitted lobe
@@ -188,7 +220,7 @@ template <typename F> struct Sensor {      // PerspectiveCamera::sample_directio
 template <typename F> struct Vertex {
     V<F> d, T;               // incoming direction and throughput (the incoming origin only matters to the hit)
     int lobe; V<F> l;        // LOBE_FRAME: the sampled local direction
-    V<F> W, dW;              // bsdf weight and d W / d cos(theta_i) (conductor's Fresnel term; zero elsewhere)
+    V<F> W, dW, dWe;         // bsdf weight, d W / d cos(theta_i) and d W / d rel_eta (the Fresnel term carried by a conductor's / dielectric's weight)
     F rel_eta;               // dielectric: int_ior / ext_ior
     F mag;                   // signed ray-origin offset along ng (spawn_ray, interaction.h:158-162): taken as constant
     F rr;                    // 1 / q of the roulette step that FOLLOWS this vertex (1 if none); q is detached
@@ -258,7 +290,8 @@ template <typename F> GA_HD void transport_adjoint(const Shade<F> &s, const Vert
         if (vx.cont) { g1 = dot(s.ng, wo); g2 = dot(s.ng, md); r = (wiz * g1) / (wolz * g2); corr = abs_(r); }
         aT = aT + (aT_out * vx.W) * (corr * vx.rr);                         // T' = T W corr rr
         const V<F> tw = aT_out * vx.T;
-        awiz += dot(tw, vx.dW) * (corr * vx.rr);                            // W = W(cos theta_i) (conductor)
+        awiz += dot(tw, vx.dW) * (corr * vx.rr);                            // W = W(cos theta_i, rel_eta): Fresnel term of a conductor / dielectric
+        arel += dot(tw, vx.dWe) * (corr * vx.rr);
         if (vx.cont) {
             const F acorr = dot(tw, vx.W) * vx.rr, ar = r < (F) 0 ? -acorr : acorr;
             const F den = wolz * g2, aa = ar / den, ab = -ar * r / den;     // r = (wiz g1) / (wolz g2)

@@ -203,7 +203,7 @@ MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_dep
         ga::Shade<float> shd; shd.p = G3(si.p); shd.ng = G3(si.n); shd.ns = G3(si.sh_n); shd.sh_s = G3(si.sh_s); shd.sh_t = G3(si.sh_t);
         ga::Vertex<float> vx;
         vx.d = G3(r.d); vx.T = G3(T); vx.lobe = (int) (flags & MI_TF_LOBE_MASK);
-        vx.W = G3(Wv); vx.dW = ga::mk<float>(0.f, 0.f, 0.f); vx.rel_eta = bsdf.rel_eta; vx.rr = rr;
+        vx.W = G3(Wv); vx.dW = vx.dWe = ga::mk<float>(0.f, 0.f, 0.f); vx.rel_eta = bsdf.rel_eta; vx.rr = rr;
         vx.cont = (flags & MI_TF_CONT) != 0u && k + 1 < (int32_t) nv;       // (nothing downstream of the last vertex: its continuation has no adjoint)
         vx.conn = (flags & MI_TF_CONN) != 0u;
         vx.l = ga::mk<float>(0.f, 0.f, 1.f); vx.mag = 0.f;
@@ -220,6 +220,8 @@ MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_dep
             v3 Fm = V3(fresnel_conductor_(c - hh, bsdf.eta[0], bsdf.k[0]), fresnel_conductor_(c - hh, bsdf.eta[1], bsdf.k[1]), fresnel_conductor_(c - hh, bsdf.eta[2], bsdf.k[2]));
             vx.dW = G3(((Fp - Fm) * (0.5f / hh)) * ld3(bsdf.reflectance));
         }
+        if (FULL && bsdf.type == MI355_BSDF_DIELECTRIC && vx.lobe != ga::LOBE_FRAME)      // weight = t_i / detach(t_i) (or r_i / detach(r_i)), dielectric.cpp:343-351
+            ga::dielectric_weight_partials(si.wi.z, bsdf.rel_eta, vx.lobe == ga::LOBE_REFLECT, vx.W, vx.dW, vx.dWe);
         vx.refl = G3(Wv); vx.K = sample_scale * MI_INV_PI;
         vx.Gv = vx.Gx = vx.Gy = ga::mk<float>(0.f, 0.f, 0.f);
         if (vx.conn) {

@@ -23,6 +23,7 @@
 // interior derivative (this pass, and AD alike) follows its in-facet slope, whose jumps at the facet edges cancel it in reality
 // (measured on a mirror ball: 29 - 60 % depending on the tessellation; near-normal refraction is hardly affected).
 #pragma once
+#include "mi355_geo_adjoint.h"
 
 struct Df { float v, d; };
 MI_DEV Df DF(float v, float d = 0.f) { Df r; r.v = v; r.d = d; return r; }
@@ -274,6 +275,12 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
                 v3 Fm = V3(fresnel_conductor_(c - hh, bsdf.eta[0], bsdf.k[0]), fresnel_conductor_(c - hh, bsdf.eta[1], bsdf.k[1]), fresnel_conductor_(c - hh, bsdf.eta[2], bsdf.k[2]));
                 v3 dF = ((Fp - Fm) * (0.5f / hh)) * ld3(bsdf.reflectance);
                 W = D3vd(bsdf_val, dF * wi.z.d);
+            }
+            if (FULL && bsdf.type == MI355_BSDF_DIELECTRIC && bs.delta) {  // weight = t_i / detach(t_i) (or r_i / detach(r_i)): value 1, gradient d(t_i) / t_i (dielectric.cpp:343-351)
+                const bool refl_lobe = bs.wo.z * si.wi.z > 0.f;
+                const float drel = sc.shapes[hit.shape].bsdf == gt.bsdf ? gt.d_rel_eta : 0.f;
+                ga::V<float> dWc, dWe; ga::dielectric_weight_partials(si.wi.z, bsdf.rel_eta, refl_lobe, ga::mk<float>(bsdf_val.x, bsdf_val.y, bsdf_val.z), dWc, dWe);
+                W = D3vd(bsdf_val, V3(dWc.x, dWc.y, dWc.z) * wi.z.d + V3(dWe.x, dWe.y, dWe.z) * drel);
             }
             T = (T * W) * dcorr;
             eta *= bs.eta;

@@ -632,7 +632,8 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         @staticmethod
         def forward(ctx, *tensors):
             for k, t in zip(diff_keys, tensors):
-                params._push(k, t)
+                if params._values[k] is not t or k in params._dirty:          # (params.update() above has pushed everything that was assigned)
+                    params._push(k, t); params._dirty.discard(k)
             return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
 
         @staticmethod

@@ -1,69 +1,105 @@
-"""mi.ad.Adam / mi.ad.SGD on torch tensors (src/python/python/ad/optimizers.py:116-302).
+"""mi.ad.SGD / mi.ad.Adam on torch tensors, statement for statement after src/python/python/ad/optimizers.py:116-302.
 
 Usage mirrors the reference:
     opt = mi.Adam(lr=0.05); opt[key] = params[key]; params.update(opt)
     loop: img = mi.render(scene, params, spp=..., seed=it); loss.backward(); opt.step(); params.update(opt)
 Variables are leaf tensors with requires_grad=True living on the scene's device; `step()` reads their .grad
 (filled by the render op's backward) and replaces them with fresh leaves, like the reference re-enables gradients.
+A variable whose .grad is None is the reference's "gradient of shape 0": no step is taken for it.
+
+Two quirks of the reference are kept on purpose (tests/test_host_cpu.py::test_optimizers_follow_the_reference pins them):
+  * SGD with momentum steps with the PREVIOUS velocity (`step = lr * self.state[k]` is formed before the state is replaced,
+    optimizers.py:163-170), so the first step of a fresh variable is zero;
+  * Adam increments its step counter t[k] BEFORE it looks at the gradient (optimizers.py:265-273), so an iteration without a
+    gradient still advances the bias correction; reset(k) (new key, or a shape change) zeroes the moments AND t[k].
 """
 import math
 from collections import defaultdict
 
 
 class Optimizer:
+    """optimizers.py:6-114"""
+
     def __init__(self, lr, params=None):
-        self.lr_default = float(lr)
+        self.lr = {}
+        self.set_learning_rate(lr)
         self.variables = {}
         self.state = {}
-        self.lr = {}
         if params is not None:
-            for k in params.keys():
-                self[k] = params[k]
+            for k, v in params.items():
+                self.__setitem__(k, v)
 
-    def __contains__(self, k): return k in self.variables
-    def __getitem__(self, k): return self.variables[k]
+    def __contains__(self, key): return key in self.variables
+    def __getitem__(self, key): return self.variables[key]
+    def __delitem__(self, key): del self.variables[key]
+    def __len__(self): return len(self.variables)
     def keys(self): return self.variables.keys()
     def items(self): return self.variables.items()
 
     def __setitem__(self, key, value):
-        v = value.detach().clone().requires_grad_(True)
-        if key not in self.variables or self.variables[key].shape != v.shape:
-            self.reset_state = True
-            self.state.pop(key, None)
-        self.variables[key] = v
+        """Overwrite the value of a parameter; the optimizer state is kept unless the parameter is new or changed its shape
+        (optimizers.py:41-60)."""
+        import torch
+        if not (torch.is_tensor(value) and value.is_floating_point()):
+            raise Exception('Optimizer.__setitem__(): value should be differentiable!')
+        needs_reset = (key not in self.variables) or tuple(self.variables[key].shape) != tuple(value.shape)
+        self.variables[key] = value.detach().clone().requires_grad_(True)
+        if needs_reset:
+            self.reset(key)
 
     def set_learning_rate(self, lr):
-        if isinstance(lr, dict):
-            self.lr.update({k: float(v) for k, v in lr.items()})
-        else:
+        if isinstance(lr, (float, int)):
             self.lr_default = float(lr)
+        elif isinstance(lr, dict):
+            for k, v in lr.items():
+                self.lr[k] = float(v)
+        else:
+            raise Exception('Optimizer.set_learning_rate(): value should be a float or a dict!')
 
     def _lr(self, k):
         return self.lr.get(k, self.lr_default)
 
+    def reset(self, key):
+        """Resets the internal state associated with a parameter, if any (e.g. momentum)."""
+        pass
+
 
 class SGD(Optimizer):
-    """optimizers.py:116-201 (momentum optional)"""
+    """optimizers.py:116-201"""
 
-    def __init__(self, lr, momentum=0.0, params=None):
-        assert 0 <= momentum < 1 and lr > 0
+    def __init__(self, lr, momentum=0, mask_updates=False, params=None):
+        assert momentum >= 0 and momentum < 1
+        assert lr > 0
         self.momentum = momentum
+        self.mask_updates = mask_updates
         super().__init__(lr, params)
 
     def step(self):
         import torch
         for k, p in list(self.variables.items()):
-            g = p.grad
-            if g is None:
+            g_p = p.grad
+            if g_p is None:
                 continue
-            if self.momentum == 0:
-                u = p.detach() - self._lr(k) * g
+            if self.momentum != 0:
+                if tuple(g_p.shape) != tuple(self.state[k].shape):
+                    self.reset(k)
+                next_state = self.momentum * self.state[k] + g_p
+                step = self._lr(k) * self.state[k]                # the previous velocity, as in the reference (:166)
+                if self.mask_updates:
+                    nonzero = g_p != 0
+                    next_state = torch.where(nonzero, next_state, self.state[k])
+                    step = torch.where(nonzero, step, torch.zeros_like(step))
+                self.state[k] = next_state
+                value = p.detach() - step
             else:
-                v = self.state.get(k)
-                v = self.momentum * v + g if v is not None else g.clone()
-                self.state[k] = v
-                u = p.detach() - self._lr(k) * v
-            self.variables[k] = u.requires_grad_(True)
+                value = p.detach() - self._lr(k) * g_p
+            self.variables[k] = value.requires_grad_(True)
+
+    def reset(self, key):
+        import torch
+        if self.momentum == 0:
+            return
+        self.state[key] = torch.zeros_like(self.variables[key].detach())
 
 
 class Adam(Optimizer):
@@ -73,29 +109,37 @@ class Adam(Optimizer):
         assert 0 <= beta_1 < 1 and 0 <= beta_2 < 1 and lr > 0 and epsilon > 0
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.mask_updates, self.uniform = mask_updates, uniform
-        self.t = defaultdict(int)
+        self.t = defaultdict(lambda: 0)
         super().__init__(lr, params)
 
     def step(self):
         import torch
         for k, p in list(self.variables.items()):
-            g = p.grad
-            if g is None:
-                continue
             self.t[k] += 1
-            lr_t = self._lr(k) * math.sqrt(1 - self.beta_2 ** self.t[k]) / (1 - self.beta_1 ** self.t[k])
-            st = self.state.get(k)
-            if st is None or st[0].shape != g.shape:
-                st = (torch.zeros_like(g), torch.zeros_like(g))
-            m_tp, v_tp = st
-            m_t = self.beta_1 * m_tp + (1 - self.beta_1) * g
-            v_t = self.beta_2 * v_tp + (1 - self.beta_2) * g * g
+            lr_scale = math.sqrt(1 - self.beta_2 ** self.t[k]) / (1 - self.beta_1 ** self.t[k])
+            lr_t = self._lr(k) * lr_scale
+            g_p = p.grad
+            if g_p is None:
+                continue
+            elif tuple(g_p.shape) != tuple(self.state[k][0].shape):
+                self.reset(k)
+            m_tp, v_tp = self.state[k]
+            m_t = self.beta_1 * m_tp + (1 - self.beta_1) * g_p
+            v_t = self.beta_2 * v_tp + (1 - self.beta_2) * g_p * g_p
             if self.mask_updates:
-                nz = g != 0
-                m_t = torch.where(nz, m_t, m_tp); v_t = torch.where(nz, v_t, v_tp)
+                nonzero = g_p != 0
+                m_t = torch.where(nonzero, m_t, m_tp); v_t = torch.where(nonzero, v_t, v_tp)
             self.state[k] = (m_t, v_t)
-            denom = (torch.sqrt(v_t.max()) if self.uniform else torch.sqrt(v_t)) + self.epsilon
-            step = lr_t * m_t / denom
+            if self.uniform:
+                step = lr_t * m_t / (torch.sqrt(v_t.max()) + self.epsilon)
+            else:
+                step = lr_t * m_t / (torch.sqrt(v_t) + self.epsilon)
             if self.mask_updates:
-                step = torch.where(nz, step, torch.zeros_like(step))
+                step = torch.where(nonzero, step, torch.zeros_like(step))
             self.variables[k] = (p.detach() - step).requires_grad_(True)
+
+    def reset(self, key):
+        import torch
+        z = torch.zeros_like(self.variables[key].detach())
+        self.state[key] = (z, z.clone())
+        self.t[key] = 0

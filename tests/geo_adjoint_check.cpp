@@ -108,7 +108,8 @@ static void test_transport(int lobe, bool conn, bool cont, bool inside) {
     vx.d = unit(mk<F>(0.2, -0.15, inside ? 1.0 : -1.0)); vx.T = mk<F>(0.8, 1.1, 0.6);
     if (inside) { s.ng = -s.ng; }                                          // a ray leaving the glass through a surface whose geometric normal is flipped too
     vx.lobe = lobe; vx.l = unit(mk<F>(0.3, -0.2, 0.9));
-    vx.W = mk<F>(0.9, 0.7, 0.8); vx.dW = lobe == LOBE_REFLECT ? mk<F>(0.2, -0.1, 0.3) : mk<F>(0, 0, 0);
+    vx.W = mk<F>(0.9, 0.7, 0.8); vx.dW = lobe != LOBE_FRAME ? mk<F>(0.2, -0.1, 0.3) : mk<F>(0, 0, 0);
+    vx.dWe = lobe != LOBE_FRAME ? mk<F>(-0.15, 0.25, 0.1) : mk<F>(0, 0, 0);
     vx.rel_eta = 1.5; vx.mag = 1e-4; vx.rr = 1.25; vx.cont = cont; vx.conn = conn;
     vx.refl = mk<F>(0.5, 0.6, 0.7); vx.K = 0.01;
     const V3d A = rv(-1, 1), B = rv(-0.2, 0.2), Cc = rv(-0.2, 0.2);         // model image adjoint: G(px, py) = A + B px + C py
@@ -118,7 +119,7 @@ static void test_transport(int lobe, bool conn, bool cont, bool inside) {
     auto phi = [&](const std::vector<double> &y) {
         size_t k = 0; Shade<F> ss; ss.p = get(y, k); ss.ng = get(y, k); ss.ns = get(y, k); ss.sh_s = get(y, k); ss.sh_t = get(y, k);
         Vertex<F> v2 = vx; v2.d = get(y, k); v2.T = get(y, k); v2.rel_eta = y[k];
-        if (lobe == LOBE_REFLECT) v2.W = vx.W + vx.dW * (-dot(v2.d, ss.ns) - wiz0);   // W(cos theta_i), linearised around the primal
+        if (lobe != LOBE_FRAME) v2.W = vx.W + vx.dW * (-dot(v2.d, ss.ns) - wiz0) + vx.dWe * (v2.rel_eta - vx.rel_eta);   // W(cos theta_i, eta), linearised around the primal
         double px = 0, py = 0; if (conn) film_position(se, ss.p, px, py);
         v2.Gv = A + B * px + Cc * py;
         TransportOut<F> o = transport_forward(ss, v2, se);
@@ -154,7 +155,24 @@ static void test_face_normals() {
     if (!(e < 1e-10)) g_fail = 1;
 }
 
+static void test_fresnel() {
+    for (int inside = 0; inside < 2; ++inside) {
+        const double c0 = inside ? -0.83 : 0.62, e0 = 1.52;
+        double r, dc, de; fresnel_partials(c0, e0, r, dc, de);
+        auto fr = [](double c, double e) { double r_, a_, b_; fresnel_partials(c, e, r_, a_, b_); return r_; };
+        const double h = 1e-6, fc = (fr(c0 + h, e0) - fr(c0 - h, e0)) / (2 * h), fe = (fr(c0, e0 + h) - fr(c0, e0 - h)) / (2 * h);
+        const double err = std::max(fabs(fc - dc), fabs(fe - de)) / std::max(fabs(dc), fabs(de));
+        // the value against the closed form for this angle: Fresnel equations for unpolarised light
+        const double n1 = inside ? e0 : 1.0, n2 = inside ? 1.0 : e0, ci = fabs(c0), st = n1 / n2 * sqrt(1 - ci * ci), ct = sqrt(1 - st * st);
+        const double rs = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct), rp = (n1 * ct - n2 * ci) / (n1 * ct + n2 * ci), ref = 0.5 * (rs * rs + rp * rp);
+        printf("%-44s r = %.9f (closed form %.9f), partials vs fd: %.3e %s\n", inside ? "fresnel_partials (from inside)" : "fresnel_partials (from outside)", r, ref, err,
+               (err < 1e-6 && fabs(r - ref) < 1e-12) ? "ok" : "FAIL");
+        if (!(err < 1e-6 && fabs(r - ref) < 1e-12)) g_fail = 1;
+    }
+}
+
 int main() {
+    test_fresnel();
     for (int nrm = 0; nrm < 2; ++nrm) for (int flip = 0; flip < 2; ++flip) for (int uv = 0; uv < 2; ++uv) test_mesh_hit(nrm, flip, uv);
     test_plane_sphere();
     for (int lobe = 0; lobe < 3; ++lobe) for (int conn = 0; conn < 2; ++conn) for (int cont = 0; cont < 2; ++cont) test_transport(lobe, conn, cont, false);

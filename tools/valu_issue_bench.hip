@@ -3,9 +3,12 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -o valu_issue_bench tools/valu_issue_bench.hip && ./valu_issue_bench > profiles/r02_valu_issue.json
 //
-// Every wave runs ITERS x 32 independent v_fma_f32 (8 accumulator chains, 4 rounds per trip: a chain's next fma is 8 issues
-// away, well past the 4-cycle dependent latency).  The number of waves per SIMD is pinned through the dynamic LDS size of the
-// 256-thread workgroups (160 KB / k  =>  k workgroups per CU  =>  k waves on each of the 4 SIMDs).  Reported per k:
+// Every wave runs ITERS x 128 independent v_fma_f32 (8 accumulator chains, 16 rounds per trip: a chain's next fma is 8 issues
+// away, well past the 4-cycle dependent latency; the loop's scalar bookkeeping and taken branch are amortised over 128 issues).
+// The number of waves per SIMD is set by the grid: k x (number of CUs) workgroups of 256 threads, which the dispatcher spreads
+// evenly (k workgroups per CU => k waves on each of the 4 SIMDs; the p05 / p95 spread of the per-wave cycle counts shows how even).
+// (A first version pinned the residency through the dynamic LDS size instead; from 3 workgroups per CU on that did not give the
+// intended residency -- the per-wave cycle counts showed two resident workgroups and a second round -- so it was dropped.)  Reported per k:
 //   cyc_per_inst_smemtime   median over waves of (s_memtime delta) / (k * instructions of one wave): SIMD cycles per instruction
 //   cyc_per_inst_wall       kernel wall time (HIP events) * clock / (k * instructions): the same from outside, clock = the value
 //                           returned by hipDeviceGetAttribute(ClockRate); under load the chip may clock lower (DVFS), which makes
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(256) void k_issue(float *out, int iters, unsigned l
     __builtin_amdgcn_sched_barrier(0);
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 16; ++r) {
             if (OP == 0) {
                 asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -53,14 +56,14 @@ int main() {
     int dev = 0; CHECK(hipSetDevice(dev));
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount, clock_khz = prop.clockRate;
-    const int iters = 1 << 15;                                              // 32768 x 32 = 1 048 576 instructions per wave
-    const double n_inst = (double) iters * 32.0;
+    const int iters = 1 << 13;                                              // 8192 x 128 = 1 048 576 instructions per wave
+    const double n_inst = (double) iters * 128.0;
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"instructions_per_wave\": %.0f, \"results\": [", prop.name, prop.gcnArchName, cus, clock_khz, n_inst);
     bool first = true;
     for (int op = 0; op < 2; ++op)
         for (int k : { 1, 2, 3, 4, 5, 6, 8 }) {
             const int blocks = cus * k;
-            const size_t lds = (size_t) (160 * 1024 / k) - (k == 1 ? 0 : 512);   // k workgroups fill the CU's 160 KB
+            const size_t lds = 0;
             float *out; unsigned long long *cyc;
             CHECK(hipMalloc((void **) &out, (size_t) blocks * 256 * 4)); CHECK(hipMalloc((void **) &cyc, (size_t) blocks * 4 * 8));
             auto kern = op == 0 ? k_issue<0> : k_issue<1>;
