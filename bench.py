@@ -50,14 +50,23 @@ def main():
     ap.add_argument("--no-prb", action="store_true", help="skip the PRB backward leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--prb-plain", action="store_true", help="A/B: PRB leg without the albedo texture (constant reflectances only)")
-    ap.add_argument("--ptracer", action="store_true", help="extra leg: particle tracer (ptracer) on the Cornell box, 512^2 @ 64 spp, box and gaussian filter")
-    ap.add_argument("--veach", action="store_true", help="extra leg: BASELINE configs[3] (Veach-MIS scene, roughconductor + dielectric, 1024^2 @ 512 spp)")
+    ap.add_argument("--ptracer", action="store_true", help="(legs run by default now; kept for old command lines)")
+    ap.add_argument("--veach", action="store_true", help="(legs run by default now; kept for old command lines)")
+    ap.add_argument("--no-veach", action="store_true", help="skip the BASELINE configs[3] leg (Veach-MIS scene, 1024^2 @ 512 spp)")
+    ap.add_argument("--no-ptracer", action="store_true", help="skip the particle tracer leg (Cornell box 512^2 @ 64 spp)")
+    ap.add_argument("--no-lens", action="store_true", help="skip the BASELINE configs[4] leg (lens doublet, ptracer + geometry adjoint)")
+    ap.add_argument("--lens-subdiv", type=int, default=7, help="icosphere level of the lens surface meshes (the notebook uses 7)")
+    ap.add_argument("--only", default="", help="comma-separated legs to run besides the headline one: prb,veach,ptracer,lens,cpu (default: all)")
     ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
     ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
+    if args.only:
+        want = set(args.only.split(","))
+        args.no_prb = args.no_prb or "prb" not in want; args.no_veach = args.no_veach or "veach" not in want
+        args.no_ptracer = args.no_ptracer or "ptracer" not in want; args.no_lens = args.no_lens or "lens" not in want; args.no_cpu = args.no_cpu or "cpu" not in want
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +248,7 @@ def main():
 
     # ---- optional: config C4 (FULL kernels: glossy / specular BSDFs, spheres), tile-sharded like the headline leg ----
     c4 = None
-    if args.veach:
+    if not args.no_veach:
         sc4 = mi.load_dict(mi.veach_mis_scene(1024))
         i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
         tuned4 = i4.tune(sc4, 512)                                    # re-packing or path regeneration, whichever is faster on this scene
@@ -271,7 +280,7 @@ def main():
 
     # ---- optional: particle tracer (forward part) -----------------------------------------------------
     pt = None
-    if args.ptracer:
+    if not args.no_ptracer:
         pt = {}
         for rf in ("box", "gaussian", "gaussian-direct"):          # gaussian: deferred tile-sorted splat (default); -direct: plain atomics
             dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
@@ -304,6 +313,48 @@ def main():
                 pt[rf]["render_forward_design_ms"] = timed(lambda: ip.render_forward_design(scp, shape=cube, vertex_tangent=vt, seed=0, spp=args.prb_spp))
             scp.release()
 
+    # ---- BASELINE configs[4]: the lens doublet of notebooks/doublet_full_optim.ipynb -- ptracer + reverse-mode geometry adjoint -----------
+    lens = None
+    if not args.no_lens and world == 1:
+        ld = mi.lens_design
+        surfs = [{'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 140, 'z0': 48}, {'radial_extent': 8.0, 'K': 0.0, 'c': -1 / 24, 'z0': 49}, {'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 24, 'z0': 52}]
+        mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
+        t0 = time.perf_counter()
+        system = ld.LensSystem([ld.EvenAsphericSurface(**sf) for sf in surfs], mats, subdiv_levels=args.lens_subdiv); system.disable_all_materials()
+        prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, init_camera_z=0.1, fov=100.0).prepare()
+        build_s = time.perf_counter() - t0
+        scl, pl = prob.scene, prob.params
+        il = scl.integrator(); il.timing = True
+        system.update(pl, prob.optimizer); pl.update()
+        gin_l = torch.ones((128, 128, 3), dtype=torch.float32, device=dev)
+
+        def timed_l(fn, n=3):
+            fn(); torch.cuda.synchronize(dev); il.counters(scl, reset=True); t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev); ms = (time.perf_counter() - t0) / n * 1e3
+            c = il.counters(scl, reset=True)
+            return round(ms, 3), round(c["kernel_ms"] / max(c["kernel_launches"], 1), 3)
+
+        def upd():
+            for e in system.elements:                   # SceneParameters.update of the six meshes: refit + normals on the device
+                for key in (e.lens_key, e.baffle_key):
+                    pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
+            pl.update(); il.render(scl, seed=0, spp=1)
+        r_ms, r_k = timed_l(lambda: il.render(scl, seed=0, spp=256))
+        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True))
+        c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False))
+        u_ms, _ = timed_l(upd)
+        losses = [prob.step(it) for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
+        t0 = time.perf_counter(); losses += [prob.step(it) for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
+        info = scl.info()
+        lens = {"metric": "lens doublet (BASELINE configs[4]): ptracer 128^2, render @256 spp + render_backward @128 spp over all vertices and IORs",
+                "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
+                "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
+                "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
+                "light_paths_per_s_backward": round(128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
+        scl.release()
+
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -335,6 +386,8 @@ def main():
             out["veach"] = c4
         if pt is not None:
             out["ptracer"] = pt
+        if lens is not None:
+            out["lens"] = lens
         print(json.dumps(out), flush=True)
     scene.release()
     if dist is not None:

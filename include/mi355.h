@@ -386,6 +386,10 @@ int mi355_debug_lane_radiance(mi355_scene *scene, const mi355_render_params *p,
 int mi355_debug_ray_intersect(mi355_scene *scene, const float *d_rays, uint32_t n,
                               float *d_hits, void *stream);
 
+/* Diagnostic builds (-DMI_BVH_STATS, tools/bvh_stats.py): traversal work since the last reset -- out[0] rays that entered the BVH,
+   out[1] nodes fetched, out[2] triangles tested, out[3] unused.  All zero in the shipped build. */
+int mi355_debug_bvh_stats(mi355_scene *scene, uint64_t out[4], int reset);
+
 /* Test hook: cap the deferred-splat record queue of the particle tracer at `records` (0 = size it from the launch, the default), so
    that the overflow path -- records beyond the capacity are splatted with direct atomics -- can be exercised on a small scene. */
 int mi355_debug_set_splat_capacity(mi355_scene *scene, uint32_t records);

@@ -41,7 +41,7 @@ struct DShape {                      // 176 B, read through the scalar cache
     float frame_s[3], frame_t[3], frame_n[3]; float inv_area;   // rectangle.cpp:115-126
     uint32_t tri_offset, tri_count;  // into DScene::tris / faces (mesh)
     uint32_t vtx_offset;             // into positions/normals/texcoords
-    int32_t  bvh_root;               // -1: scan the triangles linearly
+    int32_t  bvh_root;               // >= 0: the mesh's triangles are in the scene BVH; -1: flattened into DScene::prims / boxes
     float bbox_min[3], bbox_max[3];
     uint32_t cdf_offset;             // mesh: into DScene::area_cdf (inclusive prefix sums of the face areas, ORIGINAL face order)
     uint32_t grad_offset;            // mesh: offset of its MI355_PARAM_VERTEX_POSITIONS block in the gradient buffer (0xffffffff: none)
@@ -72,10 +72,13 @@ struct DPrimFin {    // (b1, b2) = A (s, t) + c for each of the two triangles of
     uint32_t tri_a, tri_b;      // ORIGINAL face ids (the reference's prim_index)
     float a[6], b[6];
 };
-struct DBvhNode {                                          // binary BVH over one mesh's triangles
-    float lo[3]; uint32_t left;                            // inner: children = left, left+1; leaf: first triangle
-    float hi[3]; uint32_t count;                           // 0 = inner node, else number of triangles
-};
+// ONE 4-wide BVH over the triangles of every mesh that is not flattened (128-byte nodes = eight 16-byte loads per lane and step,
+// half the dependent steps of a binary tree).  Child boxes are SoA ([axis][child]) so that the four slab tests of a lane share their
+// ray operands.  `entry`: 0xffffffff = empty slot; bit 31 clear = index of an inner node; bit 31 set = leaf, bits 29-30 = triangle
+// count - 1, bits 0-28 = first triangle (a slot of DScene::tris, the leaf's triangles are contiguous).
+struct DBvh4 { float lo[3][4]; float hi[3][4]; uint32_t entry[4]; uint32_t pad[4]; };
+#define MI_BVH_EMPTY 0xffffffffu
+#define MI_BVH_LEAF 0x80000000u
 struct DBsdf {                       // 96 B
     uint32_t type; float reflectance[3]; int32_t texture; int32_t grad_slot;
     float alpha_u, alpha_v; uint32_t distribution, sample_visible;      // roughconductor.cpp:163-212
@@ -100,13 +103,14 @@ struct DScene {
     const float    *normals;      // 3 per vertex (zeros when the mesh has none)
     const float    *texcoords;    // 2 per vertex
     const float    *area_cdf;     // meshes: Mesh::build_pmf table (mesh.cpp:430-470), one float per face
-    const DBvhNode *bvh;
+    const DBvh4 *bvh;             // node 0 = root (n_bvh_shapes != 0)
+    const uint32_t *tri_shape;    // traversal slot -> shape index
     const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
     const DPrimFin *fins;
     const DBox     *boxes;        // parallelepiped meshes
     const DSphere  *spheres;
-    uint32_t n_spheres, features; // features: bit 0 = some BSDF is not `diffuse`, bit 1 = analytic spheres present,
-                                  // bit 2 = realisticlens sensor; any bit set -> kernels instantiated with FULL = true
+    uint32_t n_spheres, features; // features: bit 0 = some BSDF is not `diffuse`, bit 1 = analytic spheres present, bit 2 = realisticlens sensor,
+                                  // bit 3 = meshes traversed through the BVH; any bit set -> kernels instantiated with FULL = true
     const uint32_t *bvh_shapes;   // shapes traversed through their BVH
     uint32_t n_prims, n_bvh_shapes, n_boxes;
     const DBsdf    *bsdfs;
@@ -287,7 +291,7 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
     return tn <= tf * 1.00001f + 1e-6f;
 }
 
-#define MI_BVH_STACK 20
+#define MI_BVH_STACK 32
 #ifndef MI_PRIM_UNROLL
 #define MI_PRIM_UNROLL 1
 #endif
@@ -295,46 +299,96 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
 #define MI_STR(x) MI_STR2(x)
 #define MI_UNROLL_PRIMS _Pragma(MI_STR(unroll MI_PRIM_UNROLL))
 #define MI_FLAT_MAX 64      // meshes up to this many triangles are expanded into the flat primitive list
-// Per-lane BVH traversal of one (large) mesh.  The short stack lives in LDS, laid out [level][lane] so that
-// the 64 lanes of a wave touch 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32);
-// `stk` already points at this lane's column.  Node boxes are re-tested on pop against the
-// current ray.maxt, so a closer hit prunes everything behind it.
+// Per-lane traversal of the scene BVH (DBvh4).  The stack lives in LDS, laid out [level][lane] so that the 64 lanes of a wave touch
+// 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32); `stk` already points at this lane's column.  Its depth bounds the
+// tree: a node pushes at most three siblings, the host builds trees of at most MI_BVH_LEVELS levels (build_scene_bvh).
+// Closest hit: the hit children of a node are visited near to far (sorted by entry distance) -- leaves at once, so that a hit shrinks
+// ray.maxt before anything farther is looked at; inner children go on the stack far first.
 #define MI_STK(i) stk[(i) * 64]
-MI_DEV void mesh_closest(const DScene &sc, const DShape &sh, uint32_t shape_index, Ray &ray, v3 inv_d, Hit &hit,
-                         bool active, uint32_t *stk) {
-    int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
+#define MI_BVH_LEVELS 11    // 3 * (MI_BVH_LEVELS - 1) <= MI_BVH_STACK
+// MI_BVH_STATS (diagnostic builds only, tools/bvh_stats.py): traversal steps per ray -- [0] rays that entered the BVH, [1] nodes fetched, [2] triangles tested
+#ifdef MI_BVH_STATS
+static __device__ unsigned long long g_bvh_stats[4];
+#define BVH_STAT(k, n) atomicAdd(&g_bvh_stats[k], (unsigned long long) (n))
+#else
+#define BVH_STAT(k, n)
+#endif
+struct Bvh4Hits { float tn[4]; uint32_t e[4]; };
+// slab test of the four children of `node`; a child that is missed (or empty) gets tn = +inf.  Conservative like box_overlap.
+MI_DEV Bvh4Hits bvh4_node(const DScene &sc, uint32_t node, const Ray &ray, v3 inv_d, float tmax) {
+    const float4 *n4 = reinterpret_cast<const float4 *>(sc.bvh + node);
+    Bvh4Hits h;
+    float tn[4] = { 0.f, 0.f, 0.f, 0.f }, tf[4] = { tmax, tmax, tmax, tmax };
+    {   const float4 lo = n4[0], hi = n4[3]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.x) * inv_d.x, b = (u[c] - ray.o.x) * inv_d.x; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
+    {   const float4 lo = n4[1], hi = n4[4]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.y) * inv_d.y, b = (u[c] - ray.o.y) * inv_d.y; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
+    {   const float4 lo = n4[2], hi = n4[5]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.z) * inv_d.z, b = (u[c] - ray.o.z) * inv_d.z; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
+    const uint4 en = *reinterpret_cast<const uint4 *>(n4 + 6);
+    h.e[0] = en.x; h.e[1] = en.y; h.e[2] = en.z; h.e[3] = en.w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) h.tn[c] = (h.e[c] != MI_BVH_EMPTY && tn[c] <= tf[c] * 1.00001f + 1e-6f) ? tn[c] : MI_INF;
+    return h;
+}
+MI_DEV void bvh4_sort(Bvh4Hits &h) {                                       // near to far: the 5-exchange network for four keys
+#define MI_CSWAP(a, b) { const bool sw = h.tn[b] < h.tn[a]; const float ta = sw ? h.tn[b] : h.tn[a], tb = sw ? h.tn[a] : h.tn[b]; \
+                         const uint32_t ea = sw ? h.e[b] : h.e[a], eb = sw ? h.e[a] : h.e[b]; h.tn[a] = ta; h.tn[b] = tb; h.e[a] = ea; h.e[b] = eb; }
+    MI_CSWAP(0, 1) MI_CSWAP(2, 3) MI_CSWAP(0, 2) MI_CSWAP(1, 3) MI_CSWAP(1, 2)
+#undef MI_CSWAP
+}
+MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
+    int sp = 0; uint32_t node = 0u; bool have = active;
+    if (active) BVH_STAT(0, 1);
     while (have) {
-        DBvhNode nd = sc.bvh[node];
-        bool descend = false;
-        if (box_overlap(nd.lo, nd.hi, ray, inv_d)) {
-            if (nd.count) {
-                for (uint32_t k = 0; k < nd.count; ++k) {
-                    uint32_t f = nd.left + k; float t, u, v;
-                    if (tri_intersect(sc.tris[sh.tri_offset + f], ray, t, u, v) && t < hit.t) {
-                        hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[sh.tri_offset + f]; hit.shape = shape_index; ray.maxt = t;
+        Bvh4Hits h = bvh4_node(sc, node, ray, inv_d, ray.maxt);
+        BVH_STAT(1, 1);
+        bvh4_sort(h);
+        uint32_t next = MI_BVH_EMPTY;
+#pragma unroll
+        for (int c = 3; c >= 0; --c)                                       // far -> near: the nearest inner child ends up in `next`, the others on the stack
+            if (h.tn[c] != MI_INF && !(h.e[c] & MI_BVH_LEAF)) { if (next != MI_BVH_EMPTY && sp < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)                                        // near -> far: leaves are intersected at once
+            if (h.tn[c] <= ray.maxt && (h.e[c] & MI_BVH_LEAF)) {
+                const uint32_t first = h.e[c] & 0x1fffffffu, count = ((h.e[c] >> 29) & 3u) + 1u;
+                BVH_STAT(2, count);
+                for (uint32_t k = 0; k < count; ++k) {
+                    float t, u, v;
+                    if (tri_intersect(sc.tris[first + k], ray, t, u, v) && t < hit.t) {
+                        hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[first + k]; hit.shape = sc.tri_shape[first + k]; ray.maxt = t;
                     }
                 }
-            } else if (sp < MI_BVH_STACK) { MI_STK(sp) = nd.left + 1; sp++; node = nd.left; descend = true; }
-        }
-        if (!descend) { if (sp > 0) { --sp; node = MI_STK(sp); } else have = false; }
+            }
+        if (next != MI_BVH_EMPTY) node = next;
+        else if (sp > 0) { --sp; node = MI_STK(sp); }
+        else have = false;
     }
 }
-MI_DEV bool mesh_any(const DScene &sc, const DShape &sh, const Ray &ray, v3 inv_d, bool active, uint32_t *stk) {
+MI_DEV bool bvh_any(const DScene &sc, const Ray &ray, v3 inv_d, bool active, uint32_t *stk) {
     bool occluded = false;
-    int sp = 0; uint32_t node = (uint32_t) sh.bvh_root; bool have = active;
+    int sp = 0; uint32_t node = 0u; bool have = active;
+    if (active) BVH_STAT(0, 1);
     while (have) {
-        DBvhNode nd = sc.bvh[node];
-        bool descend = false;
-        if (box_overlap(nd.lo, nd.hi, ray, inv_d)) {
-            if (nd.count) {
-                for (uint32_t k = 0; k < nd.count; ++k) {
-                    float t, u, v;
-                    if (tri_intersect(sc.tris[sh.tri_offset + nd.left + k], ray, t, u, v)) occluded = true;
-                }
-                if (occluded) break;
-            } else if (sp < MI_BVH_STACK) { MI_STK(sp) = nd.left + 1; sp++; node = nd.left; descend = true; }
+        const Bvh4Hits h = bvh4_node(sc, node, ray, inv_d, ray.maxt);
+        BVH_STAT(1, 1);
+        uint32_t next = MI_BVH_EMPTY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (h.tn[c] == MI_INF) continue;
+            if (h.e[c] & MI_BVH_LEAF) {
+                const uint32_t first = h.e[c] & 0x1fffffffu, count = ((h.e[c] >> 29) & 3u) + 1u;
+                BVH_STAT(2, count);
+                for (uint32_t k = 0; k < count; ++k) { float t, u, v; if (tri_intersect(sc.tris[first + k], ray, t, u, v)) occluded = true; }
+            } else { if (next != MI_BVH_EMPTY && sp < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
         }
-        if (!descend) { if (sp > 0) { --sp; node = MI_STK(sp); } else have = false; }
+        if (occluded) break;
+        if (next != MI_BVH_EMPTY) node = next;
+        else if (sp > 0) { --sp; node = MI_STK(sp); }
+        else have = false;
     }
     return occluded;
 }
@@ -481,12 +535,9 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
             hit.u = b1; hit.v = b2;
         }
     }
-    if (sc.n_bvh_shapes) {
+    if (FULL && sc.n_bvh_shapes) {                                          // (a scene with BVH meshes runs the FULL kernels: features bit 3)
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
-        for (uint32_t i = 0; i < sc.n_bvh_shapes; ++i) {
-            uint32_t si = sc.bvh_shapes[i];
-            mesh_closest(sc, sc.shapes[si], si, ray, inv_d, hit, active, stk);
-        }
+        bvh_closest(sc, ray, inv_d, hit, active, stk);
     }
     return hit;
 }
@@ -513,10 +564,9 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
         float t;
         if (sphere_intersect(spheres + k, ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
-    if (sc.n_bvh_shapes) {
+    if (FULL && sc.n_bvh_shapes) {
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
-        for (uint32_t i = 0; i < sc.n_bvh_shapes; ++i)
-            occluded = mesh_any(sc, sc.shapes[sc.bvh_shapes[i]], ray, inv_d, active && !occluded, stk) || occluded;
+        occluded = bvh_any(sc, ray, inv_d, active && !occluded, stk) || occluded;
     }
     return occluded;
 }

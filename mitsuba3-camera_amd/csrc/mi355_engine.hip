@@ -56,7 +56,12 @@
 #define GRAD_QUEUE 496                      // texture-gradient records per workgroup (16 KB, 2 per lane); overflow -> direct atomics
 // one LDS region per workgroup, reused in turn by: BVH traversal stacks | compaction state exchange | film splat staging
 #define CMAX(a, b) ((a) > (b) ? (a) : (b))
-#define REGION_FLOATS CMAX(CMAX(WAVES * WAVE_FLOATS, WAVES * STACK_WORDS), CSTATE_WORDS * BLOCK)
+// (only the FULL kernels traverse a BVH -- scenes with BVH meshes set features bit 3 -- so only they reserve the traversal stack:
+// the all-diffuse flat-primitive kernels keep their 27 KB and five workgroups per CU)
+#define REGION_BASIC CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS * BLOCK)
+#define REGION_FLOATS(FULL) ((FULL) ? CMAX(REGION_BASIC, WAVES * STACK_WORDS) : REGION_BASIC)
+#define STACK_FLOATS(FULL) ((FULL) ? WAVES * STACK_WORDS : 64)
+#define STK_PTR(base, FULL, wave, lane_id) (reinterpret_cast<uint32_t *>(base) + ((FULL) ? (wave) * STACK_WORDS + (lane_id) : 0u))
 
 struct RenderArgs {
     uint32_t seed, spp_total, max_depth, rr_depth, flags;
@@ -163,12 +168,12 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
 template <int INTEGRATOR, int OUT, bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
-    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li;
     if (OUT == OUT_LANES) {   // lanes of the whole job, no sharding
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
 // Waves run independent trip counts: no workgroup barrier inside the loop, only wave-scope fences.
 // ---------------------------------------------------------------------------------------------------------------
 #define RING 128                            // records per wave: 63 waiting + 64 new at most
-#define RG_WAVE_WORDS CMAX(STACK_WORDS, WAVE_FLOATS)   // per wave and private: BVH stack | splat staging (never live together)
+#define RG_WAVE_WORDS(FULL) ((FULL) ? CMAX(STACK_WORDS, WAVE_FLOATS) : WAVE_FLOATS)   // per wave and private: BVH stack | splat staging (never live together)
 MI_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -283,13 +288,13 @@ MI_DEV void ring_flush(const DScene &sc, float *stage, const float *ring, uint32
 
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS];
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS(FULL)];
     __shared__ float s_ring[WAVES * 5 * RING];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t lane_id = threadIdx.x & 63;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    float *stage = smem + wave * RG_WAVE_WORDS;
+    float *stage = smem + wave * RG_WAVE_WORDS(FULL);
     uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + lane_id;
     float *ring = s_ring + wave * 5 * RING;
     // pool of this wave: shard pixels [q, q_end), all s_count samples of each
@@ -361,14 +366,14 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen
 // ---------------------------------------------------------------------------------------------------------------
 template <int INTEGRATOR, bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
-    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];         // BVH stack | compaction state | splat staging
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_wcnt[2 * WAVES];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_id = tid & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     uint32_t i = blockIdx.x * BLOCK + tid;
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
@@ -487,12 +492,12 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_render_forward(DScene sc, RenderArgs a, const float *tangent, const uint32_t *small_map,
                                                                                       float *film, unsigned long long *g_counters) {
-    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters, const uint32_t *redo) {
     if (redo && !redo[blockIdx.x]) return;                                  // second launch: only the workgroups the one-pass kernel gave up on
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     __shared__ float s_grad[MAX_SMALL_GRAD];
     __shared__ float s_q[GRAD_QUEUE * 8];
     __shared__ uint32_t s_qn;
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) s_grad[k] = 0.f;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + wave * STACK_WORDS) + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
@@ -767,7 +772,7 @@ template <bool FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     extern __shared__ float s_grad_dyn[];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
     const PtGradSink sink = { grad_rgb, s_grad_dyn, copy_shift, d_grad, small_map, all_params != 0u };
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < a.n_local;
     const uint32_t ii = on ? i : 0u;
@@ -806,9 +811,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
 // and sampler streams of k_ptracer, dual numbers alongside; the derivative film is accumulated with plain float atomics.
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < a.n_local;
     const uint32_t ii = on ? i : 0u;
@@ -970,12 +975,12 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
                                                                GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds) {
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     extern __shared__ float s_ior_dyn[];
     for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) s_ior_dyn[k] = 0.f;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem) + wave * STACK_WORDS + lane_id;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;                    // slot on the tape
     const uint32_t i = lane_first + t;
     const bool on = t < n_chunk && i < a.n_local;
@@ -1027,36 +1032,42 @@ __global__ __launch_bounds__(256) void k_vertex_normals_bwd(const float *positio
         atomicAdd(g, av[c].x); atomicAdd(g + 1, av[c].y); atomicAdd(g + 2, av[c].z);
     }
 }
-// Scene::parameters_changed for one mesh traversed through a BVH: triangles in traversal order from the new positions ...
-__global__ __launch_bounds__(256) void k_mesh_tris(const float *positions, const uint32_t *faces, const uint32_t *tri_face, uint32_t vtx_offset, uint32_t tri_offset,
-                                                   uint32_t n_faces, DTri *tris) {
+// Scene::parameters_changed for the meshes in the scene BVH: every leaf-ordered triangle from the (new) positions ...
+__global__ __launch_bounds__(256) void k_mesh_tris(const float *positions, const uint32_t *faces, const uint32_t *tri_face, const uint32_t *tri_shape, const DShape *shapes,
+                                                   uint32_t n, DTri *tris) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= n_faces) return;
-    const uint32_t *fi = faces + 3 * (size_t) (tri_offset + tri_face[tri_offset + k]);
-    const v3 a = ld3(positions + 3 * (size_t) (vtx_offset + fi[0])), b = ld3(positions + 3 * (size_t) (vtx_offset + fi[1])), c = ld3(positions + 3 * (size_t) (vtx_offset + fi[2]));
+    if (k >= n) return;
+    const DShape &sh = shapes[tri_shape[k]];
+    const uint32_t *fi = faces + 3 * (size_t) (sh.tri_offset + tri_face[k]);
+    const v3 a = ld3(positions + 3 * (size_t) (sh.vtx_offset + fi[0])), b = ld3(positions + 3 * (size_t) (sh.vtx_offset + fi[1])), c = ld3(positions + 3 * (size_t) (sh.vtx_offset + fi[2]));
     DTri t; t.p0[0] = a.x; t.p0[1] = a.y; t.p0[2] = a.z; t.e1[0] = b.x - a.x; t.e1[1] = b.y - a.y; t.e1[2] = b.z - a.z; t.e2[0] = c.x - a.x; t.e2[1] = c.y - a.y; t.e2[2] = c.z - a.z;
-    tris[tri_offset + k] = t;
+    tris[k] = t;
 }
-// ... and the node boxes refitted bottom-up, one launch per tree level (deepest first); topology and leaf contents are kept.
-__global__ __launch_bounds__(256) void k_bvh_refit_level(DBvhNode *nodes, const uint2 *level_nodes, uint32_t n, const DTri *tris) {
+// ... and the child boxes refitted bottom-up, one launch per tree level (deepest first); topology and leaf contents are kept.
+__global__ __launch_bounds__(256) void k_bvh_refit_level(DBvh4 *nodes, const uint32_t *level_nodes, uint32_t n, const DTri *tris) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint32_t node = level_nodes[i].x, tri_offset = level_nodes[i].y;
-    DBvhNode nd = nodes[node];
-    float lo[3] = { MI_INF, MI_INF, MI_INF }, hi[3] = { -MI_INF, -MI_INF, -MI_INF };
-    if (nd.count) {
-        for (uint32_t k = 0; k < nd.count; ++k) {
-            const DTri t = tris[tri_offset + nd.left + k];
-            for (int c = 0; c < 3; ++c) {
-                const float a = t.p0[c], b = t.p0[c] + t.e1[c], d = t.p0[c] + t.e2[c];
-                lo[c] = fminf(lo[c], fminf(a, fminf(b, d))); hi[c] = fmaxf(hi[c], fmaxf(a, fmaxf(b, d)));
+    const uint32_t node = level_nodes[i];
+    DBvh4 nd = nodes[node];
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t e = nd.entry[c];
+        float lo[3] = { MI_INF, MI_INF, MI_INF }, hi[3] = { -MI_INF, -MI_INF, -MI_INF };
+        if (e == MI_BVH_EMPTY) { for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.f; }
+        else if (e & MI_BVH_LEAF) {
+            const uint32_t first = e & 0x1fffffffu, count = ((e >> 29) & 3u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const DTri t = tris[first + k];
+                for (int a = 0; a < 3; ++a) {
+                    const float p = t.p0[a], q = t.p0[a] + t.e1[a], r = t.p0[a] + t.e2[a];
+                    lo[a] = fminf(lo[a], fminf(p, fminf(q, r))); hi[a] = fmaxf(hi[a], fmaxf(p, fmaxf(q, r)));
+                }
             }
+        } else {
+            const DBvh4 ch = nodes[e];                                      // (a deeper level: refitted by an earlier launch)
+            for (int k = 0; k < 4; ++k) if (ch.entry[k] != MI_BVH_EMPTY) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], ch.lo[a][k]); hi[a] = fmaxf(hi[a], ch.hi[a][k]); }
         }
-    } else {
-        const DBvhNode l = nodes[nd.left], r = nodes[nd.left + 1];
-        for (int c = 0; c < 3; ++c) { lo[c] = fminf(l.lo[c], r.lo[c]); hi[c] = fmaxf(l.hi[c], r.hi[c]); }
+        for (int a = 0; a < 3; ++a) { nodes[node].lo[a][c] = lo[a]; nodes[node].hi[a][c] = hi[a]; }
     }
-    for (int c = 0; c < 3; ++c) { nodes[node].lo[c] = lo[c]; nodes[node].hi[c] = hi[c]; }
 }
 
 // HDRFilm::develop, hdrfilm.cpp:304-409
@@ -1070,7 +1081,7 @@ __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
 
 __global__ __launch_bounds__(BLOCK) void k_debug_intersect(DScene sc, const float *rays, uint32_t n, float *hits) {
     __shared__ uint32_t smem[WAVES * STACK_WORDS];
-    uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);
+    uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);   // (this kernel is the FULL variant)
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x; bool act = i < n; uint32_t ii = act ? i : 0;
     Ray r; r.o = ld3(rays + 8 * (size_t) ii); r.d = ld3(rays + 8 * (size_t) ii + 3); r.maxt = rays[8 * (size_t) ii + 6];
     Hit h = scene_intersect<true>(sc, r, act, stk);
@@ -1176,20 +1187,21 @@ struct mi355_scene {
     // geometry updates (MI355_PARAM_VERTEX_POSITIONS): what Mesh::parameters_changed / Scene::parameters_changed need
     std::vector<uint32_t> vcount;                                           // per shape: vertex count (meshes)
     std::vector<uint32_t> vadj_off, vadj;                                   // CSR over ALL mesh vertices: incident (local face * 4 + corner), ascending faces
-    std::vector<uint2> bvh_levels; std::vector<uint32_t> bvh_level_off;     // BVH nodes (node, owning shape's tri_offset) grouped by depth, root level first
+    std::vector<uint32_t> bvh_levels, bvh_level_off;                        // BVH nodes grouped by depth, root level first (refit runs deepest level first)
+    std::vector<uint32_t> tri_shape; uint32_t *d_tri_shape = nullptr; uint64_t n_faces_total = 0;
     std::vector<char> dirty; bool geom_dirty = false;                       // per shape: positions changed since the last refit
-    uint32_t *d_vadj_off = nullptr, *d_vadj = nullptr; float *d_nrm_len = nullptr, *d_nrm_adj = nullptr; uint2 *d_bvh_levels = nullptr;
+    uint32_t *d_vadj_off = nullptr, *d_vadj = nullptr; float *d_nrm_len = nullptr, *d_nrm_adj = nullptr; uint32_t *d_bvh_levels = nullptr;
     float *d_tape = nullptr; size_t tape_floats = 0;                        // path tape of the geometry adjoint
     float *d_ntan = nullptr; size_t ntan_floats = 0;                        // forward design mode: tangent of the vertex normals
     size_t cap_prims = 0, cap_fins = 0, cap_boxes = 0;                      // device capacities of the flat tables (they are rebuilt when a small mesh moves)
-    std::vector<DBvhNode> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
+    std::vector<DBvh4> bvh; std::vector<DBsdf> bsdfs; std::vector<DEmitter> emitters; std::vector<DTexture> textures;
     std::vector<float> texdata;
     std::vector<mi355_param_info> layout; uint64_t grad_total = 0;
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
     DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_pupil = nullptr; float *d_area_cdf = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
-          *d_texcoords = nullptr; DBvhNode *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
+          *d_texcoords = nullptr; DBvh4 *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
     uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
@@ -1209,28 +1221,123 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     return MI355_OK;
 }
 
-// binary BVH, median split along the longest centroid axis, leaves of <= 4 triangles
-struct BuildTri { float lo[3], hi[3], c[3]; uint32_t face; };
-static void bvh_build(std::vector<DBvhNode> &nodes, std::vector<BuildTri> &bt, uint32_t node, uint32_t begin, uint32_t end) {
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+// ---- scene BVH: ONE tree over the triangles of every mesh that is not flattened --------------------------------------------------------
+// Binary tree by binned SAH (16 bins on each axis, leaves of <= 4 triangles), depth-limited so that the collapsed tree has at most
+// MI_BVH_LEVELS levels: where the budget gets tight the split falls back to the object median, which halves the count.  Two binary
+// levels collapse into one DBvh4 node.  Topology is fixed after the build; `vertex_positions` updates refit the boxes on the device.
+struct BuildRef { float lo[3], hi[3], c[3]; uint32_t shape, face; };
+struct BinNode { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };
+static inline float box_area(const float *lo, const float *hi) { float d[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] }; return d[0] < 0.f ? 0.f : 2.f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
+static int32_t bin_build(std::vector<BinNode> &nodes, std::vector<BuildRef> &r, uint32_t begin, uint32_t end, int depth, int max_depth) {
+    const int32_t id = (int32_t) nodes.size(); nodes.push_back(BinNode());
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (uint32_t i = begin; i < end; ++i) for (int k = 0; k < 3; ++k) {
-        lo[k] = std::min(lo[k], bt[i].lo[k]); hi[k] = std::max(hi[k], bt[i].hi[k]);
-        clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]);
+        lo[k] = std::min(lo[k], r[i].lo[k]); hi[k] = std::max(hi[k], r[i].hi[k]); clo[k] = std::min(clo[k], r[i].c[k]); chi[k] = std::max(chi[k], r[i].c[k]);
     }
-    for (int k = 0; k < 3; ++k) { nodes[node].lo[k] = lo[k]; nodes[node].hi[k] = hi[k]; }
-    uint32_t n = end - begin;
-    if (n <= 4) { nodes[node].left = begin; nodes[node].count = n; return; }
-    int axis = 0; float ext = chi[0] - clo[0];
-    for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
-    uint32_t mid = begin + n / 2;
-    std::nth_element(bt.begin() + begin, bt.begin() + mid, bt.begin() + end,
-                     [axis](const BuildTri &a, const BuildTri &b) { return a.c[axis] < b.c[axis]; });
-    uint32_t left = (uint32_t) nodes.size();
-    nodes.push_back(DBvhNode()); nodes.push_back(DBvhNode());
-    nodes[node].left = left; nodes[node].count = 0;
-    bvh_build(nodes, bt, left, begin, mid);
-    bvh_build(nodes, bt, left + 1, mid, end);
+    for (int k = 0; k < 3; ++k) { nodes[id].lo[k] = lo[k]; nodes[id].hi[k] = hi[k]; }
+    const uint32_t n = end - begin;
+    nodes[id].left = nodes[id].right = -1; nodes[id].first = begin; nodes[id].count = n;
+    if (n <= 4) return id;
+    // levels still available below this node vs. levels a balanced split of n needs: ceil(log2(ceil(n / 4)))
+    int need = 0; for (uint32_t m = (n + 3) / 4; m > 1; m = (m + 1) / 2) ++need;
+    const bool tight = depth + need >= max_depth;
+    uint32_t mid = begin + n / 2; int axis = 0; bool sah_ok = false;
+    if (!tight) {
+        const int NB = 16; float best = INFINITY; int best_axis = -1, best_bin = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            const float ext = chi[ax] - clo[ax]; if (!(ext > 0.f)) continue;
+            float blo[NB][3], bhi[NB][3]; uint32_t cnt[NB];
+            for (int b = 0; b < NB; ++b) { cnt[b] = 0; for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; } }
+            const float sc = (float) NB / ext;
+            for (uint32_t i = begin; i < end; ++i) {
+                int b = std::min(NB - 1, std::max(0, (int) ((r[i].c[ax] - clo[ax]) * sc)));
+                cnt[b]++; for (int k = 0; k < 3; ++k) { blo[b][k] = std::min(blo[b][k], r[i].lo[k]); bhi[b][k] = std::max(bhi[b][k], r[i].hi[k]); }
+            }
+            float rarea[NB]; uint32_t rcnt[NB]; float al[3] = { INFINITY, INFINITY, INFINITY }, ah[3] = { -INFINITY, -INFINITY, -INFINITY }; uint32_t c = 0;
+            for (int b = NB - 1; b > 0; --b) { for (int k = 0; k < 3; ++k) { al[k] = std::min(al[k], blo[b][k]); ah[k] = std::max(ah[k], bhi[b][k]); } c += cnt[b]; rarea[b] = box_area(al, ah); rcnt[b] = c; }
+            for (int k = 0; k < 3; ++k) { al[k] = INFINITY; ah[k] = -INFINITY; } c = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                for (int k = 0; k < 3; ++k) { al[k] = std::min(al[k], blo[b][k]); ah[k] = std::max(ah[k], bhi[b][k]); } c += cnt[b];
+                if (c == 0 || rcnt[b + 1] == 0) continue;
+                const float cost = box_area(al, ah) * (float) ((c + 3) / 4) + rarea[b + 1] * (float) ((rcnt[b + 1] + 3) / 4);
+                if (cost < best) { best = cost; best_axis = ax; best_bin = b; }
+            }
+        }
+        if (best_axis >= 0) {
+            const float ext = chi[best_axis] - clo[best_axis], sc = 16.f / ext, c0 = clo[best_axis]; const int ax = best_axis, bb = best_bin;
+            auto it = std::partition(r.begin() + begin, r.begin() + end, [=](const BuildRef &a) { return std::min(15, std::max(0, (int) ((a.c[ax] - c0) * sc))) <= bb; });
+            const uint32_t m = (uint32_t) (it - r.begin());
+            // a lopsided split must still leave both sides shallow enough
+            auto fits = [&](uint32_t cnt_) { int nd = 0; for (uint32_t q = (cnt_ + 3) / 4; q > 1; q = (q + 1) / 2) ++nd; return depth + 1 + nd <= max_depth; };
+            if (m > begin && m < end && fits(m - begin) && fits(end - m)) { mid = m; sah_ok = true; }
+        }
+    }
+    if (!sah_ok) {
+        float ext = chi[0] - clo[0]; for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
+        mid = begin + n / 2;
+        std::nth_element(r.begin() + begin, r.begin() + mid, r.begin() + end, [axis](const BuildRef &a, const BuildRef &b) { return a.c[axis] < b.c[axis]; });
+    }
+    const int32_t l = bin_build(nodes, r, begin, mid, depth + 1, max_depth), rr = bin_build(nodes, r, mid, end, depth + 1, max_depth);
+    nodes[id].left = l; nodes[id].right = rr;
+    return id;
+}
+static uint32_t bvh4_collapse(const std::vector<BinNode> &bn, int32_t b, std::vector<DBvh4> &out, std::vector<uint32_t> &depth_of, uint32_t depth) {
+    const uint32_t id = (uint32_t) out.size(); out.push_back(DBvh4()); depth_of.push_back(depth);
+    int32_t kids[4]; int nk = 0;
+    const int32_t two[2] = { bn[b].left, bn[b].right };
+    for (int k = 0; k < 2; ++k) {                                           // grandchildren where the child is an inner node
+        const BinNode &c = bn[two[k]];
+        if (c.left >= 0) { kids[nk++] = c.left; kids[nk++] = c.right; } else kids[nk++] = two[k];
+    }
+    DBvh4 nd; memset(&nd, 0, sizeof(nd));
+    for (int k = 0; k < 4; ++k) nd.entry[k] = MI_BVH_EMPTY;
+    for (int k = 0; k < nk; ++k) {
+        const BinNode &c = bn[kids[k]];
+        for (int a = 0; a < 3; ++a) { nd.lo[a][k] = c.lo[a]; nd.hi[a][k] = c.hi[a]; }
+        if (c.left < 0) nd.entry[k] = MI_BVH_LEAF | ((c.count - 1u) << 29) | c.first;
+        else nd.entry[k] = bvh4_collapse(bn, kids[k], out, depth_of, depth + 1);
+    }
+    out[id] = nd;
+    return id;
+}
+// builds s->bvh, s->tris / tri_face / tri_shape (leaf order) and the refit level lists from the host mirrors of the BVH shapes
+static int build_scene_bvh(mi355_scene *s) {
+    s->bvh.clear(); s->tris.clear(); s->tri_face.clear(); s->tri_shape.clear(); s->bvh_levels.clear(); s->bvh_level_off.assign(1, 0u);
+    if (s->bvh_shapes.empty()) return MI355_OK;
+    std::vector<BuildRef> refs;
+    for (uint32_t si : s->bvh_shapes) {
+        const DShape &sh = s->shapes[si];
+        const float *P = s->positions.data() + 3 * (size_t) sh.vtx_offset;
+        for (uint32_t f = 0; f < sh.tri_count; ++f) {
+            const uint32_t *fi = s->faces.data() + 3 * (size_t) (sh.tri_offset + f);
+            BuildRef r; r.shape = si; r.face = f;
+            for (int k = 0; k < 3; ++k) {
+                const float a = P[3 * (size_t) fi[0] + k], b = P[3 * (size_t) fi[1] + k], c = P[3 * (size_t) fi[2] + k];
+                r.lo[k] = std::min(a, std::min(b, c)); r.hi[k] = std::max(a, std::max(b, c)); r.c[k] = (r.lo[k] + r.hi[k]) * .5f;
+            }
+            refs.push_back(r);
+        }
+    }
+    if (refs.size() >= (1u << 29)) return fail(MI355_ERR_UNSUPPORTED, "more than 2^29 triangles in the scene BVH");
+    std::vector<BinNode> bn; bn.reserve(refs.size());
+    const int max_bin_depth = 2 * (MI_BVH_LEVELS - 1) + 1;                  // binary leaves at depth <= this collapse into <= MI_BVH_LEVELS levels of DBvh4 nodes
+    bin_build(bn, refs, 0, (uint32_t) refs.size(), 0, max_bin_depth);
+    std::vector<uint32_t> depth_of;
+    if (bn[0].left < 0) return fail(MI355_ERR_INVALID, "scene BVH over fewer than five triangles");
+    bvh4_collapse(bn, 0, s->bvh, depth_of, 0);
+    uint32_t levels = 0; for (uint32_t d : depth_of) levels = std::max(levels, d + 1);
+    if (levels > MI_BVH_LEVELS) return fail(MI355_ERR_UNSUPPORTED, "scene BVH deeper than the traversal stack allows (MI_BVH_LEVELS): too many triangles for this build");
+    for (const BuildRef &r : refs) {                                        // leaf order; DTri carries p0, e1, e2 (mesh.h:436)
+        const DShape &sh = s->shapes[r.shape];
+        const uint32_t *fi = s->faces.data() + 3 * (size_t) (sh.tri_offset + r.face);
+        const float *P = s->positions.data() + 3 * (size_t) sh.vtx_offset, *a = P + 3 * (size_t) fi[0], *b = P + 3 * (size_t) fi[1], *c = P + 3 * (size_t) fi[2];
+        DTri t; for (int q = 0; q < 3; ++q) { t.p0[q] = a[q]; t.e1[q] = b[q] - a[q]; t.e2[q] = c[q] - a[q]; }
+        s->tris.push_back(t); s->tri_face.push_back(r.face); s->tri_shape.push_back(r.shape);
+    }
+    std::vector<std::vector<uint32_t>> lv(levels);
+    for (uint32_t i = 0; i < depth_of.size(); ++i) lv[depth_of[i]].push_back(i);
+    for (auto &l : lv) { s->bvh_levels.insert(s->bvh_levels.end(), l.begin(), l.end()); s->bvh_level_off.push_back((uint32_t) s->bvh_levels.size()); }
+    return MI355_OK;
 }
 
 // ---- flat primitive list ------------------------------------------------------------------------------
@@ -1468,7 +1575,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             s->prims.push_back(pr);
         } else if (sd.type == MI355_SHAPE_MESH) {
             if (!sd.vertex_positions || !sd.faces || !sd.face_count || !sd.vertex_count) return fail(MI355_ERR_INVALID, "mesh without vertices/faces");
-            o.tri_offset = (uint32_t) s->tris.size(); o.tri_count = sd.face_count; o.vtx_offset = (uint32_t) (s->positions.size() / 3);
+            o.tri_offset = (uint32_t) (s->faces.size() / 3); o.tri_count = sd.face_count; o.vtx_offset = (uint32_t) (s->positions.size() / 3);
             if (sd.vertex_normals) o.flags |= DSHAPE_HAS_NRM;
             if (sd.vertex_texcoords) o.flags |= DSHAPE_HAS_UV;
             s->positions.insert(s->positions.end(), sd.vertex_positions, sd.vertex_positions + 3 * (size_t) sd.vertex_count);
@@ -1476,7 +1583,6 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             else s->normals.insert(s->normals.end(), 3 * (size_t) sd.vertex_count, 0.f);
             if (sd.vertex_texcoords) s->texcoords.insert(s->texcoords.end(), sd.vertex_texcoords, sd.vertex_texcoords + 2 * (size_t) sd.vertex_count);
             else s->texcoords.insert(s->texcoords.end(), 2 * (size_t) sd.vertex_count, 0.f);
-            std::vector<BuildTri> bt(sd.face_count);
             for (int k = 0; k < 3; ++k) { o.bbox_min[k] = INFINITY; o.bbox_max[k] = -INFINITY; }
             float area = 0.f;                                               // Mesh::build_pmf: float prefix sums, surface area = the last one
             o.cdf_offset = (uint32_t) s->area_cdf.size();
@@ -1485,11 +1591,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
                 for (int k = 0; k < 3; ++k) if (fi[k] >= sd.vertex_count) return fail(MI355_ERR_INVALID, "face index out of range");
                 const float *a = sd.vertex_positions + 3 * (size_t) fi[0], *b = sd.vertex_positions + 3 * (size_t) fi[1], *c = sd.vertex_positions + 3 * (size_t) fi[2];
                 for (int k = 0; k < 3; ++k) {
-                    bt[f].lo[k] = std::min(a[k], std::min(b[k], c[k])); bt[f].hi[k] = std::max(a[k], std::max(b[k], c[k]));
-                    bt[f].c[k] = (bt[f].lo[k] + bt[f].hi[k]) * .5f;
-                    o.bbox_min[k] = std::min(o.bbox_min[k], bt[f].lo[k]); o.bbox_max[k] = std::max(o.bbox_max[k], bt[f].hi[k]);
+                    o.bbox_min[k] = std::min(o.bbox_min[k], std::min(a[k], std::min(b[k], c[k]))); o.bbox_max[k] = std::max(o.bbox_max[k], std::max(a[k], std::max(b[k], c[k])));
                 }
-                bt[f].face = f;
                 h3 cr = hcross(hsub(H3(b[0], b[1], b[2]), H3(a[0], a[1], a[2])), hsub(H3(c[0], c[1], c[2]), H3(a[0], a[1], a[2])));
                 area += 0.5f * sqrtf(hdot(cr, cr));
                 s->area_cdf.push_back(area);
@@ -1499,19 +1602,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             size_t fins_before = s->fins.size();
             if (try_make_box(s, i, sd)) { }
             else if (sd.face_count <= MI_FLAT_MAX) { s->fins.resize(fins_before); flatten_mesh(s, i, sd); }
-            else {
-                s->bvh_shapes.push_back(i);
-                uint32_t root = (uint32_t) s->bvh.size(); s->bvh.push_back(DBvhNode());
-                std::vector<DBvhNode> &nodes = s->bvh;
-                bvh_build(nodes, bt, root, 0, sd.face_count);
-                o.bvh_root = (int32_t) root;
-            }
-            for (uint32_t k = 0; k < sd.face_count; ++k) {                  // traversal order; DTri carries p0,e1,e2 (mesh.h:436)
-                uint32_t f = bt[k].face; const uint32_t *fi = sd.faces + 3 * (size_t) f;
-                const float *a = sd.vertex_positions + 3 * (size_t) fi[0], *b = sd.vertex_positions + 3 * (size_t) fi[1], *c = sd.vertex_positions + 3 * (size_t) fi[2];
-                DTri t; for (int q = 0; q < 3; ++q) { t.p0[q] = a[q]; t.e1[q] = b[q] - a[q]; t.e2[q] = c[q] - a[q]; }
-                s->tris.push_back(t); s->tri_face.push_back(f);
-            }
+            else { s->bvh_shapes.push_back(i); o.bvh_root = 0; ds.features |= 8u; }   // its triangles go into the scene BVH (build_scene_bvh, after this loop)
+            s->n_faces_total += sd.face_count;
         } else if (sd.type == MI355_SHAPE_SPHERE) {                         // Sphere::update, sphere.cpp:150-172
             h3 c = H3(o.to_world[3], o.to_world[7], o.to_world[11]);
             h3 ex = hxf_vector(o.to_world, H3(1.f, 0.f, 0.f)); float radius = sqrtf(hdot(ex, ex));
@@ -1584,23 +1676,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             for (uint32_t f = 0; f < sh.tri_count; ++f) for (uint32_t c = 0; c < 3; ++c) s->vadj[cur[sh.vtx_offset + s->faces[3 * (size_t) (sh.tri_offset + f) + c]]++] = f * 4u + c;
         }
     }
-    {   // BVH nodes by depth (refit order) and the depth check of the traversal stack
-        std::vector<std::vector<uint2>> lv;
-        for (uint32_t si : s->bvh_shapes) {
-            const DShape &sh = s->shapes[si];
-            std::vector<std::pair<uint32_t, uint32_t>> todo; todo.push_back({ (uint32_t) sh.bvh_root, 0u });
-            while (!todo.empty()) {
-                auto [node, depth] = todo.back(); todo.pop_back();
-                if (lv.size() <= depth) lv.resize(depth + 1);
-                lv[depth].push_back(make_uint2(node, sh.tri_offset));
-                if (!s->bvh[node].count) { todo.push_back({ s->bvh[node].left, depth + 1 }); todo.push_back({ s->bvh[node].left + 1, depth + 1 }); }
-            }
-        }
-        // the traversal keeps one pending sibling per level below the root: MI_BVH_STACK of them
-        if (lv.size() > (size_t) MI_BVH_STACK + 1) return fail(MI355_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (MI_BVH_STACK): mesh too large for this build");
-        s->bvh_level_off.assign(1, 0u);
-        for (auto &l : lv) { s->bvh_levels.insert(s->bvh_levels.end(), l.begin(), l.end()); s->bvh_level_off.push_back((uint32_t) s->bvh_levels.size()); }
-    }
+    { int rc_bvh = build_scene_bvh(s); if (rc_bvh) return rc_bvh; }       // the scene BVH over the large meshes, its leaf-ordered triangles, the refit lists
     s->dirty.assign(s->shapes.size(), 0);
     if (s->small_map.size() > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant differentiable parameters for the LDS reducer");
     // sensor / film
@@ -1651,6 +1727,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_tris, s->tris))) return rc;
     if ((rc = upload(&s->d_faces, s->faces))) return rc;
     if ((rc = upload(&s->d_tri_face, s->tri_face))) return rc;
+    if ((rc = upload(&s->d_tri_shape, s->tri_shape))) return rc;
     if ((rc = upload(&s->d_positions, s->positions))) return rc;
     if ((rc = upload(&s->d_normals, s->normals))) return rc;
     if ((rc = upload(&s->d_texcoords, s->texcoords))) return rc;
@@ -1702,7 +1779,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     HIP_TRY(hipMalloc((void **) &s->d_gw, (size_t) se.crop_width * se.crop_height * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
-    ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
+    ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.tri_shape = s->d_tri_shape; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
     ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes; ds.boxes = s->d_boxes; ds.n_boxes = (uint32_t) s->boxes.size();
     ds.spheres = s->d_spheres; ds.n_spheres = (uint32_t) s->spheres.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
@@ -1729,7 +1806,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
                      s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf,
                      s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_tile_u32,
-                     s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan };
+                     s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
@@ -1788,15 +1865,10 @@ static int ensure_geometry(mi355_scene *s, hipStream_t st) {
                                (const uint32_t *) s->d_vadj, sh.vtx_offset, sh.tri_offset, nv, s->d_normals, s->d_nrm_len, (const float *) nullptr, (float *) nullptr);
             HIP_TRY(hipGetLastError());
             if (!(sh.flags & DSHAPE_NRM_DEP)) { sh.flags |= DSHAPE_NRM_DEP; shapes_changed = true; }
-            HIP_TRY(hipMemcpyAsync(s->normals.data() + 3 * (size_t) sh.vtx_offset, s->d_normals + 3 * (size_t) sh.vtx_offset, 3 * (size_t) nv * sizeof(float), hipMemcpyDeviceToHost, st));
         }
-        if (sh.bvh_root >= 0) {
-            hipLaunchKernelGGL(k_mesh_tris, dim3((sh.tri_count + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const uint32_t *) s->d_faces, (const uint32_t *) s->d_tri_face,
-                               sh.vtx_offset, sh.tri_offset, sh.tri_count, s->d_tris);
-            HIP_TRY(hipGetLastError());
-            refit = true;
-        } else reflatten = true;
-        {   // recompute_bbox (mesh.cpp:415-428); build_pmf when the mesh is sampled (mesh.cpp:141-142, :430-470): float prefix sums of the face areas
+        if (sh.bvh_root >= 0) refit = true; else reflatten = true;
+        bool sampled = sh.emitter >= 0; for (const DEmitter &e : s->emitters) sampled = sampled || e.shape == i;
+        if (sampled || sh.bvh_root < 0) {   // recompute_bbox (mesh.cpp:415-428); build_pmf when the mesh is sampled (mesh.cpp:141-142, :430-470): float prefix sums of the face areas
             const float *P = s->positions.data() + 3 * (size_t) sh.vtx_offset;
             for (int k = 0; k < 3; ++k) { sh.bbox_min[k] = INFINITY; sh.bbox_max[k] = -INFINITY; }
             for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { sh.bbox_min[k] = std::min(sh.bbox_min[k], P[3 * v + k]); sh.bbox_max[k] = std::max(sh.bbox_max[k], P[3 * v + k]); }
@@ -1808,16 +1880,19 @@ static int ensure_geometry(mi355_scene *s, hipStream_t st) {
                 area += 0.5f * sqrtf(hdot(cr, cr));
                 s->area_cdf[sh.cdf_offset + f] = area;
             }
-            sh.inv_area = 1.f / area; shapes_changed = true; cdf_changed = cdf_changed || sh.emitter >= 0;
-            for (const DEmitter &e : s->emitters) if (e.shape == i) cdf_changed = true;
+            sh.inv_area = 1.f / area; shapes_changed = true; cdf_changed = cdf_changed || sampled;
         }
         s->dirty[i] = 0;
     }
-    if (refit)                                                              // bottom-up, one launch per level
+    if (refit) {                                                            // the leaf-ordered triangles, then the boxes bottom-up, one launch per level
+        const uint32_t nt = (uint32_t) s->tris.size();
+        hipLaunchKernelGGL(k_mesh_tris, dim3((nt + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const uint32_t *) s->d_faces, (const uint32_t *) s->d_tri_face,
+                           (const uint32_t *) s->d_tri_shape, (const DShape *) s->d_shapes, nt, s->d_tris);
         for (size_t l = s->bvh_level_off.size() - 1; l-- > 0;) {
             const uint32_t b = s->bvh_level_off[l], n = s->bvh_level_off[l + 1] - b;
-            if (n) hipLaunchKernelGGL(k_bvh_refit_level, dim3((n + 255u) / 256u), dim3(256), 0, st, s->d_bvh, (const uint2 *) (s->d_bvh_levels + b), n, (const DTri *) s->d_tris);
+            if (n) hipLaunchKernelGGL(k_bvh_refit_level, dim3((n + 255u) / 256u), dim3(256), 0, st, s->d_bvh, (const uint32_t *) (s->d_bvh_levels + b), n, (const DTri *) s->d_tris);
         }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));                                      // the host copies below must not overtake kernels that still read the old tables
     int rc;
@@ -1834,12 +1909,14 @@ static int set_geometry_param(mi355_scene *s, uint32_t kind, uint32_t index, con
         if (count != 3ull * s->vcount[index]) return fail(MI355_ERR_INVALID, "vertex_positions update must keep the vertex count (topology changes need a new scene)");
         const DShape &sh = s->shapes[index];
         float *h = s->positions.data() + 3 * (size_t) sh.vtx_offset, *d = s->d_positions + 3 * (size_t) sh.vtx_offset;
+        // the host mirror is what the flat tables and the emitter tables are rebuilt from; a mesh in the scene BVH that is not sampled
+        // is refitted entirely on the device and needs no host copy (no D2H transfer, no synchronisation)
+        bool need_host = sh.bvh_root < 0 || sh.emitter >= 0; for (const DEmitter &e : s->emitters) need_host = need_host || e.shape == index;
         if (device_src) {
             HIP_TRY(hipMemcpyAsync(d, values, count * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h, values, count * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if (need_host) { HIP_TRY(hipMemcpyAsync(h, values, count * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
         } else { memcpy(h, values, count * 4); HIP_TRY(hipMemcpy(d, values, count * 4, hipMemcpyHostToDevice)); }
-        for (uint64_t k = 0; k < count; ++k) if (!std::isfinite(h[k])) return fail(MI355_ERR_INVALID, "vertex_positions contains a non-finite value");
+        if (need_host || !device_src) for (uint64_t k = 0; k < count; ++k) if (!std::isfinite(h[k])) return fail(MI355_ERR_INVALID, "vertex_positions contains a non-finite value");
         s->dirty[index] = 1; s->geom_dirty = true;
         return MI355_OK;
     }
@@ -2211,7 +2288,7 @@ extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *
         uint32_t copy_shift = 5;                                            // 32 copies (one per LDS bank) while they fit in 8 KB
         while (copy_shift > 0 && (n_small << copy_shift) > 2048u) --copy_shift;
         const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u;
-        const uint32_t lds_budget = (full ? 40960u : 163840u / MI_MIN_WAVES_1P);
+        const uint32_t lds_budget = (full ? 163840u / 3u : 163840u / MI_MIN_WAVES_1P);   // FULL: three workgroups per CU (its launch bounds), 54 KB each
         if (static_lds + small_bytes + 256u + 64u * 16u > lds_budget) return fail(MI355_ERR_UNSUPPORTED, "no LDS left for the gradient record queue");
         uint32_t q_granules = (lds_budget - 256u - static_lds - small_bytes) / 16u;
         const uint32_t dyn_bytes = small_bytes + q_granules * 16u;
@@ -2254,7 +2331,7 @@ extern "C" int mi355_lens_exit_pupil_bounds(const mi355_scene *s, float *out) {
 extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
     if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
     out[0] = (uint32_t) s->prims.size(); out[1] = (uint32_t) s->boxes.size(); out[2] = (uint32_t) s->bvh_shapes.size();
-    out[3] = (uint32_t) s->bvh.size(); out[4] = (uint32_t) s->tris.size(); out[5] = (uint32_t) s->grad_total;
+    out[3] = (uint32_t) s->bvh.size(); out[4] = (uint32_t) s->n_faces_total; out[5] = (uint32_t) s->grad_total;
     out[6] = (uint32_t) s->spheres.size(); out[7] = s->ds.features;
     return MI355_OK;
 }
@@ -2278,6 +2355,19 @@ extern "C" int mi355_debug_lane_radiance(mi355_scene *s, const mi355_render_para
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_LANES, false>), grid, block, 0, st, s->ds, a, nof, d_out, noc);
     }
     HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_debug_bvh_stats(mi355_scene *s, uint64_t out[4], int reset) {
+    if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+#ifdef MI_BVH_STATS
+    HIP_TRY(hipSetDevice(s->device)); HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[4]; HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bvh_stats), sizeof(h)));
+    for (int i = 0; i < 4; ++i) out[i] = h[i];
+    if (reset) { memset(h, 0, sizeof(h)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), h, sizeof(h))); }
+#else
+    (void) reset;
+#endif
     return MI355_OK;
 }
 extern "C" int mi355_debug_set_splat_capacity(mi355_scene *s, uint32_t records) {

@@ -511,15 +511,17 @@ class SceneParameters:
         self._values[key] = v
         self._dirty.add(key)
 
-    def update(self, values=None):
-        torch = _torch()
+    def update(self, values=None, skip=()):
+        """SceneParameters.update (util.py:185-232): push every assigned parameter to the device replica; returns the keys pushed.
+        `skip`: keys the caller pushes itself (mi.render's differentiable parameters)."""
         if values is not None:
             for k, v in values.items():
-                self[k] = v
-        for key in sorted(self._dirty):
+                if k in self._entries:
+                    self[k] = v
+        out = sorted(k for k in self._dirty if k not in skip)
+        for key in out:
             self._push(key, self._values[key])
-        out = sorted(self._dirty)
-        self._dirty.clear()
+        self._dirty.difference_update(out)
         return out
 
     def _push(self, key, tensor):
@@ -540,11 +542,12 @@ class SceneParameters:
             return
         abi.check(abi.lib().mi355_scene_set_param_device(self.scene.handle(), kind, index, C.c_void_p(v.data_ptr()), v.numel(),
                                                           _stream_ptr(v.device)))
-        host = v.cpu().numpy()
         if kind == abi.PARAM_VERTEX_POSITIONS:         # Mesh::parameters_changed: the engine refits and recomputes the normals; the host copy follows lazily
             sh = self.scene.shapes[index]
-            sh.vertex_positions = np.ascontiguousarray(host.reshape(-1, 3).copy()); sh._normals_stale = sh.vertex_normals is not None
-        elif kind == abi.PARAM_BSDF_REFLECTANCE:
+            sh._positions_device = v; sh._normals_stale = sh._vn is not None      # (no download here: the host copies catch up when somebody reads them)
+            return
+        host = v.cpu().numpy()
+        if kind == abi.PARAM_BSDF_REFLECTANCE:
             self.scene.bsdfs[index].reflectance = host.copy()
         elif kind == abi.PARAM_EMITTER_RADIANCE:
             self.scene.emitters[index].radiance = host.copy()
@@ -622,9 +625,9 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     elif seed_grad == seed:
         raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
 
-    if params is not None:
-        params.update()
     diff_keys = [k for k in (params.keys() if params is not None else []) if params[k].requires_grad]
+    if params is not None:
+        params.update(skip=diff_keys)      # (the differentiable ones are pushed by the render op itself, every time: their tensors may be edited in place)
     if not diff_keys:
         return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
 
@@ -632,8 +635,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         @staticmethod
         def forward(ctx, *tensors):
             for k, t in zip(diff_keys, tensors):
-                if params._values[k] is not t or k in params._dirty:          # (params.update() above has pushed everything that was assigned)
-                    params._push(k, t); params._dirty.discard(k)
+                params._push(k, t); params._dirty.discard(k)
             return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
 
         @staticmethod

@@ -138,8 +138,36 @@ class Shape:
         self.bsdf = bsdf
         self.emitter = emitter
         self.flip_normals = flip_normals
-        self.vertex_positions = self.vertex_normals = self.vertex_texcoords = self.faces = None
-        self._normals_stale = False      # vertex_positions were updated: the engine recomputed the normals on the device; desc() catches up lazily
+        self._vp = self._vn = None
+        self._normals_stale = False      # vertex_positions were updated: the engine recomputed the normals on the device; the host copy catches up lazily
+        self._positions_device = None    # ... and the positions themselves still live in a device tensor (SceneParameters._push)
+        self.vertex_texcoords = self.faces = None
+
+    # The host copies of an updated mesh are brought up to date on first use (positions from the device tensor, normals recomputed as
+    # Mesh::parameters_changed does, mesh.cpp:138-139): an optimisation loop that never looks at them never pays for the download.
+    @property
+    def vertex_positions(self):
+        if self._positions_device is not None:
+            self._vp = np.ascontiguousarray(self._positions_device.detach().cpu().numpy().reshape(-1, 3).astype(np.float32)); self._positions_device = None
+        return self._vp
+
+    @vertex_positions.setter
+    def vertex_positions(self, v):
+        self._vp = v; self._positions_device = None
+
+    @property
+    def vertex_normals(self):
+        if self._normals_stale and self._vn is not None:
+            self._vn = compute_vertex_normals(self.vertex_positions, self.faces)
+        self._normals_stale = False
+        return self._vn
+
+    @vertex_normals.setter
+    def vertex_normals(self, v):
+        self._vn = v; self._normals_stale = False
+
+    def sync_host(self):
+        return self.vertex_positions, self.vertex_normals
 
     def primitive_count(self):
         return 1 if self.type != abi.SHAPE_MESH else int(self.faces.shape[0])
@@ -452,12 +480,11 @@ class Scene:
             sh[i].flip_normals = 1 if s.flip_normals else 0
             sh[i].to_world[:] = s.to_world.affine12().tolist(); sh[i].to_object[:] = s.to_world.inverse_affine12().tolist()
             if s.type == abi.SHAPE_MESH:
+                s.sync_host()
                 sh[i].vertex_count = s.vertex_positions.shape[0]; sh[i].face_count = s.faces.shape[0]
                 sh[i].vertex_positions = s.vertex_positions.ctypes.data_as(abi.f32p)
                 sh[i].faces = s.faces.ctypes.data_as(abi.u32p)
                 if s.vertex_normals is not None:
-                    if s._normals_stale:      # Mesh::parameters_changed -> recompute_vertex_normals (mesh.cpp:138-139)
-                        s.vertex_normals = compute_vertex_normals(s.vertex_positions, s.faces); s._normals_stale = False
                     sh[i].vertex_normals = s.vertex_normals.ctypes.data_as(abi.f32p)
                 if s.vertex_texcoords is not None:
                     sh[i].vertex_texcoords = s.vertex_texcoords.ctypes.data_as(abi.f32p)

@@ -71,7 +71,7 @@ def test_box_and_quad_primitives(mi, orc, torch_cuda):
     oracle's per-triangle Moeller-Trumbore, including prim_index and barycentrics (through uv)."""
     T = mi.ScalarTransform4f
     scene = mi.load_dict(small_cbox(mi, 32))
-    assert scene.info() == {"flat_prims": 6, "boxes": 2, "bvh_meshes": 0, "bvh_nodes": 0, "triangles": 24, "grad_floats": 12,
+    assert scene.info() == {"flat_prims": 6, "boxes": 2, "bvh_meshes": 0, "bvh_nodes": 0, "triangles": 24, "grad_floats": 12 + 2 * 24 * 3,
                             "spheres": 0, "features": 0}
     shear = mi.Transform4f([[0.5, 0.2, 0.0, 0.1], [0.0, 0.4, 0.1, -0.2], [0.1, 0.0, 0.3, 0.2], [0, 0, 0, 1]])
     v = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1]], dtype=np.float32)
@@ -357,7 +357,9 @@ def test_veach_render_and_backward(mi, orc, torch_cuda, veach64):
     g = integ.render_backward(veach64, params, torch.tensor(gin), seed=6, spp=16).cpu().numpy()
     g_ref = o.render_backward(o.params(integ, 6, 16), gin)
     lay, total = mi.scene_param_layout(veach64)
-    assert (lay, total) == o.param_layout() and total == 3 + 5 * 3           # grey albedo + 5 emitters; conductors/dielectric carry none
+    colour = [e for e in lay if e[0] in (mi.abi.PARAM_BSDF_REFLECTANCE, mi.abi.PARAM_TEXTURE_DATA, mi.abi.PARAM_EMITTER_RADIANCE)]
+    assert (lay, total) == o.param_layout() and sum(e[3] for e in colour) == 3 + 5 * 3    # grey albedo + 5 emitters; conductors carry none
+    assert [e for e in lay if e[0] == mi.abi.PARAM_BSDF_IOR] == [(mi.abi.PARAM_BSDF_IOR, [i for i, b in enumerate(veach64.bsdfs) if b.type == mi.abi.BSDF_DIELECTRIC][0], total - 2, 2)]
     assert np.allclose(g, g_ref, rtol=2e-2, atol=2e-3 * np.abs(g_ref).max())
     # linearity identity for every emitter: d<1, image>/d rad_c = sum(image_c contribution of that emitter) -> sum over emitters = image sum / 1
     tot = sum((g[off:off + 3] * veach64.emitters[i].radiance).sum() for k, i, off, sz in lay if k == mi.abi.PARAM_EMITTER_RADIANCE)
@@ -610,7 +612,7 @@ def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
     lay, total = o.param_layout()
     v = rng.normal(size=total).astype(np.float32)
     for key in params.keys():
-        kind, index, shape = params._entries[key]; off, size = params._layout[(kind, index)]
+        kind, index, shape = params._entries[key]; off, size = params._slot(key)
         params.set_tangent(key, torch.tensor(v[off:off + size].reshape(shape)))
     gimg = integ.render_forward(scene, params, seed=5, spp=32).cpu().numpy()
     ref = o.render_forward(o.params(integ, 5, 32), v)
@@ -957,6 +959,9 @@ def test_particle_tracer_all_parameter_gradients(mi, orc, torch_cuda, scene_name
     lay, total = o.param_layout()
     for kind, index, off, size in lay:
         a, b = g[off:off + size], ref[off:off + size]
+        if kind in (mi.abi.PARAM_VERTEX_POSITIONS, mi.abi.PARAM_BSDF_IOR):    # (the geometry pass was not asked for: tests/test_gpu_geometry.py)
+            assert np.abs(a).max() == 0 and np.abs(b).max() == 0
+            continue
         assert np.isfinite(a).all() and np.abs(b).max() > 0, (kind, index)
         assert np.allclose(a, b, rtol=2e-2, atol=3e-3 * np.abs(b).max()), (kind, index, np.abs(a - b).max(), np.abs(b).max())
     only = mi.traverse(scene); only.keep(r".*\.emitter\.radiance\.value")
