@@ -413,6 +413,49 @@ MI_DEV bool prim_test(P pr, const Ray &ray, float tlim, float &t, float &s, floa
     s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
     return ((int) (t >= 0.f) & (int) (t < tlim) & (int) (fminf(s, u) >= pr->lo) & (int) (fmaxf(s, u) <= 1.f) & (int) (s + u <= pr->smax)) != 0;   // branch-free on purpose
 }
+// Software-pipelined scalar loads for the flat-primitive loops.  Written as `load record k; test record k` the compiler puts an
+// s_waitcnt in front of every test, and the scalar-cache latency of each 64-byte record is exposed once per primitive and ray
+// (profiles/r02_a: 43 % of the wave-cycles of the forward kernel are spent parked at s_waitcnt).  A value-level rewrite (load k + 1 into a
+// second struct, test k) is rotated straight back by the optimiser, so the loads are issued by hand: prim_issue() starts the three
+// s_load of a record into a register tuple the compiler cannot sink, prim_wait() is the s_waitcnt that makes them usable.  The loops
+// issue record k + 1 before they test record k.  The compiler's own wait-count bookkeeping does not know about these loads, so every
+// loop DRAINS them (prim_drain) before it is left: no hand-issued load is ever outstanding in compiler-scheduled code.
+// MEASURED (round 2, MI355X, Cornell 512^2 @ 256 spp, profiles/r02_prim_pipeline_on.json vs _off.json): k_render_compact 9.44 ms with the
+// pipelined loads against 9.02 ms with the plain loop -- the second register set pushes the kernel past its SGPR budget (30 v_writelane /
+// v_readlane spill moves instead of 4) and the scalar cache already answers the 15 records within the shadow of 4-5 resident waves.
+// It therefore stays OFF; -DMI_PRIM_PIPELINE=1 rebuilds the experiment.
+#ifndef MI_PRIM_PIPELINE
+#define MI_PRIM_PIPELINE 0
+#endif
+typedef float mi_f32x8 __attribute__((ext_vector_type(8)));
+typedef float mi_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mi_f32x2 __attribute__((ext_vector_type(2)));
+struct PrimRegs { mi_f32x8 a; mi_f32x4 b; mi_f32x2 c; };                    // m[0..7] | m[8..11] | lo, smax
+MI_DEV PrimRegs prim_issue(MI_K(DPrim) *p) {
+    PrimRegs r;
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c) : "s"(p));
+    __builtin_amdgcn_sched_barrier(0);                                      // the test of the OTHER record stays behind the issue: that is the overlap
+    return r;
+}
+MI_DEV void prim_wait(PrimRegs &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c)); }
+// wait for `cur`, then start the next record into `nxt`.  `cur` passes THROUGH the statement, so every instruction of cur's test depends on
+// it and stays behind the issue of the next load (as two statements the optimiser sank the issue below the test in one of the two halves).
+MI_DEV void prim_wait_issue(PrimRegs &cur, PrimRegs &nxt, MI_K(DPrim) *p) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %6, 0x0\n\ts_load_dwordx4 %1, %6, 0x20\n\ts_load_dwordx2 %2, %6, 0x30"
+                 : "=&s"(nxt.a), "=&s"(nxt.b), "=&s"(nxt.c), "+s"(cur.a), "+s"(cur.b), "+s"(cur.c) : "s"(p));
+}
+MI_DEV void prim_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+MI_DEV bool prim_test_regs(const PrimRegs &r, const Ray &ray, float tlim, float &t, float &s, float &u) {
+    float os = fmaf(r.a[2], ray.o.z, fmaf(r.a[1], ray.o.y, fmaf(r.a[0], ray.o.x, r.a[3])));
+    float ot = fmaf(r.a[6], ray.o.z, fmaf(r.a[5], ray.o.y, fmaf(r.a[4], ray.o.x, r.a[7])));
+    float oh = fmaf(r.b[2], ray.o.z, fmaf(r.b[1], ray.o.y, fmaf(r.b[0], ray.o.x, r.b[3])));
+    float ds = fmaf(r.a[2], ray.d.z, fmaf(r.a[1], ray.d.y, r.a[0] * ray.d.x));
+    float dt = fmaf(r.a[6], ray.d.z, fmaf(r.a[5], ray.d.y, r.a[4] * ray.d.x));
+    float dh = fmaf(r.b[2], ray.d.z, fmaf(r.b[1], ray.d.y, r.b[0] * ray.d.x));
+    t = -oh * rcp_(dh);
+    s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
+    return ((int) (t >= 0.f) & (int) (t < tlim) & (int) (fminf(s, u) >= r.c[0]) & (int) (fmaxf(s, u) <= 1.f) & (int) (s + u <= r.c[1])) != 0;
+}
 MI_DEV float excl_limit(float maxt) { return maxt >= MI_LARGEST ? MI_INF : __uint_as_float(__float_as_uint(maxt) + 1u); }
 
 // Slab test of one oriented box: entering distance if the origin is outside, exiting distance if it is inside
@@ -485,12 +528,28 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
     uint32_t best = 0xffffffffu;
     const uint32_t n = sc.n_prims;
     MI_K(DPrim) *prims = as_const_table(sc.prims); MI_K(DBox) *boxes = as_const_table(sc.boxes); MI_K(DSphere) *spheres = as_const_table(sc.spheres);
+#if MI_PRIM_PIPELINE
+    if (!FULL && n) {                                                       // (FULL scenes test `fin` for disks too: they keep the plain loop)
+        PrimRegs A = prim_issue(prims), B;                                  // two register sets, used in turn: a load never waits for the reads of the other set
+        for (uint32_t k = 0; k < n;) {
+            prim_wait_issue(A, B, prims + (k + 1u < n ? k + 1u : k));          // record k + 1 in flight while record k is tested
+            { float t, s, u; const bool h = prim_test_regs(A, ray, tlim, t, s, u); tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best; }
+            if (++k >= n) break;
+            prim_wait_issue(B, A, prims + (k + 1u < n ? k + 1u : k));
+            { float t, s, u; const bool h = prim_test_regs(B, ray, tlim, t, s, u); tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best; }
+            ++k;
+        }
+        prim_drain();
+    } else
+#endif
+    {
     MI_UNROLL_PRIMS
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
         bool h = prim_test(prims + k, ray, tlim, t, s, u);
         if (FULL && prims[k].fin == MI_DISK_FIN) h = h && fmaf(s, s, u * u) <= 1.f;   // Disk::ray_intersect_preliminary_impl, disk.cpp:392-416
         tlim = h ? t : tlim; hit.u = h ? s : hit.u; hit.v = h ? u : hit.v; best = h ? k : best;
+    }
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
         float t;
@@ -549,12 +608,28 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
     const uint32_t n = sc.n_prims;
     MI_K(DPrim) *prims = as_const_table(sc.prims); MI_K(DBox) *boxes = as_const_table(sc.boxes); MI_K(DSphere) *spheres = as_const_table(sc.spheres);
+#if MI_PRIM_PIPELINE
+    if (!FULL && n) {
+        PrimRegs A = prim_issue(prims), B;
+        for (uint32_t k = 0; k < n;) {
+            prim_wait_issue(A, B, prims + (k + 1u < n ? k + 1u : k));
+            { float t, s, u; if (prim_test_regs(A, ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; } }
+            if (++k >= n) break;
+            prim_wait_issue(B, A, prims + (k + 1u < n ? k + 1u : k));
+            { float t, s, u; if (prim_test_regs(B, ray, tlim, t, s, u)) { occluded = true; tlim = 0.f; } }
+            ++k;
+        }
+        prim_drain();
+    } else
+#endif
+    {
     MI_UNROLL_PRIMS
     for (uint32_t k = 0; k < n; ++k) {
         float t, s, u;
         bool h = prim_test(prims + k, ray, tlim, t, s, u);
         if (FULL && prims[k].fin == MI_DISK_FIN) h = h && fmaf(s, s, u * u) <= 1.f;   // Disk::ray_test_impl, disk.cpp:418-431
         if (h) { occluded = true; tlim = 0.f; }
+    }
     }
     for (uint32_t k = 0; k < sc.n_boxes; ++k) {
         float t;

@@ -288,3 +288,147 @@ def test_huge_jobs_are_split_into_passes(mi):
     p = mi.PathIntegrator({"max_depth": 3})._params(sc, 0, 1024)
     assert p.passes >= 5 and 1024 % p.passes == 0 and 4096 * 4096 * (1024 // p.passes) <= 0xffffffff
     assert mi.PathIntegrator({"max_depth": 3})._params(sc, 0, 64).passes in (0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: geometry adjoint (host check), optimizers, lens-design helpers, oracle geometry derivative
+# ------------------------------------------------------------------------------------------------
+def test_geo_adjoint_matches_finite_differences(tmp_path):
+    """csrc/mi355_geo_adjoint.h -- the hand-written reverse mode of one light-path vertex the GPU kernel runs in fp32 -- compiled for the
+    host in double precision and checked function by function against central finite differences (tests/geo_adjoint_check.cpp)."""
+    import subprocess
+    exe = str(tmp_path / "geo_adjoint_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "geo_adjoint_check.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) >= 28 and all(l.rstrip().endswith("ok") for l in lines), r.stdout
+
+
+def test_optimizers_follow_the_reference(mi):
+    """mi.ad.SGD / mi.ad.Adam as src/python/python/ad/optimizers.py:116-302 states them, including two quirks: SGD with momentum steps
+    with the PREVIOUS velocity (:163-170, first step zero), Adam advances t[k] before it looks at the gradient (:265-273) and reset()
+    zeroes moments and t."""
+    import torch
+    x0 = torch.tensor([1.0, -2.0])
+    g1, g2 = torch.tensor([0.5, 1.0]), torch.tensor([-1.0, 0.25])
+    opt = mi.SGD(lr=0.1, momentum=0.9); opt["x"] = x0
+    opt["x"].grad = g1.clone(); opt.step()
+    assert torch.allclose(opt["x"].detach(), x0)                             # step = lr * state(previous) = 0
+    opt["x"].grad = g2.clone(); opt.step()
+    assert torch.allclose(opt["x"].detach(), x0 - 0.1 * g1)                  # the velocity of step 1, applied at step 2
+    assert torch.allclose(opt.state["x"], 0.9 * g1 + g2)
+    plain = mi.SGD(lr=0.1); plain["x"] = x0; plain["x"].grad = g1.clone(); plain.step()
+    assert torch.allclose(plain["x"].detach(), x0 - 0.1 * g1)
+    masked = mi.SGD(lr=0.1, momentum=0.5, mask_updates=True); masked["x"] = x0
+    masked["x"].grad = torch.tensor([0.0, 1.0]); masked.step(); masked["x"].grad = torch.tensor([0.0, 1.0]); masked.step()
+    assert masked["x"][0] == x0[0] and masked.state["x"][0] == 0
+    ad = mi.Adam(lr=0.01); ad["x"] = x0
+    ad.step()                                                                # no gradient: t advances, nothing else
+    assert ad.t["x"] == 1 and torch.allclose(ad["x"].detach(), x0)
+    ad["x"].grad = g1.clone(); ad.step()
+    t = 2; m = 0.1 * g1; v = 0.001 * g1 * g1
+    lr_t = 0.01 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+    assert ad.t["x"] == 2 and torch.allclose(ad["x"].detach(), x0 - lr_t * m / (v.sqrt() + 1e-8), atol=1e-7)
+    ad["x"] = torch.tensor([1.0, 2.0, 3.0])                                  # shape change: state and t are reset
+    assert ad.t["x"] == 0 and ad.state["x"][0].shape == (3,) and float(ad.state["x"][0].abs().sum()) == 0
+    ad["x"] = torch.tensor([4.0, 5.0, 6.0])                                  # same shape: state kept
+    ad["x"].grad = torch.ones(3); ad.step(); assert ad.t["x"] == 1
+    ad["x"] = torch.tensor([0.0, 0.0, 0.0]); assert ad.t["x"] == 1
+    with pytest.raises(Exception):
+        ad["y"] = 3
+
+
+def test_lens_design_geometry_helpers(mi):
+    """notebooks/scripts/lens_design/geometry.py restated (mitsuba3-camera_amd/lens_design.py): icosphere counts, the hemisphere cut, the
+    ordered boundary loop, the spherical cap's radius and sag, the surface + baffle meshes of create_surface_geometry."""
+    ld = mi.lens_design
+    for n in range(4):
+        V, F = ld.icosphere(n)
+        assert V.shape == (10 * 4 ** n + 2, 3) and F.shape == (20 * 4 ** n, 3) and np.allclose(np.linalg.norm(V, axis=1), 1)
+        e = np.sort(np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]]), axis=1)
+        assert (np.unique(e, axis=0, return_counts=True)[1] == 2).all()      # closed manifold
+        nrm = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]]); assert ((nrm * V[F].mean(axis=1)).sum(axis=1) > 0).all()   # outward
+    V, F = ld.get_hemisphere_ico(3)
+    loop = ld.boundary_loop(F)
+    assert V[:, 2].min() > -0.2 and len(loop) == len(set(loop.tolist())) and np.abs(V[loop, 2]).max() < 0.2
+    edges = {(int(a), int(b)) for f in F for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0]))}
+    assert all((int(loop[i]), int(loop[(i + 1) % len(loop)])) in edges for i in range(len(loop)))
+    surf = ld.EvenAsphericSurface(radial_extent=8.0, c=1 / 24, K=0.0, z0=52.0, a4=1e-6)
+    Vl, Fl, Va, Fa, mask = ld.create_surface_geometry(3, 8.0, surf.compute_z_np, c=surf.get_curvature(), baffle_radius=8.8, flip_normals=True)
+    r = np.linalg.norm(Vl[:, :2], axis=1)
+    # (the hemisphere is cut along icosphere edges: its rim zig-zags between two rings of vertices, as in the fork's own construction)
+    assert abs(r.max() - 8.0) < 1e-6 and r[mask].min() > 0.9 * 8.0 and r[~mask].max() < r[mask].max() and mask.sum() == len(ld.boundary_loop(Fl))
+    sag = 52.0 - (r ** 2 / 24) / (1 + np.sqrt(1 - r ** 2 / 576)) - 1e-6 * r ** 4
+    assert np.allclose(Vl[:, 2], sag, atol=2e-4)
+    n = np.cross(Vl[Fl[:, 1]] - Vl[Fl[:, 0]], Vl[Fl[:, 2]] - Vl[Fl[:, 0]]); assert (n[:, 2] < 0).all()          # flipped: facing the film
+    assert Va.shape[0] == 2 * mask.sum() and Fa.shape[0] == 4 * mask.sum() and np.abs(Va[:, :2]).max() <= 8.8 + 1e-9
+    # the torch sag function is the one the optimisation differentiates: d z / d z0 = 1, d z / d c < 0 off axis
+    import torch
+    z0 = torch.tensor([52.0], requires_grad=True); c = torch.tensor([8.0 / 24], requires_grad=True)
+    surf.params["z0"] = z0; surf.params["c"] = c
+    z = surf.compute_z(torch.tensor([0.0, 4.0]), torch.tensor([0.0, 0.0]))
+    gz0, gc = torch.autograd.grad(z.sum(), [z0, c])
+    assert abs(float(gz0) - 2.0) < 1e-6 and float(gc) < 0
+    # angle-weighted vertex normals (mesh.cpp:376-413) of the cap point along the analytic normal of the sphere
+    vn = mi.scene.compute_vertex_normals(Vl.astype(np.float32), Fl.astype(np.uint32))
+    centre = np.array([0, 0, 52.0 - 24.0]); ana = (centre - Vl); ana /= np.linalg.norm(ana, axis=1, keepdims=True)
+    inner = ~mask
+    assert (np.abs((vn[inner] * ana[inner]).sum(axis=1)) > 0.999).all()
+
+
+def test_oracle_geometry_derivative_against_finite_differences(mi, orc):
+    """The oracle's forward-mode (multi-dual) geometry derivative of the particle tracer (oracle/mi_oracle_geo.inc) against central finite
+    differences of the oracle's own primal, with identical seeds: a flat tilted glass interface (two triangles) between a collimated disk
+    source and a diffuse screen -- vertex gradient contracted with the tilt, and the IOR gradient.  The image functional vanishes towards
+    the frame (film-border splats are a boundary term that AD does not see)."""
+    T = mi.ScalarTransform4f
+    res = 24
+
+    def wedge(ior, tilt):
+        q = np.array([[-0.8, -0.8, 1.0 + 0.8 * tilt], [0.8, -0.8, 1.0 - 0.8 * tilt], [0.8, 0.8, 1.0 - 0.8 * tilt], [-0.8, 0.8, 1.0 + 0.8 * tilt]], dtype=np.float32)
+        return {'type': 'scene', 'white': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': (0.8, 0.7, 0.6)}}, 'black': {'type': 'diffuse', 'reflectance': 0.0},
+                'screen': {'type': 'rectangle', 'to_world': T.look_at(target=[0, 0, 1], origin=[0, 0, 0], up=[0, 1, 0]).scale([2, 2, 1]), 'bsdf': {'type': 'ref', 'id': 'white'}},
+                'lens': {'type': 'mesh', 'vertex_positions': q, 'faces': np.array([[0, 2, 1], [0, 3, 2]], dtype=np.uint32),
+                         'bsdf': {'type': 'dielectric', 'int_ior': ior, 'ext_ior': 1.0, 'specular_reflectance': 0.0}},
+                'source': {'type': 'disk', 'to_world': T.look_at(target=[0, 0, 1.0], origin=[0, 0, 3.0], up=[0, 1, 0]) @ T.scale([0.2, 0.2, 1]),
+                           'bsdf': {'type': 'ref', 'id': 'black'}, 'emitter': {'type': 'directionalarea', 'radiance': 1.0}},
+                'sensor': {'type': 'perspective', 'near_clip': 0.01, 'far_clip': 10.0, 'fov': 60.0, 'to_world': T.look_at(target=[0.1, 0.05, 0.0], origin=[0.3, 0.2, 0.6], up=[0, 1, 0]),
+                           'film': {'type': 'hdrfilm', 'width': res, 'height': res, 'pixel_format': 'rgb', 'rfilter': {'type': 'gaussian'}}}}
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5})
+    yy, xx = np.mgrid[0:res, 0:res]
+    window = (np.sin(np.pi * (xx + 0.5) / res) * np.sin(np.pi * (yy + 0.5) / res)) ** 2
+    gin = np.repeat(((0.5 + xx / res + 0.3 * yy / res) * window)[:, :, None], 3, axis=2).astype(np.float32)
+    spp, ior0, tilt0, eps = 512, 1.6, 0.35, 4e-3
+
+    def f(ior, tilt):
+        o = orc.OracleScene(mi.load_dict(wedge(ior, tilt)), mi.abi)
+        return float((o.ptracer_render(o.params(integ, 4, spp))[0].astype(np.float64) * gin).sum())
+    sc = mi.load_dict(wedge(ior0, tilt0)); o = orc.OracleScene(sc, mi.abi)
+    p = o.params(integ, 4, spp); p.flags |= mi.abi.FLAG_GEOMETRY_GRADS
+    g = o.ptracer_backward(p, gin)
+    lay, _ = o.param_layout()
+    off_v = [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_VERTEX_POSITIONS and sc.shapes[i].id == "lens"][0]
+    off_i = [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_BSDF_IOR][0]
+    dq = np.array([[0, 0, 0.8], [0, 0, -0.8], [0, 0, -0.8], [0, 0, 0.8]], dtype=np.float64)
+    g_tilt, fd_tilt = float((g[off_v:off_v + 12].reshape(4, 3) * dq).sum()), (f(ior0, tilt0 + eps) - f(ior0, tilt0 - eps)) / (2 * eps)
+    g_ior, fd_ior = float(g[off_i]), (f(ior0 + eps, tilt0) - f(ior0 - eps, tilt0)) / (2 * eps)
+    assert abs(fd_tilt) > 0 and abs(g_tilt - fd_tilt) < 4e-2 * abs(fd_tilt), (g_tilt, fd_tilt)
+    assert abs(fd_ior) > 0 and abs(g_ior - fd_ior) < 6e-2 * abs(fd_ior), (g_ior, fd_ior)       # (the finite difference sees ~100 lobe flips: noisy)
+    assert g[off_i + 1] != 0                                                 # ext_ior: the ratio's denominator
+
+
+def test_baseline_config_1_runs_at_its_stated_size(mi, orc):
+    """BASELINE configs[0]: the Cornell box at 256 x 256 @ 16 spp on the host CPU ("plumbing, no GPU") -- the oracle at that size, whole image,
+    with the sanity identities of a converging render: finite, the light is the brightest thing, red bleeds left and green right, two
+    disjoint halves of the samples agree within Monte-Carlo noise."""
+    d = mi.cornell_box()      # 256 x 256 as mi.cornell_box() ships it (util.py:565-699)
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+    integ = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+    img, n = o.render(o.params(integ, 0, 16))
+    assert img.shape == (256, 256, 3) and n == 256 * 256 * 16 and np.isfinite(img).all()
+    assert img[30:36, 112:144].mean() > 20 * img[128:, :].mean()             # the emitter, top centre
+    left, right = img[100:200, 8:40], img[100:200, 216:248]
+    assert left[..., 0].mean() > 2 * left[..., 1].mean() and right[..., 1].mean() > 2 * right[..., 0].mean()
+    a, _ = o.render(o.params(integ, 1, 8)); b, _ = o.render(o.params(integ, 2, 8))
+    assert abs(a.mean() - b.mean()) < 0.02 * a.mean() and abs(0.5 * (a + b).mean() - img.mean()) < 0.02 * img.mean()
