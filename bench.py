@@ -9,8 +9,12 @@ to the ranks (strong scaling, total work fixed); the only exchange is one all-re
 accumulator before develop.
 
 The same JSON line carries
-  roofline      algorithmic bytes (88 N_gen + 48 N_isect + 196 N_shade + 104 N_shadow + 20 N_splat
-                + 60 H W, from the engine's device counters) / HIP-event time of the path kernel, vs 8 TB/s HBM3E
+  roofline      the resource that binds the fused path kernel: wave64 VALU instruction issue.  achieved = VALU instructions per
+                launch (SQ_INSTS_VALU of the committed PMC pass, profiles/r02_pmc_summary.json) / HIP-event time of the kernel
+                measured live; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction (MI355X_MICROARCH.md; the microbenchmark
+                profiles/r02_valu_issue.json reaches 2.2); frac <= 1.  `traffic` and `hbm` come from the same PMC pass.
+                `contract` keeps the SURVEY.md 8(d) algorithmic bytes (88 N_gen + 48 N_isect + 196 N_shade + 104 N_shadow +
+                20 N_splat + 60 H W) of the unfused SoA formulation -- a bookkeeping figure, not a physical bound.
   cpu_baseline  the CPU oracle (scalar C restatement, OpenMP over all host cores) on a bounded sample of the same
                 workload (512x512 at a few spp), rank 0, N = 1 only
   prb           PRB backward (BASELINE config C3: 512x512 @ 64 spp, gradient w.r.t. a 256x256x3 albedo texture on the
@@ -30,7 +34,67 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package, load_oracle  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6.3 TB/s
+N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
+PEAK_CLOCK_GHZ = 2.4        # MI355X peak engine clock (MI355X_MICROARCH.md)
+VALU_CYCLES_PEAK = 2.0      # cycles one SIMD needs per wave64 VALU instruction (guide); profiles/r02_valu_issue.json measures 2.2-2.5
+VALU_PEAK_GINST = N_SIMD * PEAK_CLOCK_GHZ / VALU_CYCLES_PEAK      # 1228.8 G wave64-instructions / s
+PMC_FILE = os.path.join("profiles", "r02_pmc_summary.json")      # tools/pmc.sh + tools/pmc_summary.py, committed
 TILE_ROWS = 16
+
+
+def pmc_kernel(substr):
+    """Counters of one kernel from the committed PMC pass (None when the file or the kernel is missing)."""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            ks = json.load(f)["kernels"]
+        for name, rec in ks.items():
+            if substr in name and "counters" in rec:
+                return rec
+    except Exception:
+        pass
+    return None
+
+
+def microbench_cycles(waves=5):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) as f:
+            for r in json.load(f)["results"]:
+                if r["op"] == "v_fma_f32" and r["waves_per_simd"] == waves:
+                    return r["cyc_per_inst_wall"]      # wall time x nominal clock: the same convention as cycles_per_inst_measured (DVFS included)
+    except Exception:
+        pass
+    return None
+
+
+def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes):
+    """roofline block of a fused path kernel: bound = wave64 VALU issue.  Instruction count and HBM traffic per launch are read from
+    the committed PMC pass (scaled by lanes when this launch covers a different number of lanes than the profiled one), the time is the
+    HIP-event time measured in this run."""
+    rec = pmc_kernel(pmc_name)
+    sec = kernel_ms * 1e-3
+    out = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Ginst/s (wave64 VALU)", "frac": None, "traffic": None,
+           "kernel": kernel, "kernel_ms": round(kernel_ms, 4)}
+    if rec is not None and sec > 0:
+        c = rec["counters"]; scale = lanes_per_launch / float(rec["grid"])
+        insts = c["SQ_INSTS_VALU"] * scale
+        out.update({"achieved": round(insts / sec / 1e9, 1), "frac": round(insts / sec / 1e9 / VALU_PEAK_GINST, 4),
+                    "insts_per_launch": int(insts), "cycles_per_inst_measured": round(sec * PEAK_CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
+                    "cycles_per_inst_peak": VALU_CYCLES_PEAK, "cycles_per_inst_microbench": microbench_cycles(),
+                    "pmc": {"file": PMC_FILE, "kernel": pmc_name, "lanes_profiled": int(rec["grid"]), "scaled_by_lanes": round(scale, 6),
+                            "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "GRBM_GUI_ACTIVE": c.get("GRBM_GUI_ACTIVE"),
+                            "cycles_per_inst_pmc": (round(c["GRBM_GUI_ACTIVE"] / 8 * N_SIMD / c["SQ_INSTS_VALU"], 3) if c.get("GRBM_GUI_ACTIVE") else None),
+                            "waves": c.get("SQ_WAVES"), "insts_per_wave": {k[9:].lower(): round(c[k] / c["SQ_WAVES"], 1) for k in
+                                ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if k in c and c.get("SQ_WAVES")}}})
+        if "hbm_write_bytes" in rec and "hbm_read_bytes" in rec:
+            traffic = (rec["hbm_read_bytes"][1] + rec["hbm_write_bytes"]) * scale        # read side: the x2-corrected upper bound
+            out["traffic"] = int(traffic)
+            out["hbm"] = {"traffic_measured": int(traffic), "read_bytes": [int(v * scale) for v in rec["hbm_read_bytes"]], "write_bytes": int(rec["hbm_write_bytes"] * scale),
+                          "achieved_GBs": round(traffic / sec / 1e9, 1), "peak_GBs": HBM_PEAK_GBS, "frac_of_peak": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)}
+    else:
+        out["note"] = "no PMC record for this kernel in %s: instruction count unknown, frac not stated" % PMC_FILE
+    out["contract"] = {"algorithmic_bytes_per_launch": int(contract_bytes), "GBs": round(contract_bytes / sec / 1e9, 1) if sec > 0 else None,
+                       "note": "SURVEY.md 8(d) bytes of the unfused SoA wavefront formulation / kernel time; the fused kernel keeps that state in registers, so this is bookkeeping, not a bound"}
+    return out
 
 
 def algorithmic_bytes(c, n_pixels_developed):
@@ -54,6 +118,7 @@ def main():
     ap.add_argument("--veach", action="store_true", help="(legs run by default now; kept for old command lines)")
     ap.add_argument("--no-veach", action="store_true", help="skip the BASELINE configs[3] leg (Veach-MIS scene, 1024^2 @ 512 spp)")
     ap.add_argument("--no-ptracer", action="store_true", help="skip the particle tracer leg (Cornell box 512^2 @ 64 spp)")
+    ap.add_argument("--ptracer-direct", action="store_true", help="A/B: also time the particle tracer's Gaussian splat with plain atomics (230 ms)")
     ap.add_argument("--no-lens", action="store_true", help="skip the BASELINE configs[4] leg (lens doublet, ptracer + geometry adjoint)")
     ap.add_argument("--lens-subdiv", type=int, default=7, help="icosphere level of the lens surface meshes (the notebook uses 7)")
     ap.add_argument("--only", default="", help="comma-separated legs to run besides the headline one: prb,veach,ptracer,lens,cpu (default: all)")
@@ -167,13 +232,6 @@ def main():
     launches = max(cnt["kernel_launches"], 1)
     kernel_ms = cnt["kernel_ms"] / launches
     alg = algorithmic_bytes(cnt, npix * args.steps * (len(my_tiles) / n_tiles if world > 1 else 1.0)) / launches
-    achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None                      # measured HBM bytes per launch of this kernel: a separate --pmc run (tools/pmc.sh), committed
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)[KERNEL_NAME]["bytes_per_launch"] if (world == 1 and args.res == 512 and args.spp == 256) else None
-    except Exception:
-        traffic = None
     # next to the nominal 8 TB/s, the device-to-device copy rate measured on THIS box (read + write bytes / time)
     copy_gbs = None
     if rank == 0:
@@ -186,14 +244,37 @@ def main():
         e1.record(); torch.cuda.synchronize(dev)
         copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "peak_measured_copy": None if copy_gbs is None else round(copy_gbs, 1),
-                "frac_of_measured_copy": None if copy_gbs is None else round(achieved / copy_gbs, 4),
-                "note": "achieved = algorithmic bytes of the SoA wavefront formulation (SURVEY.md 8d) / kernel time; the fused kernel keeps them in registers and is VALU-issue bound (DESIGN.md 4, profiles/r01_n_pmc_summary.txt), so frac can exceed 1 while the measured HBM traffic stays at `traffic`",
-                "kernel": KERNEL_NAME, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
-                "algorithmic_bytes_per_launch": int(alg),
-                "events_per_lane": {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}}
+    lanes_launch = cnt["n_gen"] / launches
+    roofline = valu_roofline(KERNEL_NAME, {"k_render_compact": "k_render_compact<0, false>", "k_render_regen": "k_render_regen<false>"}.get(KERNEL_NAME, "k_render<0, 1, false>"),
+                             kernel_ms, lanes_launch, alg)
+    roofline["launches"] = int(launches)
+    roofline["events_per_lane"] = {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}
+    if roofline.get("hbm") is not None:
+        roofline["hbm"]["peak_measured_copy_GBs"] = None if copy_gbs is None else round(copy_gbs, 1)
+
+    # ---- per-frame latency with nothing overlapped (kernel, film reduce, develop: each followed by a device sync) -------------------
+    def timed_phase(fn):
+        torch.cuda.synchronize(dev); t = time.perf_counter(); fn(); torch.cuda.synchronize(dev); return (time.perf_counter() - t) * 1e3
+    lat = {"kernel_ms": 0.0, "reduce_ms": 0.0, "develop_ms": 0.0}
+    n_lat = 3
+    for i in range(n_lat):
+        film = films[0]; film.zero_()
+        p = integ._params(scene, 500 + i, args.spp, shard=my_shard if world > 1 else None)
+        lat["kernel_ms"] += timed_phase(lambda: mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream)))
+        if dist is not None:
+            lat["reduce_ms"] += timed_phase(lambda: dist.reduce(film, dst=0, op=dist.ReduceOp.SUM))
+        if rank == 0:
+            lat["develop_ms"] += timed_phase(lambda: mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream)))
+        if dist is not None:
+            dist.barrier()
+    lat = {k: round(v / n_lat, 3) for k, v in lat.items()}
+    lat["frame_ms"] = round(lat["kernel_ms"] + lat["reduce_ms"] + lat["develop_ms"], 3)
+    if dist is not None:                          # the slowest rank's figures
+        tt = torch.tensor([lat["kernel_ms"], lat["reduce_ms"], lat["develop_ms"], lat["frame_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        lat = dict(zip(("kernel_ms", "reduce_ms", "develop_ms", "frame_ms"), [round(float(v), 3) for v in tt.tolist()]))
+    lat["note"] = "one frame with every phase followed by a device sync (max over ranks); `ms_per_step` above is the pipelined rate: the reduce of frame k overlaps the kernel of frame k + 1"
+    integ.counters(scene, reset=True)
 
     # ---- PRB backward leg (config C3) ------------------------------------------------------------------
     prb = None
@@ -236,13 +317,11 @@ def main():
         prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
                "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
-               "roofline": (lambda kms, L: {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "k_prepare_grad + k_prb_backward_1p (+ redo)",
-                                            "algorithmic_bytes_per_launch": int(L), "achieved": round(L / (kms * 1e-3) / 1e9, 1),
-                                            "frac": round(L / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})(
-                   c3["kernel_ms"] / max(c3["kernel_launches"], 1),
-                   # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
-                   ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
-                   + 8 * params.grad_buffer(dev).numel()),
+               "roofline": valu_roofline("k_prepare_grad + k_prb_backward_1p (+ redo)", "k_prb_backward_1p<false, false>",
+                                         c3["kernel_ms"] / max(c3["kernel_launches"], 1), c3["n_gen"] / max(c3["kernel_launches"], 1),
+                                         # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
+                                         ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
+                                         + 8 * params.grad_buffer(dev).numel()),
                "render_forward_ms": fwd_ms, "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
         scene3.release()
 
@@ -282,7 +361,7 @@ def main():
     pt = None
     if not args.no_ptracer:
         pt = {}
-        for rf in ("box", "gaussian", "gaussian-direct"):          # gaussian: deferred tile-sorted splat (default); -direct: plain atomics
+        for rf in ("box", "gaussian") + (("gaussian-direct",) if args.ptracer_direct else ()):   # gaussian: deferred tile-sorted splat (default); -direct: plain atomics (A/B)
             dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
             dp["sensor"]["film"]["rfilter"] = {"type": rf.split("-")[0]}
             scp = mi.load_dict(dp)
@@ -381,7 +460,7 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Cornell box (mi.cornell_box), forward path trace %dx%d @ %d spp, max_depth=6, rr_depth=5 (BASELINE configs[1])" % (W, H, args.spp),
                           "lanes_per_step": lanes_per_step, "mode": MODE_NAME, "sharding": "16-row tiles round-robin (one launch per rank), film reduce to rank 0 overlapped with the next frame" if world > 1 else "none"},
-               "roofline": roofline, "cpu_baseline": cpu, "prb": prb}
+               "roofline": roofline, "latency": lat, "cpu_baseline": cpu, "prb": prb}
         if c4 is not None:
             out["veach"] = c4
         if pt is not None:

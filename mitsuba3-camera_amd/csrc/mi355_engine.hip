@@ -38,7 +38,7 @@
 #define BLOCK 256
 #define WAVES (BLOCK / 64)
 #ifndef MI_MIN_WAVES
-#define MI_MIN_WAVES 5                      // k_render: waves per SIMD the register allocator must leave room for (LDS allows 5 blocks/CU)
+#define MI_MIN_WAVES 5                      // k_render*: waves per SIMD the register allocator must leave room for (94 VGPRs; at 6 it spills 20 and gains nothing: profiles/r02_occupancy_ab.txt)
 #endif
 #ifndef MI_MIN_WAVES_BWD
 #define MI_MIN_WAVES_BWD 4                  // k_prb_backward spills at 5 (measured slower)
@@ -50,7 +50,7 @@
 #define SPLAT_ROWS 14                       // 5 x-weights + 5 y-weights + 4 channel values (separable filter)
 #define WAVE_FLOATS (SPLAT_ROWS * ROW_STRIDE)
 #define STACK_WORDS (MI_BVH_STACK * 64)     // per wave
-#define CSTATE_WORDS 23                     // per lane, k_render_compact (21 + eta, prev_delta in FULL scenes)
+#define CSTATE_WORDS(FULL) ((FULL) ? 23 : 21) // per lane, k_render_compact (21 + eta, prev_delta in FULL scenes)
 #define MAX_SMALL_GRAD 1024
 #define MAX_SPLAT_RECORDS (128ull << 20)   // deferred-splat queue of the particle tracer: 40 B per record (unsorted + sorted copy)
 #define GRAD_QUEUE 496                      // texture-gradient records per workgroup (16 KB, 2 per lane); overflow -> direct atomics
@@ -58,8 +58,8 @@
 #define CMAX(a, b) ((a) > (b) ? (a) : (b))
 // (only the FULL kernels traverse a BVH -- scenes with BVH meshes set features bit 3 -- so only they reserve the traversal stack:
 // the all-diffuse flat-primitive kernels keep their 27 KB and five workgroups per CU)
-#define REGION_BASIC CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS * BLOCK)
-#define REGION_FLOATS(FULL) ((FULL) ? CMAX(REGION_BASIC, WAVES * STACK_WORDS) : REGION_BASIC)
+#define REGION_BASIC CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS(false) * BLOCK)
+#define REGION_FLOATS(FULL) ((FULL) ? CMAX(CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS(true) * BLOCK), WAVES * STACK_WORDS) : REGION_BASIC)
 #define STACK_FLOATS(FULL) ((FULL) ? WAVES * STACK_WORDS : 64)
 #define STK_PTR(base, FULL, wave, lane_id) (reinterpret_cast<uint32_t *>(base) + ((FULL) ? (wave) * STACK_WORDS + (lane_id) : 0u))
 
@@ -370,17 +370,22 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_wcnt[2 * WAVES];
+#ifdef MI_LDS_PAD                                                              // occupancy experiments only (tools/occupancy_ab.sh): extra LDS per workgroup
+    __shared__ float s_pad[MI_LDS_PAD];
+    if (a.seed == 0xfffffffeu && a.max_depth == 0xffffu) s_pad[threadIdx.x % MI_LDS_PAD] = 0.f;
+#endif
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_id = tid & 63;
     float *smem_wave = smem + wave * WAVE_FLOATS;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     uint32_t i = blockIdx.x * BLOCK + tid;
+    Counters3 cnt = {};
+    PROF_START(cnt);
     LaneInfo li = lane_info(sc, a, i);
     Pcg32 rng; sampler_seed(rng, a.seed, li.lane);
     float pos_x, pos_y; Ray ray0;
     const float cam_w = camera_ray<FULL>(sc, rng, li.px, li.py, pos_x, pos_y, ray0);   // stays with the ORIGINAL slot, like pos
     PathState st; path_init(st, ray0, rng);
-    Counters3 cnt = {};
     fin[tid] = 0.f; fin[BLOCK + tid] = 0.f; fin[2 * BLOCK + tid] = 0.f; fin[3 * BLOCK + tid] = 0.f;
     uint32_t orig = tid;                       // which original slot the path in this thread belongs to
     bool valid_ray = false;
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
     for (uint32_t it = 0; it < a.max_depth; ++it) {
         const bool mine = alive;
         alive = false;
+        PROF(cnt, 6);
         if (__any(mine)) {                                                  // wave-uniform: empty waves skip the bounce
             bool hit_any;
             MI_SCENE_RELOAD(scb);                                           // re-derived every bounce (mi355_device.h)
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
             else alive = prb_primal_step<FULL>(scb, st, it, a.max_depth, a.rr_depth, mine, stk, hit_any, cnt);
             valid_ray = valid_ray || hit_any;
         }
+        PROF_START(cnt);                                                    // (section 6: everything between two path steps -- barriers, re-pack)
         if (mine && !alive) {                                               // path over: park its radiance in its original slot
             bool v = valid_ray;
             fin[orig] = v ? st.result.x : 0.f; fin[BLOCK + orig] = v ? st.result.y : 0.f; fin[2 * BLOCK + orig] = v ? st.result.z : 0.f;
@@ -457,11 +464,16 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compa
         if (sc.n_bvh_shapes) __syncthreads();                               // the BVH stack aliases the state just read
     }
     __syncthreads();
+    PROF(cnt, 6);
     float values[4] = { fin[tid] * cam_w, fin[BLOCK + tid] * cam_w, fin[2 * BLOCK + tid] * cam_w, 1.f };   // integrator.cpp:461, 477-486
     MI_SCENE_RELOAD(scl);                                                   // the splat's filter table / crop window: fetched here, not before the loop
     Splat sp = splat_weights(scl, pos_x, pos_y);
     __syncthreads();
     film_splat<4>(scl, a, smem_wave, film, li, blockIdx.x * BLOCK + wave * 64, sp, values);
+    PROF(cnt, 7);
+#ifdef MI_PROF
+    if (lane_id == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long) cnt.prof[k]);
+#endif
     flush_counters(s_cnt, cnt, g_counters);
 }
 
@@ -2315,7 +2327,7 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
     out->kernel_ms = s->ms_accum; out->kernel_launches = s->launches_accum; out->n_redo_groups = h[4];
 #ifdef MI_PROF
     { unsigned long long pr[8]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), sizeof(pr)));
-      fprintf(stderr, "MI_PROF cycles: isect %llu si+hit %llu emitter %llu bsdf %llu shadow %llu tail %llu gen %llu splat %llu\n",
+      fprintf(stderr, "MI_PROF cycles: isect %llu si+hit %llu emitter %llu bsdf %llu shadow %llu tail %llu gen+repack %llu splat %llu\n",
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
       if (reset) { memset(pr, 0, sizeof(pr)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), pr, sizeof(pr))); } }
 #endif
