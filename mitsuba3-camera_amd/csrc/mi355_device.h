@@ -1668,12 +1668,62 @@ MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {
     float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
     atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
 }
+// Sum of v over the 64 lanes of the wave (all lanes must be executing): four DPP adds give every lane the sum of its row of 16,
+// the four row sums are read back as scalars.
+template <int CTRL> MI_DEV float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+MI_DEV float wave_sum(float v) {
+    v = dpp_add<0xB1>(v);                   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);                  // row_half_mirror
+    v = dpp_add<0x140>(v);                  // row_mirror
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)))
+         + (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+// The same accumulation from CONVERGED code (every lane of the wave calls it; slot < 0 = nothing to add).  An LDS fp32 atomic add
+// is executed lane by lane on this chip (about 2 cycles per active lane, ~120 per full wave instruction, against ~9 for an integer
+// one: profiles/r01_j_ptracer_pmc_summary.txt), and a wave's lanes mostly add to the SAME accumulator: the one light's radiance,
+// the wall the 64 samples of a pixel see.  So the lanes that share a slot are summed across the wave first (DPP, 11 instructions per
+// channel) and ONE lane adds; after MI_SMALL_GROUPS distinct slots the rest falls back to one atomic per lane.
+// Used ONCE per walk, for the radiance sums the lanes carried in registers (Prb1State::rad): doing it at every vertex for every
+// accumulator costs ~45 VALU instructions per group and was measured at no gain (4.76 -> 4.71 ms on BASELINE configs[2]).
+#define MI_SMALL_GROUPS 3
+MI_DEV void small_grad_add_wave(const GradSink1 &sink, int32_t slot, v3 g) {
+    unsigned long long todo = __ballot(slot >= 0);
+    const uint32_t lane_id = threadIdx.x & 63u;
+    for (int round = 0; round < MI_SMALL_GROUPS && todo; ++round) {
+        const int first = (int) __ffsll((long long) todo) - 1;
+        const int32_t s0 = __builtin_amdgcn_readlane(slot, first);
+        const bool mine = slot == s0;                                       // (slot >= 0 follows: s0 >= 0)
+        const float sx = wave_sum(mine ? g.x : 0.f), sy = wave_sum(mine ? g.y : 0.f), sz = wave_sum(mine ? g.z : 0.f);
+        if (lane_id == (uint32_t) first) {
+            const uint32_t c = (threadIdx.x >> 6) & ((1u << sink.copy_shift) - 1u);        // one copy per wave
+            float *gb = sink.s_grad + (((uint32_t) s0) << sink.copy_shift) + c;
+            atomicAdd(gb, sx); atomicAdd(gb + (1u << sink.copy_shift), sy); atomicAdd(gb + (2u << sink.copy_shift), sz);
+        }
+        todo &= ~__ballot(mine);
+        if (mine) slot = -1;
+    }
+    if (slot >= 0) small_grad_add(sink, slot, g);
+}
 
 // One bounce of the one-pass adjoint walk at depth `it` (for a live path the loop counter IS its depth, prb.py:249).
-struct Prb1State { Ray ray; v3 beta, P, prev_p, dL; float prev_bsdf_pdf, eta; bool prev_delta; Pcg32 rng; };
+// `rad_slot`, `rad`: the lane's pending d/d(radiance) of ONE emitter.  Both the emitter that is hit and the emitter that is sampled add
+// to a radiance accumulator at every vertex, and scenes have few emitters: the sum stays in registers for the whole walk and goes to
+// LDS once, summed over the wave (prb_sample_1p); a lane that meets a second emitter flushes the first one on the spot.
+struct Prb1State { Ray ray; v3 beta, P, prev_p, dL; float prev_bsdf_pdf, eta; bool prev_delta; Pcg32 rng; int32_t rad_slot; v3 rad; };
 MI_DEV void prb1_init(Prb1State &st, const Ray &ray, const Pcg32 &rng, v3 dL) {
     st.ray = ray; st.beta = V3(1.f, 1.f, 1.f); st.P = V3(0.f, 0.f, 0.f); st.prev_p = V3(0.f, 0.f, 0.f); st.dL = dL;
-    st.prev_bsdf_pdf = 1.f; st.eta = 1.f; st.prev_delta = true; st.rng = rng;
+    st.prev_bsdf_pdf = 1.f; st.eta = 1.f; st.prev_delta = true; st.rng = rng; st.rad_slot = -1; st.rad = V3(0.f, 0.f, 0.f);
+}
+MI_DEV void radiance_grad_add(Prb1State &st, const GradSink1 &sink, int32_t slot, v3 g) {
+    if (st.rad_slot != slot) {
+        if (st.rad_slot >= 0) small_grad_add(sink, st.rad_slot, st.rad);
+        st.rad_slot = slot; st.rad = V3(0.f, 0.f, 0.f);
+    }
+    st.rad = st.rad + g;
 }
 // `lane_tag` = the workgroup slot the path STARTED in (records and the published L_total * dL are keyed by it).
 template <bool FULL>
@@ -1699,7 +1749,7 @@ MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max
             v3 e = le_front ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);
             Le = (st.beta * le_mis) * e;
             if (le_front && sc.emitters[emitter].grad_slot >= 0)       // d Le / d radiance
-                small_grad_add(sink, sc.emitters[emitter].grad_slot, V3(st.dL.x * st.beta.x * le_mis, st.dL.y * st.beta.y * le_mis, st.dL.z * st.beta.z * le_mis));
+                radiance_grad_add(st, sink, sc.emitters[emitter].grad_slot, V3(st.dL.x * st.beta.x * le_mis, st.dL.y * st.beta.y * le_mis, st.dL.z * st.beta.z * le_mis));
         }
         active_next = active_next && (it + 1 < max_depth);          // prb.py:139
         if (!(it + 1 < max_depth)) st.P = st.P + Le;                   // last vertex: only Le remains (see prb_sample)
@@ -1784,7 +1834,7 @@ MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max
             }
             if (active_em && sc.emitters[ds.emitter].grad_slot >= 0) {                       // d Lr_dir / d radiance
                 v3 w = ((beta_pre * mis_em) * bsdf_value_em) * rcp_(ds.pdf);
-                small_grad_add(sink, sc.emitters[ds.emitter].grad_slot, st.dL * w);
+                radiance_grad_add(st, sink, sc.emitters[ds.emitter].grad_slot, st.dL * w);
             }
         }
         alive = active_next;
@@ -1801,6 +1851,7 @@ MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_de
         MI_SCENE_RELOAD(scb);
         active = prb1_step<FULL>(scb, st, it, max_depth, rr_depth, hide_emitters, active, stk, sink, threadIdx.x, cnt);
     }
+    small_grad_add_wave(sink, st.rad_slot, st.rad);                         // (converged: the loop's exit test is wave-uniform)
     rng = st.rng; L_out = st.P;
 }
 
@@ -2008,7 +2059,11 @@ MI_DEV void pt_grad_add(const PtGradSink &sink, int32_t slot, v3 g) {
     if (slot < 0) return;
     const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
     float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
+#if defined(MI_EXP) && MI_EXP == 3
+    atomicAdd((int *) gb, __float_as_int(g.x)); atomicAdd((int *) gb + (1u << sink.copy_shift), __float_as_int(g.y)); atomicAdd((int *) gb + (2u << sink.copy_shift), __float_as_int(g.z));
+#else
     atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
+#endif
 }
 // connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
 // GRAD: `weight_unit` = weight / radiance of `emitter`; nothing is splatted, the gathered image adjoint goes to the sink.

@@ -37,6 +37,9 @@
 
 #define BLOCK 256
 #define WAVES (BLOCK / 64)
+#ifndef MI_EXP
+#define MI_EXP 0                            // throw-away experiments (tools/*_ab.sh); 0 in every shipped build
+#endif
 #ifndef MI_MIN_WAVES
 #define MI_MIN_WAVES 5                      // k_render*: waves per SIMD the register allocator must leave room for (94 VGPRs; at 6 it spills 20 and gains nothing: profiles/r02_occupancy_ab.txt)
 #endif
@@ -695,6 +698,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     // Walking them with a stride that is coprime to their number puts different pixels into the lanes of one LDS atomic
     // instruction, which would otherwise serialise on the shared table entry (PMC: LDS unit 50 % busy before this).
     const uint32_t stride = n_rec_tex % 61u ? 61u : (n_rec_tex % 67u ? 67u : 1u);
+#if MI_EXP == 2
+    if (a.seed != 0xdeadbeefu) T = 0; else
+#endif
     for (uint32_t e = threadIdx.x; e < n_rec_tex * 4u; e += BLOCK) {
         const uint32_t rec = (uint32_t) (((uint64_t) (e >> 2) * stride) % n_rec_tex), tap = e & 3u;
         const uint32_t g = q_granules - 3u * (rec + 1u);
@@ -722,6 +728,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
                 }
             }
         }
+#if MI_EXP == 1
+        done = true;
+#endif
         if (!done) {
             float *gb = g_grad + tx_off;
             if (tx_c == 3) { atomicAdd(gb + (size_t) idx * 3u, v0); atomicAdd(gb + (size_t) idx * 3u + 1, v1); atomicAdd(gb + (size_t) idx * 3u + 2, v2); }
@@ -735,6 +744,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
         if (key == EMPTY) continue;
         const float v = reinterpret_cast<const float *>(&s_q[ent])[1 + ch];
         const uint32_t tex = key >> 24, off = tex < 32u ? s_texinfo[2 * tex] : (uint32_t) sc.textures[tex].grad_offset;
+#if MI_EXP == 1
+        if (v == 12345.678f)
+#endif
         if (v != 0.f) atomicAdd(g_grad + off + (size_t) (key & 0xffffffu) * 3u + ch, v);
     }
     flush_counters(s_cnt, cnt, g_counters);
