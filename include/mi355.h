@@ -386,6 +386,16 @@ int mi355_debug_lane_radiance(mi355_scene *scene, const mi355_render_params *p,
 int mi355_debug_ray_intersect(mi355_scene *scene, const float *d_rays, uint32_t n,
                               float *d_hits, void *stream);
 
+/* SurfaceInteraction3f of the closest hit of caller-provided rays (Shape::compute_surface_interaction through
+   Scene::ray_intersect, scene.cpp:192-199 + mesh.cpp / rectangle.cpp / sphere.cpp / disk.cpp `compute_surface_interaction`):
+   d_si = n x 24 floats (p3, n3, uv2, sh_frame.n3, wi3, t, shape index bit-cast (0xffffffff: no hit), sh_frame.s3, sh_frame.t3, pad2).
+   The same layout as the oracle's orc_ray_intersect(si_out): the field-by-field parity test of the two. */
+int mi355_debug_surface_interaction(mi355_scene *scene, const float *d_rays, uint32_t n, float *d_si, void *stream);
+
+/* BitmapTexture::eval_3 of texture `texture` (index into the scene's texture table) at caller-provided uv (n x 2 floats):
+   d_rgb = n x 3.  The device side of the texel-centre / wrap-mode identities of src/textures/tests/test_bitmap.py:58-157. */
+int mi355_debug_texture_eval(mi355_scene *scene, uint32_t texture, const float *d_uv, uint32_t n, float *d_rgb, void *stream);
+
 /* Diagnostic builds (-DMI_BVH_STATS, tools/bvh_stats.py): traversal work since the last reset -- out[0] rays that entered the BVH,
    out[1] nodes fetched, out[2] triangles tested, out[3] unused.  All zero in the shipped build. */
 int mi355_debug_bvh_stats(mi355_scene *scene, uint64_t out[4], int reset);

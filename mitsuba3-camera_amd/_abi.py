@@ -120,6 +120,8 @@ SYMBOLS = [
     ("mi355_ptracer_forward_design", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(DesignTangent), C.c_void_p, C.c_void_p]),
     ("mi355_render_forward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_debug_surface_interaction", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_debug_texture_eval", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_set_splat_capacity", C.c_int, [C.c_void_p, C.c_uint32]),
     ("mi355_debug_bvh_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     ("mi355_perspective_projection", None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

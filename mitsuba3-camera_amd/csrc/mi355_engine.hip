@@ -1117,6 +1117,32 @@ __global__ __launch_bounds__(BLOCK) void k_debug_intersect(DScene sc, const floa
     }
 }
 
+// compute_surface_interaction of the closest hit (the FULL variant, like k_debug_intersect): 24 floats per ray, mi355.h
+__global__ __launch_bounds__(BLOCK) void k_debug_si(DScene sc, const float *rays, uint32_t n, float *out) {
+    __shared__ uint32_t smem[WAVES * STACK_WORDS];
+    uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x; bool act = i < n; uint32_t ii = act ? i : 0;
+    Ray r; r.o = ld3(rays + 8 * (size_t) ii); r.d = ld3(rays + 8 * (size_t) ii + 3); r.maxt = rays[8 * (size_t) ii + 6];
+    Hit h = scene_intersect<true>(sc, r, act, stk);
+    if (!act) return;
+    float *o = out + 24 * (size_t) i;
+    for (int k = 0; k < 24; ++k) o[k] = 0.f;
+    o[14] = h.t; o[15] = __uint_as_float(0xffffffffu);
+    if (h.t == MI_INF) return;
+    SI si = compute_si<true>(sc, r, h);
+    o[0] = si.p.x; o[1] = si.p.y; o[2] = si.p.z; o[3] = si.n.x; o[4] = si.n.y; o[5] = si.n.z; o[6] = si.uv.x; o[7] = si.uv.y;
+    o[8] = si.sh_n.x; o[9] = si.sh_n.y; o[10] = si.sh_n.z; o[11] = si.wi.x; o[12] = si.wi.y; o[13] = si.wi.z; o[14] = si.t;
+    o[15] = __uint_as_float((uint32_t) si.shape);
+    o[16] = si.sh_s.x; o[17] = si.sh_s.y; o[18] = si.sh_s.z; o[19] = si.sh_t.x; o[20] = si.sh_t.y; o[21] = si.sh_t.z;
+}
+__global__ __launch_bounds__(BLOCK) void k_debug_texture(DScene sc, uint32_t tex, const float *uv, uint32_t n, float *out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    v2 q; q.x = uv[2 * (size_t) i]; q.y = uv[2 * (size_t) i + 1];
+    v3 c = texture_eval(sc, sc.textures[tex], q, nullptr);
+    out[3 * (size_t) i] = c.x; out[3 * (size_t) i + 1] = c.y; out[3 * (size_t) i + 2] = c.z;
+}
+
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -2397,6 +2423,24 @@ extern "C" int mi355_debug_bvh_stats(mi355_scene *s, uint64_t out[4], int reset)
 extern "C" int mi355_debug_set_splat_capacity(mi355_scene *s, uint32_t records) {
     if (!s) return fail(MI355_ERR_INVALID, "null argument");
     s->splat_cap_override = records; return MI355_OK;
+}
+extern "C" int mi355_debug_surface_interaction(mi355_scene *s, const float *d_rays, uint32_t n, float *d_si, void *stream) {
+    if (!s || !d_rays || !d_si) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!n) return MI355_OK;
+    { int rc = ensure_geometry(s, (hipStream_t) stream); if (rc) return rc; }
+    hipLaunchKernelGGL(k_debug_si, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, d_rays, n, d_si);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_debug_texture_eval(mi355_scene *s, uint32_t texture, const float *d_uv, uint32_t n, float *d_rgb, void *stream) {
+    if (!s || !d_uv || !d_rgb) return fail(MI355_ERR_INVALID, "null argument");
+    if (texture >= s->ds.n_textures) return fail(MI355_ERR_INVALID, "texture index out of range");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!n) return MI355_OK;
+    hipLaunchKernelGGL(k_debug_texture, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, texture, d_uv, n, d_rgb);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
 }
 extern "C" int mi355_debug_ray_intersect(mi355_scene *s, const float *d_rays, uint32_t n, float *d_hits, void *stream) {
     if (!s || !d_rays || !d_hits) return fail(MI355_ERR_INVALID, "null argument");

@@ -2295,7 +2295,7 @@ ORC_API uint64_t orc_render_forward(OScene *sc, const mi355_render_params *rp, c
 /* ----------------------------------------------------------------------------------------
  * ray-level test hooks (Scene::ray_intersect / ray_test on caller rays)
  * rays: n x 8 (o, d, maxt, pad); hits: n x 8 (t, u, v, prim, shape, occluded, -, -);
- * si_out (optional): n x 16 (p3, n3, uv2, sh_n3, wi3, t, pad)
+ * si_out (optional): n x 24 (p3, n3, uv2, sh_n3, wi3, t, shape (0xffffffff: no hit), sh_s3, sh_t3, pad2) -- mi355_debug_surface_interaction's layout
  * ---------------------------------------------------------------------------------------- */
 ORC_API void orc_ray_intersect(OScene *sc, const float *rays, uint32_t n, float *hits, float *si_out) {
     for (uint32_t i = 0; i < n; ++i) {
@@ -2304,9 +2304,15 @@ ORC_API void orc_ray_intersect(OScene *sc, const float *rays, uint32_t n, float 
         float *h = hits + 8 * i; uint32_t occ = (uint32_t) scene_ray_test(sc, &r);
         h[0] = pi.t; h[1] = pi.prim_uv.x; h[2] = pi.prim_uv.y; memcpy(&h[3], &pi.prim_index, 4); memcpy(&h[4], &pi.shape_index, 4); memcpy(&h[5], &occ, 4); h[6] = h[7] = 0;
         if (si_out) {
-            SI si = compute_si(sc, &r, &pi); float *o = si_out + 16 * i;
+            float *o = si_out + 24 * i; uint32_t none = 0xffffffffu;
+            for (int k = 0; k < 24; ++k) o[k] = 0.f;
+            o[14] = pi.t; memcpy(&o[15], &none, 4);
+            if (pi.t == INFINITY) continue;
+            SI si = compute_si(sc, &r, &pi);
             o[0] = si.p.x; o[1] = si.p.y; o[2] = si.p.z; o[3] = si.n.x; o[4] = si.n.y; o[5] = si.n.z; o[6] = si.uv.x; o[7] = si.uv.y;
-            o[8] = si.sh_n.x; o[9] = si.sh_n.y; o[10] = si.sh_n.z; o[11] = si.wi.x; o[12] = si.wi.y; o[13] = si.wi.z; o[14] = si.t; o[15] = 0;
+            o[8] = si.sh_n.x; o[9] = si.sh_n.y; o[10] = si.sh_n.z; o[11] = si.wi.x; o[12] = si.wi.y; o[13] = si.wi.z; o[14] = si.t;
+            memcpy(&o[15], &si.shape, 4);
+            o[16] = si.sh_s.x; o[17] = si.sh_s.y; o[18] = si.sh_s.z; o[19] = si.sh_t.x; o[20] = si.sh_t.y; o[21] = si.sh_t.z;
         }
     }
 }

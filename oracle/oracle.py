@@ -181,7 +181,7 @@ class OracleScene:
     def ray_intersect(self, rays, with_si=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         hits = np.empty((rays.shape[0], 8), dtype=np.float32)
-        si = np.empty((rays.shape[0], 16), dtype=np.float32) if with_si else None
+        si = np.empty((rays.shape[0], 24), dtype=np.float32) if with_si else None
         self.l.orc_ray_intersect(self.h, _p(rays), rays.shape[0], _p(hits), _p(si) if with_si else None)
         return (hits, si) if with_si else hits
 

@@ -16,6 +16,23 @@ from conftest import small_cbox
 
 pytestmark = pytest.mark.gpu
 
+
+def grad_close(a, b, tol=1e-3, what=""):
+    """The north star's gradient bar: max |a - b| <= tol * max |b| (1e-3 unless a test states why not).  The measured ratio of every
+    call is appended to gpurun_out/grad_parity.txt so that the committed profiles/r02_grad_parity.txt shows the margin of each test."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    err = float(np.abs(a - b).max()) / scale
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "grad_parity.txt"), "a") as f:
+            f.write("%-90s max|a-b|/max|b| = %.3e  (bar %.0e, n = %d)\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1] + " " + what, err, tol, a.size))
+    except OSError:
+        pass
+    assert np.isfinite(a).all() and err <= tol, (what, err, tol)
+    return True
+
 FMAX = np.finfo(np.float32).max
 
 
@@ -360,7 +377,7 @@ def test_veach_render_and_backward(mi, orc, torch_cuda, veach64):
     colour = [e for e in lay if e[0] in (mi.abi.PARAM_BSDF_REFLECTANCE, mi.abi.PARAM_TEXTURE_DATA, mi.abi.PARAM_EMITTER_RADIANCE)]
     assert (lay, total) == o.param_layout() and sum(e[3] for e in colour) == 3 + 5 * 3    # grey albedo + 5 emitters; conductors carry none
     assert [e for e in lay if e[0] == mi.abi.PARAM_BSDF_IOR] == [(mi.abi.PARAM_BSDF_IOR, [i for i, b in enumerate(veach64.bsdfs) if b.type == mi.abi.BSDF_DIELECTRIC][0], total - 2, 2)]
-    assert np.allclose(g, g_ref, rtol=2e-2, atol=2e-3 * np.abs(g_ref).max())
+    assert grad_close(g, g_ref, 1e-3)
     # linearity identity for every emitter: d<1, image>/d rad_c = sum(image_c contribution of that emitter) -> sum over emitters = image sum / 1
     tot = sum((g[off:off + 3] * veach64.emitters[i].radiance).sum() for k, i, off, sz in lay if k == mi.abi.PARAM_EMITTER_RADIANCE)
     img6 = integ.render(veach64, seed=6, spp=16).cpu().numpy()
@@ -418,7 +435,10 @@ def test_realisticlens_matches_oracle(mi, orc, torch_cuda, design):
     gin = np.random.default_rng(2).normal(size=(32, 32, 3)).astype(np.float32)
     g = integ.render_backward(scene, params, torch.tensor(gin), seed=9, spp=16).cpu().numpy()
     g_ref = o.render_backward(o.params(integ, 9, 16), gin)
-    assert np.allclose(g, g_ref, rtol=5e-3, atol=2e-3 * np.abs(g_ref).max())
+    # asph_singlet: the same flipped Newton acceptances as in the image above -- a flipped ray adds or removes a whole path's gradient
+    # (measured 3.6e-3 of the largest component with v_rcp / v_rsq, 16 k paths; every other design sits at 1e-6 .. 3e-4; a -DMI_EXACT_MATH
+    # build brings this design to 8.7e-4 and `singlet` from 3.1e-4 to 5.3e-7: profiles/r02_grad_parity.txt)
+    assert grad_close(g, g_ref, 5e-3 if design == "asph_singlet" else 1e-3, design)
     films = {}
     for mode in (mi.abi.MODE_STATIC, mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):      # re-packing carries eta / prev_delta and the lens weight too
         pi = mi.PathIntegrator({"max_depth": 5}); pi.mode = mode
@@ -467,7 +487,7 @@ def test_render_backward_matches_oracle(mi, orc, torch_cuda, textured):
     for kind, index, off, size in lay_gpu:
         a, b = g[off:off + size], g_ref[off:off + size]
         scale = max(np.abs(b).max(), 1e-6)
-        assert np.abs(a - b).max() < 2e-3 * scale, (kind, index, np.abs(a - b).max(), scale)
+        assert grad_close(a, b, 1e-3, "kind %d index %d" % (kind, index))
     # named access
     key = "red.reflectance.value"
     assert np.allclose(params.grad(key).cpu().numpy(), g_ref[[o for k, i, o, s in lay_cpu if k == 0 and scene.bsdfs[i].id == "red"][0]:][:3], rtol=2e-3, atol=1e-5)
@@ -592,7 +612,7 @@ def test_mesh_emitter_and_smooth_conductor(mi, orc, torch_cuda, integrator_name)
     gin = np.random.default_rng(4).normal(size=(32, 32, 3)).astype(np.float32)
     g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
     g_ref = o.render_backward(o.params(integ, 7, 16), gin)
-    assert np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+    assert grad_close(g, g_ref, 1e-3)
 
 
 @pytest.mark.parametrize("scene_name", ["cbox-textured", "veach"])
@@ -707,7 +727,7 @@ def test_film_sample_border_matches_oracle(mi, orc, torch_cuda):
         params.zero_grad()
         g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
         g_ref = o.render_backward(o.params(integ, 7, 16), gin)
-        assert np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+        assert grad_close(g, g_ref, 1e-3)
 
 
 @pytest.mark.parametrize("config", ["area_light_radiance", "directly_visible_area_light_radiance"])
@@ -922,7 +942,7 @@ def test_particle_tracer_radiance_gradients_match_oracle(mi, orc, torch_cuda):
     offs = [l[2] for l in lay if l[0] == mi.abi.PARAM_EMITTER_RADIANCE]
     assert len(offs) == 3
     for off in offs:
-        assert np.abs(ref[off:off + 3]).min() > 0 and np.allclose(g[off:off + 3], ref[off:off + 3], rtol=5e-3, atol=1e-3 * np.abs(ref).max()), (g[off:off + 3], ref[off:off + 3])
+        assert np.abs(ref[off:off + 3]).min() > 0 and grad_close(g[off:off + 3], ref[off:off + 3], 1e-3)
     rest = np.ones(g.shape[0], dtype=bool)
     for off in offs: rest[off:off + 3] = False
     assert (g[rest] == 0).all()
@@ -963,7 +983,7 @@ def test_particle_tracer_all_parameter_gradients(mi, orc, torch_cuda, scene_name
             assert np.abs(a).max() == 0 and np.abs(b).max() == 0
             continue
         assert np.isfinite(a).all() and np.abs(b).max() > 0, (kind, index)
-        assert np.allclose(a, b, rtol=2e-2, atol=3e-3 * np.abs(b).max()), (kind, index, np.abs(a - b).max(), np.abs(b).max())
+        assert grad_close(a, b, 1e-3, "kind %d index %d" % (kind, index))
     only = mi.traverse(scene); only.keep(r".*\.emitter\.radiance\.value")
     g1 = integ.render_backward(scene, only, torch.tensor(gin), seed=6, spp=16).cpu().numpy()
     for kind, index, off, size in lay:
@@ -1053,7 +1073,7 @@ def test_disk_and_directional_area(mi, orc, torch_cuda, case):
         gin = np.random.default_rng(4).normal(size=(32, 32, 3)).astype(np.float32)
         g = integ.render_backward(scene, params, torch.tensor(gin), seed=7, spp=16).cpu().numpy()
         g_ref = o.render_backward(o.params(integ, 7, 16), gin)
-        assert np.abs(g_ref).max() > 0 and np.allclose(g, g_ref, rtol=2e-2, atol=3e-3 * np.abs(g_ref).max())
+        assert np.abs(g_ref).max() > 0 and grad_close(g, g_ref, 1e-3)
 
 
 @pytest.mark.parametrize("scene_name,integrator_name", [("cbox", "path"), ("cbox", "prb"), ("veach", "path")])
@@ -1349,7 +1369,7 @@ def test_render_op_autograd_with_the_particle_tracer(mi, orc, torch_cuda):
             "light.emitter.radiance.value": [o_ for k, i, o_, s in lay if k == mi.abi.PARAM_EMITTER_RADIANCE][0]}
     for k in keys:
         got = leaves[k].grad.cpu().numpy(); ref = g_ref[offs[k]:offs[k] + 3]
-        assert np.abs(ref).max() > 0 and np.allclose(got, ref, rtol=1e-2, atol=1e-3 * np.abs(ref).max()), (k, got, ref)
+        assert np.abs(ref).max() > 0 and grad_close(got, ref, 1e-3, k)
 
 
 def test_errors_are_loud(mi, torch_cuda, cbox32):
@@ -1399,3 +1419,164 @@ def test_lens_focusing_loop(mi, torch_cuda):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     losses, x = mod.main(iterations=20, res=48, spp=32, verbose=False)
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.6 * np.mean(losses[:3]), (losses[:3], losses[-3:], x)
+
+
+def test_full_size_properties_config_4(mi, torch_cuda):
+    """BASELINE configs[3] at its FULL size (the Veach-MIS arrangement, 1024^2 x 512 spp = 5.4e8 camera paths through the FULL kernels:
+    rough conductors, a dielectric sphere, sphere emitters, MIS) through properties that need no oracle run of that size:
+      * the film is linear in the emitter radiances and a factor 2 is exact in fp32: every pixel doubles, up to the order of its atomics;
+      * static lanes, in-workgroup re-packing and path regeneration are three schedules of the SAME samples: identical films;
+      * 16-row tiles dealt to 8 ranks (the multi-GPU decomposition of bench.py) and spp slices accumulate to the whole film;
+      * W channel = sum of filter weights: the same total per sample away from the border."""
+    torch = torch_cuda
+    scene = mi.load_dict(mi.veach_mis_scene(1024))
+    W = H = 1024; spp = 512
+    base = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); base.mode = mi.abi.MODE_STATIC
+    film = base.render(scene, seed=3, spp=spp, develop=False)
+    assert film.shape == (H, W, 4) and torch.isfinite(film).all() and float(film[..., :3].mean()) > 0.0
+    w = film[8:-8, 8:-8, 3]
+    assert float((w / w.mean() - 1).abs().max()) < 0.2
+    # ---- the three schedules
+    for name, mode, regen in (("repack", mi.abi.MODE_FUSED, False), ("wavefront", mi.abi.MODE_WAVEFRONT, False), ("regen", mi.abi.MODE_FUSED, True)):
+        it = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5}); it.mode = mode; it.regen = regen
+        other = it.render(scene, seed=3, spp=spp, develop=False)
+        err = float((other - film).abs().max() / film[..., :3].abs().max())
+        assert torch.allclose(other, film, rtol=3e-4, atol=3e-3 * float(film[..., :3].mean())), (name, err)
+    # ---- linearity in the radiances (all emitters scaled by 2)
+    params = mi.traverse(scene)
+    keys = [k for k in params.keys() if k.endswith("radiance.value")]
+    assert len(keys) >= 4
+    saved = {k: params[k].clone() for k in keys}
+    for k in keys:
+        params[k] = saved[k] * 2
+    params.update()
+    film2 = base.render(scene, seed=3, spp=spp, develop=False)
+    for k in keys:
+        params[k] = saved[k]
+    params.update()
+    assert torch.allclose(film2[..., :3], film[..., :3] * 2, rtol=1e-5, atol=1e-4 * float(film[..., :3].mean())) and torch.allclose(film2[..., 3], film[..., 3], rtol=1e-5)
+    # ---- shard shapes
+    h = scene.handle(); lib = mi.abi.lib()
+    fast = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+    acc = torch.zeros_like(film)
+    for r in range(8):
+        p = fast._params(scene, 3, spp, shard=mi.shard_tiles(W, H, r, 8))
+        mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, film, rtol=3e-4, atol=3e-3 * float(film[..., :3].mean()))
+    acc = torch.zeros_like(film)
+    for s0 in range(0, spp, 128):
+        p = fast._params(scene, 3, spp, spp_shard=(s0, 128))
+        mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, film, rtol=3e-4, atol=3e-3 * float(film[..., :3].mean()))
+    scene.release()
+
+
+def test_surface_interaction_fields_match_oracle(mi, orc, torch_cuda):
+    """SurfaceInteraction3f field by field -- p, n, uv, sh_frame (s, t, n), wi, t, shape -- of the closest hit of the same rays, device
+    (`mi355_debug_surface_interaction`, the compute_si of every kernel) against the oracle (`orc_ray_intersect`'s si_out): rectangles and
+    cube meshes (Cornell box), spheres + rough plates + a dielectric sphere (Veach arrangement), an OBJ-style mesh with vertex normals and
+    texture coordinates in the scene BVH, a disk.  Rays whose two closest hits tie (edges shared by two triangles) may report either
+    primitive and are excluded, as in test_ray_intersect_*."""
+    torch = torch_cuda
+    lib = mi.abi.lib()
+    T = mi.ScalarTransform4f
+    # a UV sphere mesh (vertex normals + uvs, > 64 faces: goes to the BVH) and a disk in front of a Cornell box
+    nu, nv = 24, 12
+    th = np.linspace(0, np.pi, nv + 1)[:, None]; ph = np.linspace(0, 2 * np.pi, nu + 1)[None, :]
+    P = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3).astype(np.float32)
+    UV = np.stack([np.broadcast_to(ph / (2 * np.pi), (nv + 1, nu + 1)), np.broadcast_to(th / np.pi, (nv + 1, nu + 1))], -1).reshape(-1, 2).astype(np.float32)
+    F = []
+    for a in range(nv):
+        for b in range(nu):
+            i0 = a * (nu + 1) + b; i1 = i0 + 1; i2 = i0 + nu + 1; i3 = i2 + 1
+            if a > 0: F.append((i0, i2, i1))
+            if a < nv - 1: F.append((i1, i2, i3))
+    F = np.array(F, dtype=np.uint32)
+    scenes = []
+    scenes.append(mi.load_dict(small_cbox(mi, 32)))
+    scenes.append(mi.load_dict(mi.veach_mis_scene(32)))
+    d = small_cbox(mi, 32)
+    d["ball"] = {"type": "mesh", "vertex_positions": P * 0.3 + np.array([0.1, -0.2, 0.2], np.float32), "vertex_normals": P / np.linalg.norm(P, axis=1, keepdims=True),
+                 "vertex_texcoords": UV, "faces": F, "bsdf": {"type": "diffuse"}}
+    d["coin"] = {"type": "disk", "to_world": T.translate([-0.4, 0.3, 0.4]).rotate([0, 1, 0], 30).scale(0.25), "bsdf": {"type": "diffuse"}}
+    scenes.append(mi.load_dict(d))
+    for scene in scenes:
+        o = orc.OracleScene(scene, mi.abi)
+        rays = _rays_for(scene, o, 8192)
+        hits_ref, si_ref = o.ray_intersect(rays, with_si=True)
+        h = scene.handle()
+        r = torch.tensor(rays, device="cuda"); out = torch.empty((rays.shape[0], 24), dtype=torch.float32, device="cuda")
+        mi.abi.check(lib.mi355_debug_surface_interaction(h, C.c_void_p(r.data_ptr()), rays.shape[0], C.c_void_p(out.data_ptr()), None))
+        torch.cuda.synchronize()
+        si = out.cpu().numpy()
+        shape_ref = si_ref[:, 15].view(np.uint32); shape = si[:, 15].view(np.uint32)
+        valid = (shape_ref != 0xffffffff)
+        same = valid & (shape == shape_ref) & np.isclose(si[:, 14], si_ref[:, 14], rtol=3e-5, atol=3e-6)
+        assert valid.sum() > 0.5 * len(rays) and same.sum() > 0.995 * valid.sum(), (valid.sum(), same.sum())
+        assert ((shape == 0xffffffff) == ~valid).mean() > 0.999
+        # a ray through a shared edge may land on either triangle: the geometric normal / uv then differ legitimately; such rays show up as
+        # a different normal at (almost) the same t -- they must be rare
+        a, b = si[same], si_ref[same]
+        scale = max(1.0, float(np.abs(b[:, 0:3]).max()))
+        fields = {"p": (slice(0, 3), 2e-5 * scale), "n": (slice(3, 6), 2e-5), "uv": (slice(6, 8), 5e-5), "sh_n": (slice(8, 11), 5e-5), "wi": (slice(11, 14), 1e-4),
+                  "sh_s": (slice(16, 19), 1e-4), "sh_t": (slice(19, 22), 1e-4)}
+        for name, (sl, tol) in fields.items():
+            err = np.abs(a[:, sl] - b[:, sl]).max(axis=1)
+            assert (err <= tol).mean() > 0.998, (name, (err <= tol).mean(), err.max())
+        # frames are orthonormal, wi is the local direction towards the ray origin
+        s_, t_, n_ = a[:, 16:19], a[:, 19:22], a[:, 8:11]
+        assert np.abs((s_ * t_).sum(1)).max() < 1e-4 and np.abs((s_ * n_).sum(1)).max() < 1e-4 and np.abs(np.linalg.norm(n_, axis=1) - 1).max() < 1e-4
+        dirs = rays[same, 3:6] / np.linalg.norm(rays[same, 3:6], axis=1, keepdims=True)
+        assert np.abs(a[:, 13] + (dirs * n_).sum(1)).max() < 2e-4
+        scene.release()
+
+
+@pytest.mark.parametrize("wrap_mode", ["repeat", "clamp", "mirror"])
+def test_device_texture_fetch_identities(mi, orc, torch_cuda, wrap_mode):
+    """The reference's own asserts for `bitmap` on the DEVICE texture fetch (`mi355_debug_texture_eval` = the texture_eval every kernel
+    uses), and device == oracle on the same uv:
+      * src/textures/tests/test_bitmap.py:143-157 (test04): uv = ((x + 1/2) / W, (y + 1/2) / H) returns texel (x, y) itself;
+      * src/textures/tests/test_bitmap.py:58-130 (test03): a 20 x 20 grid over [0,1]^2 against the same grid shifted by -1 / +1
+        (repeat: equal; mirror: equal to the reversed grid; clamp: equal to the border row / column), atol 1e-4 as there."""
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    tex = rng.uniform(0.0, 1.0, (8, 8, 3)).astype(np.float32)                 # stands in for noise_8x8.png (the reference's resources are a submodule that is not checked out)
+    d = small_cbox(mi, 8)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True, "wrap_mode": wrap_mode}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    scene = mi.load_dict(d); o = orc.OracleScene(scene, mi.abi)
+    lib = mi.abi.lib(); h = scene.handle()
+
+    def dev_eval(uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        u = torch.tensor(uv, device="cuda"); out = torch.empty((uv.shape[0], 3), dtype=torch.float32, device="cuda")
+        mi.abi.check(lib.mi355_debug_texture_eval(h, 0, C.c_void_p(u.data_ptr()), uv.shape[0], C.c_void_p(out.data_ptr()), None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, o.texture_eval(0, uv))                    # same arithmetic, same bits
+        return got
+
+    def grid(xs, ys):
+        xv, yv = np.meshgrid(xs, ys)                                          # dr.meshgrid: x varies fastest
+        return dev_eval(np.stack([xv.ravel(), yv.ravel()], -1))
+    # test04: texel centres
+    centres = np.array([[(x + 0.5) / 8, (y + 0.5) / 8] for y in range(8) for x in range(8)], dtype=np.float32)
+    assert np.allclose(dev_eval(centres), tex.reshape(-1, 3), atol=1e-6)
+    assert np.allclose(dev_eval([[(7 + 0.5) / 8, (1 + 0.5) / 8]])[0], tex[1, 7], atol=1e-6)   # "coordinates of green pixel: (7, 1)"
+    # test03: wrap modes
+    n = 20
+    lin = lambda a, b: np.linspace(a, b, n, dtype=np.float32)
+    ref = grid(lin(0, 1), lin(0, 1))
+    if wrap_mode == "repeat":
+        assert np.allclose(ref, grid(lin(-1, 0), lin(-1, 0)), atol=1e-4) and np.allclose(ref, grid(lin(1, 2), lin(1, 2)), atol=1e-4)
+    elif wrap_mode == "mirror":
+        assert np.allclose(ref, grid(lin(-1, 0)[::-1], lin(-1, 0)[::-1]), atol=1e-4) and np.allclose(ref, grid(lin(1, 2)[::-1], lin(1, 2)[::-1]), atol=1e-4)
+    else:
+        r3 = ref.reshape(n, n, 3)
+        assert np.allclose(np.broadcast_to(r3[:1], (n, n, 3)), grid(lin(0, 1), lin(-1, 0)).reshape(n, n, 3), atol=1e-4)      # top: the first row, everywhere
+        assert np.allclose(np.broadcast_to(r3[-1:], (n, n, 3)), grid(lin(0, 1), lin(1, 2)).reshape(n, n, 3), atol=1e-4)     # bottom
+        assert np.allclose(np.broadcast_to(r3[:, :1], (n, n, 3)), grid(lin(-1, 0), lin(0, 1)).reshape(n, n, 3), atol=1e-4)   # left
+        assert np.allclose(np.broadcast_to(r3[:, -1:], (n, n, 3)), grid(lin(1, 2), lin(0, 1)).reshape(n, n, 3), atol=1e-4)  # right
+    scene.release()

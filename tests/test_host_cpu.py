@@ -216,7 +216,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, width=32, height=32, sample_border=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -226,6 +226,9 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = small_cbox(mi, 32)
+    d["sensor"]["film"]["width"] = width; d["sensor"]["film"]["height"] = height
+    if sample_border:
+        d["sensor"]["film"]["sample_border"] = True
     tex = np.random.default_rng(12345).uniform(0.2, 0.8, (4, 4, 3)).astype(np.float32)
     d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}
     d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
@@ -248,7 +251,7 @@ def _worker(rank, world, port, out_dir):
 
     integ = mi.PRBIntegrator({"max_depth": 4}); integ.backend = OracleBackend()
     img = integ.render(scene, seed=3, spp=4, shard=(rank, world))
-    gin = np.random.default_rng(5).normal(size=(32, 32, 3)).astype(np.float32)
+    gin = np.random.default_rng(5).normal(size=(height, width, 3)).astype(np.float32)
     g = integ.render_backward(scene, None, torch.from_numpy(gin), seed=9, spp=4, shard=(rank, world))
     np.save(os.path.join(out_dir, "img%d.npy" % rank), img.numpy()); np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
     pt = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 3}); pt.backend = OracleBackend()     # the light tracer shards over the FILM grid
@@ -279,6 +282,32 @@ def test_two_rank_sharding_over_gloo(mi, orc, tmp_path):
         assert np.allclose(np.load(tmp_path / ("pimg%d.npy" % r)), pimg_ref, rtol=1e-4, atol=1e-6)
         assert np.allclose(np.load(tmp_path / ("pg%d.npy" % r)), pg_ref, rtol=1e-3, atol=1e-5 * np.abs(pg_ref).max())
     assert np.abs(g_ref).max() > 0
+
+
+def test_three_rank_sharding_ragged_tiles_and_sample_border(mi, orc, tmp_path):
+    """world_size = 3 over gloo on a 40 x 56 film with `sample_border`: the sampled grid is (40 + 2 b) x (56 + 2 b) with b = the filter's
+    border, i.e. 60 rows of 44 lanes = three 16-row tiles and a ragged fourth of 12 rows, dealt 0, 1, 2, 0 -- rank 0 owns two tiles of
+    different size, ranks 1 and 2 one each.  Image, PRB gradient, light-traced image and its gradient are the whole job's on every rank."""
+    import torch.multiprocessing as mp
+    from conftest import small_cbox
+    W, H = 40, 56
+    d = small_cbox(mi, 32); d["sensor"]["film"]["width"] = W; d["sensor"]["film"]["height"] = H; d["sensor"]["film"]["sample_border"] = True
+    film = mi.load_dict(d).sensor.film
+    b = film.border_size if hasattr(film, "border_size") else int(np.ceil(film.rfilter.radius - 0.5))
+    assert b >= 1
+    gw, gh = W + 2 * b, H + 2 * b
+    tiles = [mi.shard_tiles(gw, gh, r, 3) for r in range(3)]
+    assert sum(t[1] for t in tiles) == gw * gh and len({t[1] for t in tiles}) >= 2 and (gh % 16) != 0      # ragged: the ranks' lane counts differ
+    port = _free_port()
+    mp.start_processes(_worker, args=(3, port, str(tmp_path), W, H, True), nprocs=3, join=True, start_method="spawn")
+    img_ref = np.load(tmp_path / "img_ref.npy"); g_ref = np.load(tmp_path / "g_ref.npy")
+    pimg_ref = np.load(tmp_path / "pimg_ref.npy"); pg_ref = np.load(tmp_path / "pg_ref.npy")
+    assert img_ref.shape == (H, W, 3) and img_ref.max() > 0 and np.abs(g_ref).max() > 0 and pimg_ref.max() > 0 and np.abs(pg_ref).max() > 0
+    for r in range(3):
+        assert np.allclose(np.load(tmp_path / ("img%d.npy" % r)), img_ref, rtol=1e-5, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / ("g%d.npy" % r)), g_ref, rtol=1e-4, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / ("pimg%d.npy" % r)), pimg_ref, rtol=1e-4, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / ("pg%d.npy" % r)), pg_ref, rtol=1e-3, atol=1e-5 * np.abs(pg_ref).max())
 
 
 def test_huge_jobs_are_split_into_passes(mi):

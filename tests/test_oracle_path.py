@@ -167,8 +167,45 @@ def test_backward_with_rr_is_unbiased_estimate_of_fd(mi, orc):
     assert np.all(np.abs(g - fd) < 0.15 * np.abs(fd)), (g, fd)
 
 
+@pytest.mark.parametrize("wrap_mode", ["repeat", "clamp", "mirror"])
+def test_texture_wrap_modes_follow_the_reference_tests(mi, orc, wrap_mode):
+    """The reference's own asserts for `bitmap`, enforced on the oracle's texture fetch (the device fetch is held to the same asserts and
+    to bit-equality with this one in test_gpu_parity.py::test_device_texture_fetch_identities):
+      * src/textures/tests/test_bitmap.py:143-157 (test04): uv = ((x + 1/2) / W, (y + 1/2) / H) returns texel (x, y);
+      * src/textures/tests/test_bitmap.py:58-130 (test03): a 20 x 20 grid over [0,1]^2 equals the grid shifted by -1 / +1 (repeat), the
+        reversed shifted grid (mirror), the border row / column (clamp); atol 1e-4 as there.
+    This pins the dr::Texture2f convention (pos = uv * res - 1/2, 4-tap lerp, wrap applied to the integer taps) to the reference's tests;
+    the image (noise_8x8.png) is replaced by random 8 x 8 RGB data -- the reference's resources submodule is not checked out."""
+    tex = np.random.default_rng(8).uniform(0.0, 1.0, (8, 8, 3)).astype(np.float32)
+    d = small_cbox(mi, 8)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True, "wrap_mode": wrap_mode}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    sc = mi.load_dict(d); o = orc.OracleScene(sc, mi.abi)
+
+    def grid(xs, ys):
+        xv, yv = np.meshgrid(xs, ys)
+        return o.texture_eval(0, np.stack([xv.ravel(), yv.ravel()], -1).astype(np.float32))
+    centres = np.array([[(x + 0.5) / 8, (y + 0.5) / 8] for y in range(8) for x in range(8)], dtype=np.float32)
+    assert np.allclose(o.texture_eval(0, centres), tex.reshape(-1, 3), atol=1e-6)
+    assert np.allclose(o.texture_eval(0, np.array([[(7 + 0.5) / 8, (1 + 0.5) / 8]], dtype=np.float32))[0], tex[1, 7], atol=1e-6)
+    n = 20
+    lin = lambda a, b: np.linspace(a, b, n, dtype=np.float32)
+    ref = grid(lin(0, 1), lin(0, 1))
+    if wrap_mode == "repeat":
+        assert np.allclose(ref, grid(lin(-1, 0), lin(-1, 0)), atol=1e-4) and np.allclose(ref, grid(lin(1, 2), lin(1, 2)), atol=1e-4)
+    elif wrap_mode == "mirror":
+        assert np.allclose(ref, grid(lin(-1, 0)[::-1], lin(-1, 0)[::-1]), atol=1e-4) and np.allclose(ref, grid(lin(1, 2)[::-1], lin(1, 2)[::-1]), atol=1e-4)
+    else:
+        r3 = ref.reshape(n, n, 3)
+        assert np.allclose(np.broadcast_to(r3[:1], (n, n, 3)), grid(lin(0, 1), lin(-1, 0)).reshape(n, n, 3), atol=1e-4)
+        assert np.allclose(np.broadcast_to(r3[-1:], (n, n, 3)), grid(lin(0, 1), lin(1, 2)).reshape(n, n, 3), atol=1e-4)
+        assert np.allclose(np.broadcast_to(r3[:, :1], (n, n, 3)), grid(lin(-1, 0), lin(0, 1)).reshape(n, n, 3), atol=1e-4)
+        assert np.allclose(np.broadcast_to(r3[:, -1:], (n, n, 3)), grid(lin(1, 2), lin(0, 1)).reshape(n, n, 3), atol=1e-4)
+
+
 def test_texture_lookup(mi, orc):
-    """dr::Texture2f convention [Dr.Jit, recalled; parity unpinned in-tree]: texel centres at (i+0.5)/res, repeat wrap."""
+    """dr::Texture2f convention (texel centres at (i+0.5)/res, repeat wrap), hand-computed taps; the reference's asserts for the same
+    convention are enforced in test_texture_wrap_modes_follow_the_reference_tests."""
     d = small_cbox(mi, 8)
     tex = np.arange(2 * 4 * 3, dtype=np.float32).reshape(2, 4, 3)
     d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex / 100, "raw": True}}
