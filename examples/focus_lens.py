@@ -3,8 +3,9 @@
 
 The fork's notebooks (notebooks/doublet_full_optim.ipynb, scripts/lens_design/design_problem.py) optimise lens scalars by rendering
 `directionalarea` sources through lens MESHES with `ptracer` and differentiating the image with respect to the mesh vertices.  This is
-that loop with one scalar: the image gradient d(image)/d(position) comes from the vertex forward mode
-(ParticleTracerIntegrator.render_forward_geometry), the loss is the spot's second moment, the update is plain gradient descent.
+that loop with one scalar: the scene is created once, `params['lens.vertex_positions']` is rewritten every iteration (BVH refit on the
+device), the gradient comes from the reverse-mode geometry adjoint behind mi.render, the loss is the spot's second moment, the update is
+plain gradient descent.  (mitsuba3-camera_amd/lens_design.py is the full mirror of the notebooks' DesignProblem: ~30 scalars, Adam.)
     python examples/focus_lens.py            # needs the GPU
 """
 import os
@@ -52,38 +53,45 @@ def scene_dict(mi, x, res):
 
 
 def spot_loss(img):
-    """Second moment of the image about its centroid (the RMS spot size squared, in pixels^2) and its derivative d loss / d image."""
+    """Second moment of the image about its centroid (the RMS spot size squared, in pixels^2), differentiable in torch."""
     import torch
     lum = img.sum(dim=2)
     h, w = lum.shape
     ys, xs = torch.meshgrid(torch.arange(h, device=img.device, dtype=torch.float32), torch.arange(w, device=img.device, dtype=torch.float32), indexing="ij")
-    lum = lum.clone().requires_grad_(True)
     tot = lum.sum()
     cx, cy = (lum * xs).sum() / tot, (lum * ys).sum() / tot
-    loss = (lum * ((xs - cx) ** 2 + (ys - cy) ** 2)).sum() / tot
-    loss.backward()
-    return float(loss.detach()), lum.grad[..., None].expand(h, w, 3)
+    return (lum * ((xs - cx) ** 2 + (ys - cy) ** 2)).sum() / tot
 
 
 def main(iterations=25, res=64, spp=64, x0=-0.9, lr=0.01, verbose=True):
+    """The notebooks' loop: ONE scene; every iteration writes the lens mesh's `vertex_positions` (a function of the design scalar x) into
+    the scene parameters -- the device replica refits its BVH and recomputes the vertex normals, it is not rebuilt -- renders with the
+    particle tracer and back-propagates the spot loss through the reverse-mode geometry adjoint (mi.render is a torch.autograd op)."""
     import torch
     mi = load_package()
     integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 100})
-    nv = icosphere(3)[0].shape[0]
-    tangent = np.tile(np.array([1, 0, 0], dtype=np.float32), (nv, 1))      # d(vertex) / d(x): the ball slides along the beam
-    x, losses = x0, []
+    scene = mi.load_dict(scene_dict(mi, x0, res))
+    params = mi.traverse(scene)
+    key = "lens.vertex_positions"
+    v, _ = icosphere(3)
+    base = torch.tensor(v * 0.5, device="cuda")                                 # the ball about the origin
+    axis = torch.tensor([1.0, 0.0, 0.0], device="cuda")                         # d(vertex) / d(x): it slides along the beam
+    x = torch.tensor(float(x0), device="cuda", requires_grad=True)
+    losses = []
     for it in range(iterations):
-        scene = mi.load_dict(scene_dict(mi, x, res))
-        img = integ.render(scene, seed=it, spp=spp)
-        loss, dloss_dimg = spot_loss(img)
-        dimg_dx = integ.render_forward_geometry(scene, "lens", tangent, seed=it, spp=spp)
-        grad = float((dloss_dimg * dimg_dx).sum())
-        x -= lr * float(np.clip(grad, -10.0, 10.0))
-        losses.append(loss)
-        scene.release()
+        params[key] = (base + x * axis).reshape(-1)                              # differentiable w.r.t. x; pushed by mi.render
+        img = mi.render(scene, params, integrator=integ, seed=it, spp=spp)
+        loss = spot_loss(img)
+        loss.backward()
+        grad = float(x.grad)
+        with torch.no_grad():
+            x -= lr * max(-10.0, min(10.0, grad))
+            x.grad.zero_()
+        losses.append(float(loss.detach()))
         if verbose:
-            print("it %2d  x = %+.4f  spot second moment = %8.3f px^2  d/dx = %+8.3f" % (it, x, loss, grad))
-    return losses, x
+            print("it %2d  x = %+.4f  spot second moment = %8.3f px^2  d/dx = %+8.3f" % (it, float(x), losses[-1], grad))
+    scene.release()
+    return losses, float(x)
 
 
 if __name__ == "__main__":

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 7u
+#define MI355_ABI_VERSION 8u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -368,6 +368,21 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
    out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6] analytic spheres,
    out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres, 4: realisticlens sensor; any bit -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
+
+/* ---- multi-GPU exchange ------------------------------------------------------------------------------------------
+   One process per GPU, every rank holds the whole scene and renders its shard (pixel range, interleaved tiles or spp slice of
+   mi355_render_params).  The only exchange of the path is a SUM over the ranks of (a) the RGBW film accumulator before develop,
+   (b) PRB's splatted weight image, (c) the parameter-gradient buffer.  This library links no communication library: a caller that wants
+   the exchange inside the calls registers a hook that sums `count` floats of device memory over all ranks IN PLACE, ordered on
+   `stream` (the shim of INTEGRATION.md section 4 does it with one ncclAllReduce on its RCCL communicator; the Python host layer leaves
+   the hook unset and calls torch.distributed itself).  With a hook set:
+     mi355_render            accumulate -> hook(film, W*H*4) -> develop   (Integrator::render of the whole job on every rank)
+     mi355_prb_splat_weights kernel -> hook(weight, W*H)
+     mi355_render_backward   kernels -> hook(grad_params, total_floats)     (d_grad_params must be zero on entry on all ranks but one)
+   mi355_render_accumulate never calls it.  The hook is a collective: every rank reaches it, also a rank whose shard is empty.  It
+   returns 0 on success; anything else fails the call with MI355_ERR_DEVICE.  fn = NULL removes the hook. */
+typedef int (*mi355_reduce_fn)(void *user, float *d_buffer, uint64_t count, void *stream);
+int mi355_set_reduce_hook(mi355_scene *scene, mi355_reduce_fn fn, void *user);
 
 /* realisticlens with sample_exit_pupil: the 64 (min.x, min.y, max.x, max.y) exit-pupil bounds the scene was created with
    (compute_exit_pupil_bounds, realisticlens.cpp:1772-1806).  out = 256 floats of host memory. */

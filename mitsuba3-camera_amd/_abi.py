@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -120,6 +120,7 @@ SYMBOLS = [
     ("mi355_ptracer_forward_design", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(DesignTangent), C.c_void_p, C.c_void_p]),
     ("mi355_render_forward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_debug_ray_intersect", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_set_reduce_hook", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_debug_surface_interaction", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_texture_eval", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_debug_set_splat_capacity", C.c_int, [C.c_void_p, C.c_uint32]),
@@ -128,6 +129,9 @@ SYMBOLS = [
                                             C.c_float, C.c_float, C.c_float, f32p]),
     ("mi355_gaussian_coeffs", None, [C.c_float, f32p]),
 ]
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)     # mi355_reduce_fn
 
 
 class Mi355Error(RuntimeError):

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libmi355.so")
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-munsafe-fp-atomics", "-fno-gpu-rdc",
-    "-Wall", "-Wno-unused-function",
+    "-Wall", "-Wno-unused-function", "-ldl",
 ]
 
 

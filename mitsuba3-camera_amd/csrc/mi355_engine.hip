@@ -35,6 +35,40 @@
 #include <numeric>
 #include <array>
 
+#include <dlfcn.h>
+
+// ---- roctx ranges named after the reference's ProfilerPhase list (include/mitsuba/core/profiler.h:15-113) ----------------------------
+// The marker library is never a link-time dependency: the ranges are emitted when librocprofiler-sdk-roctx.so (or the older
+// libroctx64.so) is ALREADY loaded in the process -- which is what `rocprofv3 --marker-trace` arranges -- or when MI355_ROCTX=1 asks for
+// it to be loaded.  Otherwise every Phase is two null checks.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        const char *libs[] = { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" };
+        const char *want = getenv("MI355_ROCTX");
+        void *h = nullptr;
+        for (const char *l : libs) if (!h) h = dlopen(l, RTLD_LAZY | RTLD_NOLOAD);
+        if (!h && want && want[0] == '1') for (const char *l : libs) if (!h) h = dlopen(l, RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char *)) dlsym(h, "roctxRangePushA"); pop = (int (*)()) dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+struct Phase {                                                             // ScopedPhase, profiler.h:72-110
+    explicit Phase(const char *name) { if (roctx().push) roctx().push(name); }
+    ~Phase() { if (roctx().pop) roctx().pop(); }
+    Phase(const Phase &) = delete; Phase &operator=(const Phase &) = delete;
+};
+// profiler_phase_id[] strings of the phases a host-visible call of this engine corresponds to (the finer phases -- RayIntersect,
+// BSDFSample, ImageBlockPut ... -- are fused into one kernel here and show up as that kernel in the kernel trace)
+constexpr const char *PHASE_INIT_SCENE = "Scene initialization", *PHASE_INIT_ACCEL = "Acceleration data structure creation",
+                     *PHASE_RENDER = "Integrator::render()", *PHASE_RENDER_FORWARD = "Integrator::render_forward()",
+                     *PHASE_RENDER_BACKWARD = "Integrator::render_backward()", *PHASE_DEVELOP = "Film::develop()",
+                     *PHASE_PARAMS = "Scene::parameters_changed()";
+}
+
 #define BLOCK 256
 #define WAVES (BLOCK / 64)
 #ifndef MI_EXP
@@ -1228,6 +1262,7 @@ extern "C" void mi355_gaussian_coeffs(float stddev, float out_coeff[10]) {
 // ---- scene object --------------------------------------------------------------------------------
 #define MAX_EVENTS 64
 struct mi355_scene {
+    mi355_reduce_fn reduce_fn = nullptr; void *reduce_user = nullptr;      // mi355_set_reduce_hook: in-place SUM over the ranks of a device buffer
     int device = 0;
     DScene ds;                                  // kernel argument (device pointers inside)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
@@ -1352,6 +1387,7 @@ static uint32_t bvh4_collapse(const std::vector<BinNode> &bn, int32_t b, std::ve
 }
 // builds s->bvh, s->tris / tri_face / tri_shape (leaf order) and the refit level lists from the host mirrors of the BVH shapes
 static int build_scene_bvh(mi355_scene *s) {
+    Phase ph(PHASE_INIT_ACCEL);
     s->bvh.clear(); s->tris.clear(); s->tri_face.clear(); s->tri_shape.clear(); s->bvh_levels.clear(); s->bvh_level_off.assign(1, 0u);
     if (s->bvh_shapes.empty()) return MI355_OK;
     std::vector<BuildRef> refs;
@@ -1838,6 +1874,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
 }
 
 extern "C" int mi355_scene_create(const mi355_scene_desc *desc, int device, mi355_scene **out) {
+    Phase ph(PHASE_INIT_SCENE);
     if (!desc || !out) return fail(MI355_ERR_INVALID, "null argument");
     if (desc->abi_version != MI355_ABI_VERSION) return fail(MI355_ERR_INVALID, "ABI version mismatch");
     int n_dev = 0;
@@ -1905,6 +1942,7 @@ static int rebuild_flat_tables(mi355_scene *s) {
 // positions changed.  Work is issued on `st`, the stream of the call that needs it.
 static int ensure_geometry(mi355_scene *s, hipStream_t st) {
     if (!s->geom_dirty) return MI355_OK;
+    Phase ph(PHASE_PARAMS);                                                 // Mesh::parameters_changed + Scene::parameters_changed: normals, refit
     bool refit = false, reflatten = false, shapes_changed = false, cdf_changed = false;
     for (uint32_t i = 0; i < s->shapes.size(); ++i) {
         if (!s->dirty[i]) continue;
@@ -2008,6 +2046,7 @@ extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t ind
     return MI355_OK;
 }
 extern "C" int mi355_scene_set_param_device(mi355_scene *s, uint32_t kind, uint32_t index, const float *d_values, uint64_t count, void *stream) {
+    Phase ph(PHASE_PARAMS);
     if (!s || !d_values) return fail(MI355_ERR_INVALID, "null argument");
     if (kind == MI355_PARAM_VERTEX_POSITIONS || kind == MI355_PARAM_BSDF_IOR) return set_geometry_param(s, kind, index, d_values, count, true, (hipStream_t) stream);
     float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
@@ -2085,6 +2124,7 @@ struct Timed {
 };
 
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
+    Phase ph(PHASE_RENDER);
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
     if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT && p->mode != MI355_MODE_STATIC) return fail(MI355_ERR_INVALID, "unknown mode");
@@ -2175,7 +2215,21 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     s->n_gen += (uint64_t) a.n_local * a.passes; s->n_splat += (uint64_t) a.n_local * a.passes;
     return MI355_OK;
 }
+// The multi-GPU exchange of SURVEY 8(e), without a communication library in this one: the caller's hook sums a device buffer over all
+// ranks in place (RCCL ncclAllReduce on `stream` in the shim of INTEGRATION.md section 4).  Collective: every rank reaches it, also one
+// whose shard is empty.
+static int reduce_hook(mi355_scene *s, float *d_buffer, uint64_t count, void *stream) {
+    if (!s->reduce_fn) return MI355_OK;
+    const int rc = s->reduce_fn(s->reduce_user, d_buffer, count, stream);
+    return rc ? fail(MI355_ERR_DEVICE, "the reduce hook reported a failure") : MI355_OK;
+}
+extern "C" int mi355_set_reduce_hook(mi355_scene *s, mi355_reduce_fn fn, void *user) {
+    if (!s) return fail(MI355_ERR_INVALID, "null scene");
+    s->reduce_fn = fn; s->reduce_user = user;
+    return MI355_OK;
+}
 extern "C" int mi355_film_develop(mi355_scene *s, const float *d_film_rgbw, float *d_image_rgb, void *stream) {
+    Phase ph(PHASE_DEVELOP);
     if (!s || !d_film_rgbw || !d_image_rgb) return fail(MI355_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     uint32_t n = s->ds.crop_w * s->ds.crop_h;
@@ -2188,6 +2242,7 @@ extern "C" int mi355_render(mi355_scene *s, const mi355_render_params *p, float 
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemsetAsync(d_film_rgbw, 0, (size_t) s->ds.crop_w * s->ds.crop_h * 16, (hipStream_t) stream));
     int rc = mi355_render_accumulate(s, p, d_film_rgbw, stream); if (rc) return rc;
+    if ((rc = reduce_hook(s, d_film_rgbw, (uint64_t) s->ds.crop_w * s->ds.crop_h * 4u, stream))) return rc;   // the film of the whole job
     if (d_image_rgb) return mi355_film_develop(s, d_film_rgbw, d_image_rgb, stream);
     return MI355_OK;
 }
@@ -2195,12 +2250,14 @@ extern "C" int mi355_prb_splat_weights(mi355_scene *s, const mi355_render_params
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_weight) return fail(MI355_ERR_INVALID, "null weight buffer");
     HIP_TRY(hipSetDevice(s->device));
-    if (a.n_local == 0) return MI355_OK;
-    hipLaunchKernelGGL(k_splat_weights, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, a, d_weight);
-    HIP_TRY(hipGetLastError());
-    return MI355_OK;
+    if (a.n_local != 0) {
+        hipLaunchKernelGGL(k_splat_weights, dim3((a.n_local + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, a, d_weight);
+        HIP_TRY(hipGetLastError());
+    }
+    return reduce_hook(s, d_weight, (uint64_t) s->ds.crop_w * s->ds.crop_h, stream);
 }
 extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p, const float *d_tangent_params, float *d_film_rgbw, void *stream) {
+    Phase ph(PHASE_RENDER_FORWARD);
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_tangent_params || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
     if (p->integrator != MI355_INTEGRATOR_PATH && p->integrator != MI355_INTEGRATOR_PRB) return fail(MI355_ERR_UNSUPPORTED, "render_forward is built for the path / prb integrators");
@@ -2219,6 +2276,7 @@ extern "C" int mi355_render_forward(mi355_scene *s, const mi355_render_params *p
     return MI355_OK;
 }
 extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_params *p, const mi355_design_tangent *t, float *d_film_rgbw, void *stream) {
+    Phase ph(PHASE_RENDER_FORWARD);
     if (!s || !p || !t || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
     if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_INVALID, "mi355_ptracer_forward_design runs the particle tracer: set integrator = MI355_INTEGRATOR_PTRACER");
     if (t->shape != MI355_NONE) {
@@ -2260,8 +2318,14 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }
+static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream);
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,
                                      float *d_grad_params, void *stream) {
+    Phase ph(PHASE_RENDER_BACKWARD);
+    int rc = render_backward_impl(s, p, d_grad_in, d_weight, d_grad_params, stream); if (rc) return rc;
+    return reduce_hook(s, d_grad_params, s->grad_total, stream);             // the gradient of the whole job, on every rank
+}
+static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     const bool pt = p->integrator == MI355_INTEGRATOR_PTRACER;
     if (!d_grad_in || (!d_weight && !pt) || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");

@@ -527,6 +527,12 @@ class Scene:
         self._handle, self._device = h, device
         return h
 
+    def set_reduce_hook(self, fn):
+        """mi355_set_reduce_hook: `fn(user, d_buffer, count, stream) -> int` sums a device buffer over all ranks in place (None removes
+        it).  The host layer itself exchanges through torch.distributed and leaves the hook unset; this is the C shim's route."""
+        self._reduce_cb = abi.REDUCE_FN(fn) if fn is not None else None      # (kept alive with the scene)
+        abi.check(abi.lib().mi355_set_reduce_hook(self.handle(), C.cast(self._reduce_cb, C.c_void_p) if fn is not None else None, None))
+
     def info(self):
         """Geometry organisation of the device replica (mi355_scene_info)."""
         out = (C.c_uint32 * 8)()

@@ -1412,8 +1412,9 @@ def test_particle_tracer_ior_forward_mode(mi, torch_cuda):
 
 
 def test_lens_focusing_loop(mi, torch_cuda):
-    """examples/focus_lens.py: the notebooks' design loop with one scalar -- light-traced image, spot-size loss, image gradient from the
-    vertex forward mode, gradient descent: the spot shrinks."""
+    """examples/focus_lens.py: the notebooks' design loop with one scalar -- ONE scene whose lens mesh is rewritten through
+    params['lens.vertex_positions'] every iteration (device refit), light-traced image, spot-size loss back-propagated through the
+    reverse-mode geometry adjoint behind mi.render, gradient descent: the spot shrinks."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("focus_lens", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "focus_lens.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
@@ -1579,4 +1580,56 @@ def test_device_texture_fetch_identities(mi, orc, torch_cuda, wrap_mode):
         assert np.allclose(np.broadcast_to(r3[-1:], (n, n, 3)), grid(lin(0, 1), lin(1, 2)).reshape(n, n, 3), atol=1e-4)     # bottom
         assert np.allclose(np.broadcast_to(r3[:, :1], (n, n, 3)), grid(lin(-1, 0), lin(0, 1)).reshape(n, n, 3), atol=1e-4)   # left
         assert np.allclose(np.broadcast_to(r3[:, -1:], (n, n, 3)), grid(lin(1, 2), lin(0, 1)).reshape(n, n, 3), atol=1e-4)  # right
+    scene.release()
+
+
+def test_reduce_hook(mi, torch_cuda):
+    """mi355_set_reduce_hook (SURVEY 8(e) through the C ABI): the hook is called once per exchange with the right buffer sizes -- the RGBW
+    film between accumulate and develop, PRB's weight image, the gradient buffer -- on the call's stream; its failure fails the call.
+    The hook used here plays "two ranks that rendered the same shard": it doubles the buffer (hipMemcpy into a torch tensor and back on
+    the null stream).  The developed image is then unchanged (RGB and W both double), the weight image and the gradients double."""
+    torch = torch_cuda
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; hip.hipMemcpy.restype = C.c_int
+    scene = mi.load_dict(small_cbox(mi, 32))
+    integ = mi.PRBIntegrator({"max_depth": 4})
+    lib = mi.abi.lib(); h = scene.handle()
+    W = H = 32
+    calls = []
+    def double(user, ptr, count, stream):
+        calls.append(int(count))
+        tmp = torch.empty(int(count), dtype=torch.float32, device="cuda")
+        if hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(ptr), int(count) * 4, 3) != 0: return 1      # hipMemcpyDeviceToDevice (synchronising)
+        tmp *= 2; torch.cuda.synchronize()
+        return 0 if hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(tmp.data_ptr()), int(count) * 4, 3) == 0 else 1
+    film = torch.zeros((H, W, 4), device="cuda"); img = torch.zeros((H, W, 3), device="cuda"); img2 = torch.zeros_like(img); film2 = torch.zeros_like(film)
+    p = integ._params(scene, 3, 8)
+    mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), None))
+    wgt = torch.zeros((H, W), device="cuda"); mi.abi.check(lib.mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(wgt.data_ptr()), None))
+    total = scene.info()["grad_floats"]
+    gin = torch.ones((H, W, 3), device="cuda"); g = torch.zeros(total, device="cuda")
+    mi.abi.check(lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), C.c_void_p(wgt.data_ptr()), C.c_void_p(g.data_ptr()), None))
+    torch.cuda.synchronize()
+    scene.set_reduce_hook(double)
+    mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None))
+    wgt2 = torch.zeros((H, W), device="cuda"); mi.abi.check(lib.mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(wgt2.data_ptr()), None))
+    g2 = torch.zeros(total, device="cuda")
+    mi.abi.check(lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), C.c_void_p(wgt.data_ptr()), C.c_void_p(g2.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert calls == [W * H * 4, W * H, total]
+    assert torch.allclose(film2, 2 * film, rtol=1e-5, atol=1e-6) and torch.allclose(img2, img, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(wgt2, 2 * wgt, rtol=1e-5) and float(g.abs().max()) > 0 and torch.allclose(g2, 2 * g, rtol=1e-4, atol=1e-6 * float(g.abs().max()))
+    # mi355_render_accumulate is the raw shard and never exchanges; an empty shard still reaches the hook (it is a collective)
+    n = len(calls)
+    acc = torch.zeros_like(film); mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(acc.data_ptr()), None)); torch.cuda.synchronize()
+    assert len(calls) == n and torch.allclose(acc, film, rtol=1e-5, atol=1e-6)
+    pe = integ._params(scene, 3, 8, shard=(W * H, 0))
+    mi.abi.check(lib.mi355_render(h, C.byref(pe), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None)); torch.cuda.synchronize()
+    assert len(calls) == n + 1 and float(film2.abs().max()) == 0.0
+    # a failing hook fails the call
+    scene.set_reduce_hook(lambda user, ptr, count, stream: 7)
+    assert lib.mi355_render(h, C.byref(p), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None) == mi.abi.ERR_DEVICE
+    scene.set_reduce_hook(None)
+    mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None)); torch.cuda.synchronize()
+    assert torch.allclose(film2, film, rtol=1e-5, atol=1e-6)
     scene.release()
