@@ -1586,22 +1586,21 @@ def test_device_texture_fetch_identities(mi, orc, torch_cuda, wrap_mode):
 def test_reduce_hook(mi, torch_cuda):
     """mi355_set_reduce_hook (SURVEY 8(e) through the C ABI): the hook is called once per exchange with the right buffer sizes -- the RGBW
     film between accumulate and develop, PRB's weight image, the gradient buffer -- on the call's stream; its failure fails the call.
-    The hook used here plays "two ranks that rendered the same shard": it doubles the buffer (hipMemcpy into a torch tensor and back on
-    the null stream).  The developed image is then unchanged (RGB and W both double), the weight image and the gradients double."""
+    The hook used here plays "two ranks that rendered the same shard": it doubles the buffer with a torch kernel on the stream the calls
+    run on (the null stream), i.e. stream-ordered like ncclAllReduce would be.  The developed image is then unchanged (RGB and W both double), the weight image and the gradients double."""
     torch = torch_cuda
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; hip.hipMemcpy.restype = C.c_int
     scene = mi.load_dict(small_cbox(mi, 32))
     integ = mi.PRBIntegrator({"max_depth": 4})
     lib = mi.abi.lib(); h = scene.handle()
     W = H = 32
     calls = []
-    def double(user, ptr, count, stream):
-        calls.append(int(count))
-        tmp = torch.empty(int(count), dtype=torch.float32, device="cuda")
-        if hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(ptr), int(count) * 4, 3) != 0: return 1      # hipMemcpyDeviceToDevice (synchronising)
-        tmp *= 2; torch.cuda.synchronize()
-        return 0 if hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(tmp.data_ptr()), int(count) * 4, 3) == 0 else 1
+    bufs = {}
+    def double(user, ptr, count, stream):                                   # stream-ordered, like an all-reduce kernel: a torch op on the
+        calls.append(int(count))                                            # same (null) stream, on the tensor that owns `ptr`
+        t = bufs.get(ptr)
+        if t is None or t.numel() != int(count): return 1
+        t *= 2
+        return 0
     film = torch.zeros((H, W, 4), device="cuda"); img = torch.zeros((H, W, 3), device="cuda"); img2 = torch.zeros_like(img); film2 = torch.zeros_like(film)
     p = integ._params(scene, 3, 8)
     mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), None))
@@ -1611,9 +1610,10 @@ def test_reduce_hook(mi, torch_cuda):
     mi.abi.check(lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), C.c_void_p(wgt.data_ptr()), C.c_void_p(g.data_ptr()), None))
     torch.cuda.synchronize()
     scene.set_reduce_hook(double)
+    bufs[film2.data_ptr()] = film2
     mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None))
-    wgt2 = torch.zeros((H, W), device="cuda"); mi.abi.check(lib.mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(wgt2.data_ptr()), None))
-    g2 = torch.zeros(total, device="cuda")
+    wgt2 = torch.zeros((H, W), device="cuda"); bufs[wgt2.data_ptr()] = wgt2; mi.abi.check(lib.mi355_prb_splat_weights(h, C.byref(p), C.c_void_p(wgt2.data_ptr()), None))
+    g2 = torch.zeros(total, device="cuda"); bufs[g2.data_ptr()] = g2
     mi.abi.check(lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), C.c_void_p(wgt.data_ptr()), C.c_void_p(g2.data_ptr()), None))
     torch.cuda.synchronize()
     assert calls == [W * H * 4, W * H, total]
