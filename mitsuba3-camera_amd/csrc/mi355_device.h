@@ -1662,11 +1662,34 @@ MI_DEV bool prb_primal_step(const DScene &sc, PathState &st, uint32_t it, uint32
 // -------------------------------------------------------------------------------------------
 // s_grad holds 2^copy_shift copies of every small-parameter accumulator, copy = lane % copies: the lanes of a wave mostly
 // add to the SAME parameter (the one light, the white walls), which on a single LDS word serialises 64-fold.
-struct GradSink1 { float *s_grad; uint32_t copy_shift; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad; };
+//
+// FIXED-POINT accumulation (round 2).  An LDS fp32 atomic add is executed lane by lane on this chip (~2 cycles per active lane, ~120 per
+// full wave instruction) while a 64-bit integer one takes ~9 (profiles/r01_j_ptracer_pmc_summary.txt); compiled out, the fp32 atomics of
+// this kernel cost 0.43 ms of 4.76 (profiles/r02_prb_experiments.txt).  So every accumulator has a 64-bit integer twin, `s_fix`, in units
+// of  q = 2^-fix_shift,  with the exponent chosen per WORKGROUP from B = max |dL| over its lanes (every addend is dL times path
+// quantities):  B * 2^fix_shift < 2^36.  An addend below  fix_limit = 2^50 q  (i.e. 2^14 B) goes to the integer twin -- at most
+// 256 lanes x 8 vertices of them per accumulator keep the sum under 2^61 --, anything larger, non-finite, or a workgroup whose B is 0 /
+// non-finite uses the fp32 accumulator as before.  The quantum is 2^-36 of the largest dL of the workgroup: finer than the rounding of
+// the fp32 sum it replaces.  The two are added when the workgroup publishes.
+struct GradSink1 { float *s_grad; uint32_t copy_shift; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad;
+                   unsigned long long *s_fix; float fix_scale, fix_limit; };
+// x (already scaled, |x| < 2^50) -> 64-bit two's complement without a 64-bit conversion: hi = floor(x / 2^32) fits an int, the rest is in [0, 2^32)
+MI_DEV unsigned long long fix_from_float(float x) {
+    const float hi = floorf(x * 2.3283064365386963e-10f);                   // 2^-32
+    const float lo = fmaf(hi, -4294967296.f, x);                            // exact: x has 24 significant bits
+    return ((unsigned long long) (uint32_t) (int32_t) hi << 32) | (unsigned long long) (uint32_t) lo;   // (uint32_t) lo saturates at 2^32 - 1: one quantum
+}
+MI_DEV float fix_to_float(unsigned long long v, float inv_scale) { return (float) (long long) v * inv_scale; }
 MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {
     const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
-    float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
-    atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
+    const uint32_t at = (((uint32_t) slot) << sink.copy_shift) + c, step = 1u << sink.copy_shift;
+    if ((fabsf(g.x) < sink.fix_limit) & (fabsf(g.y) < sink.fix_limit) & (fabsf(g.z) < sink.fix_limit)) {   // (false for NaN, and always when fix_limit = 0)
+        unsigned long long *fb = sink.s_fix + at;
+        atomicAdd(fb, fix_from_float(g.x * sink.fix_scale)); atomicAdd(fb + step, fix_from_float(g.y * sink.fix_scale)); atomicAdd(fb + 2u * step, fix_from_float(g.z * sink.fix_scale));
+    } else {
+        float *gb = sink.s_grad + at;
+        atomicAdd(gb, g.x); atomicAdd(gb + step, g.y); atomicAdd(gb + 2u * step, g.z);
+    }
 }
 // Sum of v over the 64 lanes of the wave (all lanes must be executing): four DPP adds give every lane the sum of its row of 16,
 // the four row sums are read back as scalars.
@@ -1971,7 +1994,8 @@ MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, 
 // counter for the whole launch would take ~1 M same-address atomics, ~4 ns each.  Counters sit 128 B apart.
 #define MI_SPLAT_SEGS 256u
 #define MI_SPLAT_COUNTER_STRIDE 32u
-struct SplatQueue { float4 *rec_a; float *rec_b; uint32_t *count; uint32_t *hist; uint32_t cap, seg_cap, tiles_x, tiles_y; };
+// (rec_c, rec_d: second half of a DERIVATIVE splat record -- colour and film-position tangent -- or null)
+struct SplatQueue { float4 *rec_a; float *rec_b; float4 *rec_c; float *rec_d; uint32_t *count; uint32_t *hist; uint32_t cap, seg_cap, tiles_x, tiles_y; };
 MI_DEV uint32_t splat_tile_of(const DScene &sc, const SplatQueue &q, float pos_x, float pos_y) {
     // tile of the centre pixel, clamped into the crop window (taps that stick out of the window are dropped anyway)
     int32_t cx = (int32_t) floorf(pos_x) - (int32_t) sc.crop_x, cy = (int32_t) floorf(pos_y) - (int32_t) sc.crop_y;
@@ -2059,11 +2083,7 @@ MI_DEV void pt_grad_add(const PtGradSink &sink, int32_t slot, v3 g) {
     if (slot < 0) return;
     const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
     float *gb = sink.s_grad + (((uint32_t) slot) << sink.copy_shift) + c;
-#if defined(MI_EXP) && MI_EXP == 3
-    atomicAdd((int *) gb, __float_as_int(g.x)); atomicAdd((int *) gb + (1u << sink.copy_shift), __float_as_int(g.y)); atomicAdd((int *) gb + (2u << sink.copy_shift), __float_as_int(g.z));
-#else
     atomicAdd(gb, g.x); atomicAdd(gb + (1u << sink.copy_shift), g.y); atomicAdd(gb + (2u << sink.copy_shift), g.z);
-#endif
 }
 // connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
 // GRAD: `weight_unit` = weight / radiance of `emitter`; nothing is splatted, the gathered image adjoint goes to the sink.

@@ -650,12 +650,13 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
                                                                             // dependent global load out of the resolve loops
     float *s_grad = reinterpret_cast<float *>(dyn_lds);
     const uint32_t n_acc = n_small << copy_shift;
-    float4 *s_q = dyn_lds + (n_acc + 3u) / 4u;
-    __shared__ uint32_t s_qn, s_over;
+    unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(dyn_lds + (n_acc + 3u) / 4u);   // the accumulators' 64-bit fixed-point twins
+    float4 *s_q = dyn_lds + (n_acc + 3u) / 4u + (n_acc + 1u) / 2u;
+    __shared__ uint32_t s_qn, s_over, s_bmax;
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_qn = 0; s_over = 0; }
-    for (uint32_t k = threadIdx.x; k < n_acc; k += BLOCK) s_grad[k] = 0.f;
+    if (threadIdx.x == 0) { s_qn = 0; s_over = 0; s_bmax = 0; }
+    for (uint32_t k = threadIdx.x; k < n_acc; k += BLOCK) { s_grad[k] = 0.f; s_fix[k] = 0ull; }
     if (threadIdx.x < 32u && threadIdx.x < sc.n_textures) {
         s_texinfo[2 * threadIdx.x] = (uint32_t) sc.textures[threadIdx.x].grad_offset; s_texinfo[2 * threadIdx.x + 1] = sc.textures[threadIdx.x].c;
     }
@@ -685,9 +686,19 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
             }
     }
     dL = dL * cam_w;                                                        // value = L * weight, common.py:752
+    // exponent of the fixed-point accumulators: B = max |dL| over the workgroup (bit patterns of non-negative floats order like the values;
+    // a NaN sorts above infinity and switches the workgroup to the fp32 accumulators)
+    { const float b = fmaxf(fabsf(dL.x), fmaxf(fabsf(dL.y), fabsf(dL.z)));
+      const uint32_t bits = (dL.x != dL.x || dL.y != dL.y || dL.z != dL.z) ? 0x7fc00000u : __float_as_uint(b);
+      if (bits) atomicMax(&s_bmax, bits); }                                 // (once per lane and launch: the same-address conflict does not matter here)
+    __syncthreads();
+    float fix_scale = 0.f, fix_limit = 0.f, fix_inv = 0.f;
+    { const float B = __uint_as_float(s_bmax);
+      int e = 0; (void) frexpf(B, &e);                                      // B < 2^e
+      if (B > 0.f && B < MI_INF && e > -90 && e < 100) { fix_scale = ldexpf(1.f, 36 - e); fix_inv = ldexpf(1.f, e - 36); fix_limit = ldexpf(1.f, 14 + e); } }
     Counters3 cnt = {};
     bool hide = (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0;
-    GradSink1 sink = { s_grad, copy_shift, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr };
+    GradSink1 sink = { s_grad, copy_shift, s_q, &s_qn, q_granules, &s_over, g_grad != nullptr, s_fix, fix_scale, fix_limit };
     v3 L;
     prb_sample_1p<FULL>(sc, rng, ray, a.max_depth, a.rr_depth, hide, trace, stk, dL, sink, L, cnt);
     s_ltot[threadIdx.x] = L.x * dL.x; s_ltot[BLOCK + threadIdx.x] = L.y * dL.y; s_ltot[2 * BLOCK + threadIdx.x] = L.z * dL.z;   // L_total * dL
@@ -708,15 +719,17 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backw
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_small; k += BLOCK) {
-        float v = 0.f;
-        for (uint32_t c = 0; c < (1u << copy_shift); ++c) v += s_grad[(k << copy_shift) + c];
+        float v = 0.f; unsigned long long f = 0ull;
+        for (uint32_t c = 0; c < (1u << copy_shift); ++c) { v += s_grad[(k << copy_shift) + c]; f += s_fix[(k << copy_shift) + c]; }
+        v += fix_to_float(f, fix_inv);
         if (v != 0.f) atomicAdd(g_grad + small_map[k], v);
     }
     // Texture records.  Device-scope float atomics are executed on the memory side on this part (the per-XCD L2s are not
     // coherent with each other; PMC: TCC_EA0_ATOMIC = number of atomics, ~40 B of HBM write each), and the 4 x 64 samples of a
     // workgroup hit the same few texels many times, so the (record, tap) contributions are first summed per texel in an LDS
     // hash table (open addressing in the granules the constant-reflectance records no longer need) and only the distinct
-    // texels go out: 3.2x fewer atomics on C3.  Whatever does not fit the table takes the direct path.
+    // texels go out: 3.2x fewer atomics on C3.  Whatever does not fit the table takes the direct path.  (Fixed-point sums in the table,
+    // as the small-parameter accumulators have them, were measured at no gain -- 4.47 vs 4.50 ms -- and halve its capacity: not done.)
     __syncthreads();
     const uint32_t EMPTY = 0xffffffffu;
     uint32_t T = 0;
@@ -866,9 +879,10 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
 }
 
 // Forward-mode derivative of the light-traced film with respect to the vertex positions of one mesh (mi355_geo_forward.h): the lanes
-// and sampler streams of k_ptracer, dual numbers alongside; the derivative film is accumulated with plain float atomics.
+// and sampler streams of k_ptracer, dual numbers alongside; the derivative splats are deferred like the primal ones (40-byte records,
+// k_splat_tiles<true>) unless MI355_FLAG_DIRECT_SPLAT asks for plain float atomics.
 template <bool FULL>
-__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt) {
+__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs 
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     for (uint32_t pass = 0; pass < a.passes; ++pass)
-        ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk);
+        ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk, queue.cap ? &queue : nullptr);
 }
 
 // ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------
@@ -925,7 +939,8 @@ __global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint3
 }
 // Counting sort, scatter step.  Per chunk: LDS histogram -> one global cursor atomic per non-empty tile reserves the chunk's range in
 // that tile -> every record takes the next slot of its tile's reservation (LDS atomic).
-__global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b, uint32_t n_tiles) {
+__global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b,
+                                                       float4 *out_c, float *out_d, uint32_t n_tiles) {
     extern __shared__ uint32_t s_bins[];                                    // [n_tiles] counts, then bases; [n_tiles] local cursors
     uint32_t *s_cur = s_bins + n_tiles;
     const uint32_t cps = (q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK;
@@ -945,6 +960,7 @@ __global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, 
             const uint32_t t = splat_tile_of(sc, q, a.x, a.y);
             const uint32_t dst = s_bins[t] + atomicAdd(s_cur + t, 1u);
             out_a[dst] = a; out_b[dst] = b;
+            if (out_c) { out_c[dst] = q.rec_c[i]; out_d[dst] = q.rec_d[i]; }
         }
         __syncthreads();
     }
@@ -958,7 +974,11 @@ __global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, 
 // receives at most SPLAT_RUN of them, so with m * scale <= 2^50 the sum stays below 2^62, and the quantum is 2^-50 of m -- finer
 // than the fp32 additions it replaces.  (Non-finite colours take the float path, so that they reach the film as they are.)
 #define MI_SPLAT_TW (MI_SPLAT_TILE + 2 * MI_SPLAT_APRON)
-__global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, const uint32_t *offsets, const float4 *rec_a, const float *rec_b, float *film, uint32_t n_tiles) {
+// DUAL (forward-mode derivative film): record = (x, y, dV | V, dx, dy); a tap receives dV w + V dw with w the NORMALISED weight and dw its
+// derivative along the film-position tangent (film_put_dual's arithmetic).
+template <bool DUAL>
+__global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, const uint32_t *offsets, const float4 *rec_a, const float *rec_b,
+                                                     const float4 *rec_c, const float *rec_d, float *film, uint32_t n_tiles) {
     __shared__ long long s_tile[MI_SPLAT_TW * MI_SPLAT_TW * 3];
     __shared__ uint32_t s_max;
     const uint32_t n = offsets[n_tiles];                                    // records actually queued
@@ -975,7 +995,14 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
             if (threadIdx.x == 0) s_max = 0u;
             __syncthreads();
             float m = 0.f;
-            for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) { const float4 a = rec_a[j]; m = fmaxf(m, fmaxf(fabsf(a.z), fmaxf(fabsf(a.w), fabsf(rec_b[j])))); if (!(fabsf(a.z) + fabsf(a.w) + fabsf(rec_b[j]) < MI_INF)) m = MI_INF; }
+            for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) {
+                const float4 a = rec_a[j]; float mj = fmaxf(fabsf(a.z), fmaxf(fabsf(a.w), fabsf(rec_b[j]))), sum = fabsf(a.z) + fabsf(a.w) + fabsf(rec_b[j]);
+                if (DUAL) {                                                 // |dV w + V dw| <= |dV| + |V| (|dx| + |dy|) * 8: the normalised weights' slopes stay below 8 per pixel
+                    const float4 c = rec_c[j]; const float dd = fabsf(c.w) + fabsf(rec_d[j]);
+                    mj += fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))) * dd * 8.f; sum += (fabsf(c.x) + fabsf(c.y) + fabsf(c.z)) * dd;
+                }
+                m = fmaxf(m, mj); if (!(sum < MI_INF)) m = MI_INF;
+            }
             atomicMax(&s_max, __float_as_uint(m));                          // (m >= 0: the bit patterns order like the values)
             __syncthreads();
             m = __uint_as_float(s_max);
@@ -984,6 +1011,48 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
             const int se = min(50 - e, 120);
             const float scale = ldexpf(1.f, se), inv_scale = ldexpf(1.f, -se);
             const int32_t ox = (int32_t) (tile % q.tiles_x) * MI_SPLAT_TILE - MI_SPLAT_APRON, oy = (int32_t) (tile / q.tiles_x) * MI_SPLAT_TILE - MI_SPLAT_APRON;
+            if (DUAL) {
+                if (m != 0.f) for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) {
+                    const float4 a = rec_a[j], c = rec_c[j]; const float b = rec_b[j], dy = rec_d[j];
+                    const Df px = DF(a.x, c.w), py = DF(a.y, dy);
+                    const bool box = sc.rfilter == MI355_RFILTER_BOX;
+                    const int n = box ? 0 : (int) ceilf(sc.filter_radius - .5f), count = 2 * n + 1;
+                    const int32_t pix = (int32_t) floorf(px.v) - n, piy = (int32_t) floorf(py.v) - n;
+                    Df wx[MI_MAX_TAPS], wy[MI_MAX_TAPS], sx = DF(0.f), sy = DF(0.f);
+#pragma unroll
+                    for (int i = 0; i < MI_MAX_TAPS; ++i) {
+                        wx[i] = wy[i] = DF(0.f);
+                        if (i < count) {
+                            wx[i] = box ? DF(1.f) : dfilter_eval(sc, DF((float) (pix + i) + .5f) - px);
+                            wy[i] = box ? DF(1.f) : dfilter_eval(sc, DF((float) (piy + i) + .5f) - py);
+                            sx = sx + wx[i]; sy = sy + wy[i];
+                        }
+                    }
+                    const Df norm = sx * sy;
+                    if (norm.v == 0.f) continue;
+                    const Df factor = DF(1.f) / norm;
+#pragma unroll
+                    for (int ty = 0; ty < MI_MAX_TAPS; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < MI_MAX_TAPS; ++tx) {
+                            const int32_t x = pix + tx - (int32_t) sc.crop_x, y = piy + ty - (int32_t) sc.crop_y;
+                            if (ty >= count || tx >= count || x < 0 || y < 0 || x >= W || y >= H) continue;
+                            const Df w = wy[ty] * wx[tx] * factor;
+                            const float r = fmaf(a.z, w.v, c.x * w.d), g = fmaf(a.w, w.v, c.y * w.d), bl = fmaf(b, w.v, c.z * w.d);
+                            const int32_t lx = x - ox, ly = y - oy;
+                            if (lx < 0 || ly < 0 || lx >= MI_SPLAT_TW || ly >= MI_SPLAT_TW) continue;            // (inside by construction)
+                            if (fixed) {
+                                unsigned long long *px_ = reinterpret_cast<unsigned long long *>(s_tile) + (ly * MI_SPLAT_TW + lx) * 3;
+                                if (r != 0.f) atomicAdd(px_, (unsigned long long) __float2ll_rn(r * scale));
+                                if (g != 0.f) atomicAdd(px_ + 1, (unsigned long long) __float2ll_rn(g * scale));
+                                if (bl != 0.f) atomicAdd(px_ + 2, (unsigned long long) __float2ll_rn(bl * scale));
+                            } else {
+                                float *px_ = film + ((size_t) y * W + x) * 4;
+                                atomicAdd(px_, r); atomicAdd(px_ + 1, g); atomicAdd(px_ + 2, bl);
+                            }
+                        }
+                }
+            } else
             if (m != 0.f) for (uint32_t j = start + threadIdx.x; j < stop; j += 256u) {
                 const float4 a = rec_a[j]; const float b = rec_b[j];
                 Splat sp = splat_weights(sc, a.x, a.y);
@@ -1292,6 +1361,7 @@ struct mi355_scene {
     uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
     // deferred splat of the particle tracer: record queue (unsorted + sorted copy), tile histogram / offsets / cursors, record counter
     float4 *d_rec_a = nullptr, *d_srt_a = nullptr; float *d_rec_b = nullptr, *d_srt_b = nullptr; uint32_t rec_capacity = 0;
+    float4 *d_rec_c = nullptr, *d_srt_c = nullptr; float *d_rec_d = nullptr, *d_srt_d = nullptr; uint32_t rec2_capacity = 0;   // derivative splats: second record half
     uint32_t *d_tile_u32 = nullptr; uint32_t tile_capacity = 0; uint32_t splat_cap_override = 0;
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow, [4] redone backward workgroups
     uint64_t n_gen = 0, n_splat = 0;
@@ -1892,7 +1962,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
                      s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf,
-                     s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_tile_u32,
+                     s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_rec_c, s->d_srt_c, s->d_rec_d, s->d_srt_d, s->d_tile_u32,
                      s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape };
     for (void *b : bufs) if (b) (void) hipFree(b);
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
@@ -2123,6 +2193,60 @@ struct Timed {
     int end() { if (!on) return MI355_OK; HIP_TRY(hipEventRecord(s->ev[slot][1], st)); s->n_ev++; return MI355_OK; }
 };
 
+// Deferred, tile-sorted splat of the particle tracer (film_put_deferred): queue set-up and the four passes that empty it.  `dual`: the
+// records of the forward-mode derivative film carry a second half (colour, film-position tangent) next to (position, colour tangent).
+static int splat_queue_setup(mi355_scene *s, const mi355_render_params *p, const RenderArgs &a, hipStream_t st, bool dual, SplatQueue &q) {
+    memset(&q, 0, sizeof(q));
+    const uint64_t per_lane = (uint64_t) a.passes * (p->max_depth < 0 ? 64u : (uint32_t) p->max_depth);
+    const uint32_t all_tiles = ((s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE) * ((s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE);
+    if ((p->flags & MI355_FLAG_DIRECT_SPLAT) || (uint64_t) a.n_local * per_lane >= 0xffffffffull || all_tiles > SPLAT_MAX_TILES) return MI355_OK;
+    // The queue holds every connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
+    uint64_t want = std::min<uint64_t>((uint64_t) a.n_local * a.passes * (p->max_depth < 0 ? 8u : std::min<uint32_t>((uint32_t) p->max_depth, 8u)), s->splat_cap_override ? s->splat_cap_override : MAX_SPLAT_RECORDS);
+    const uint64_t seg_cap = std::max<uint64_t>((want + MI_SPLAT_SEGS - 1u) / MI_SPLAT_SEGS, 1u);   // MI_SPLAT_SEGS segments of equal capacity
+    want = seg_cap * MI_SPLAT_SEGS;
+    q.tiles_x = (s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE; q.tiles_y = (s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE;
+    const uint32_t n_tiles = q.tiles_x * q.tiles_y;
+    if (s->rec_capacity < want) {
+        for (void *b : { (void *) s->d_rec_a, (void *) s->d_srt_a, (void *) s->d_rec_b, (void *) s->d_srt_b }) if (b) HIP_TRY(hipFree(b));
+        s->d_rec_a = s->d_srt_a = nullptr; s->d_rec_b = s->d_srt_b = nullptr; s->rec_capacity = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_rec_a, want * sizeof(float4))); HIP_TRY(hipMalloc((void **) &s->d_srt_a, want * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->d_rec_b, want * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_srt_b, want * sizeof(float)));
+        s->rec_capacity = (uint32_t) want;
+    }
+    if (dual && s->rec2_capacity < want) {
+        for (void *b : { (void *) s->d_rec_c, (void *) s->d_srt_c, (void *) s->d_rec_d, (void *) s->d_srt_d }) if (b) HIP_TRY(hipFree(b));
+        s->d_rec_c = s->d_srt_c = nullptr; s->d_rec_d = s->d_srt_d = nullptr; s->rec2_capacity = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_rec_c, want * sizeof(float4))); HIP_TRY(hipMalloc((void **) &s->d_srt_c, want * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->d_rec_d, want * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_srt_d, want * sizeof(float)));
+        s->rec2_capacity = (uint32_t) want;
+    }
+    const size_t n_cnt = (size_t) MI_SPLAT_SEGS * MI_SPLAT_COUNTER_STRIDE;
+    if (s->tile_capacity < n_tiles) {                                       // [segment counters | hist n | offsets n + 1 | cursor n]
+        if (s->d_tile_u32) HIP_TRY(hipFree(s->d_tile_u32));
+        s->d_tile_u32 = nullptr; s->tile_capacity = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_tile_u32, (n_cnt + 3 * (size_t) n_tiles + 1) * sizeof(uint32_t))); s->tile_capacity = n_tiles;
+    }
+    q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.rec_c = dual ? s->d_rec_c : nullptr; q.rec_d = dual ? s->d_rec_d : nullptr;
+    q.cap = (uint32_t) want; q.seg_cap = (uint32_t) seg_cap; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + n_cnt;
+    HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (n_cnt + (size_t) n_tiles) * sizeof(uint32_t), st));
+    return MI355_OK;
+}
+static int splat_queue_flush(mi355_scene *s, const SplatQueue &q, hipStream_t st, bool dual, float *d_film_rgbw) {
+    if (!q.cap) return MI355_OK;
+    const uint32_t n_tiles = q.tiles_x * q.tiles_y;
+    uint32_t *offsets = q.hist + n_tiles, *cursor = offsets + n_tiles + 1;
+    const uint32_t chunks = std::min<uint32_t>(MI_SPLAT_SEGS * ((q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK), 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
+    hipLaunchKernelGGL(k_splat_hist, dim3(chunks), dim3(256), n_tiles * sizeof(uint32_t), st, s->ds, q, n_tiles);
+    hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles);
+    hipLaunchKernelGGL(k_splat_scatter, dim3(chunks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b,
+                       dual ? s->d_srt_c : (float4 *) nullptr, dual ? s->d_srt_d : (float *) nullptr, n_tiles);
+    if (dual) hipLaunchKernelGGL(k_splat_tiles<true>, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b,
+                                 (const float4 *) s->d_srt_c, (const float *) s->d_srt_d, d_film_rgbw, n_tiles);
+    else hipLaunchKernelGGL(k_splat_tiles<false>, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b,
+                            (const float4 *) nullptr, (const float *) nullptr, d_film_rgbw, n_tiles);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
     Phase ph(PHASE_RENDER);
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
@@ -2142,44 +2266,11 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         // Reconstruction filters with more than one tap: deferred, tile-sorted splat (see film_put_deferred).  The queue holds every
         // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
-        SplatQueue q; memset(&q, 0, sizeof(q));
-        const uint64_t per_lane = (uint64_t) a.passes * (p->max_depth < 0 ? 64u : (uint32_t) p->max_depth);
-        const uint32_t all_tiles = ((s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE) * ((s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE);
-        if (!(p->flags & MI355_FLAG_DIRECT_SPLAT) && (uint64_t) a.n_local * per_lane < 0xffffffffull && all_tiles <= SPLAT_MAX_TILES) {
-            uint64_t want = std::min<uint64_t>((uint64_t) a.n_local * a.passes * (p->max_depth < 0 ? 8u : std::min<uint32_t>((uint32_t) p->max_depth, 8u)), s->splat_cap_override ? s->splat_cap_override : MAX_SPLAT_RECORDS);
-            const uint64_t seg_cap = std::max<uint64_t>((want + MI_SPLAT_SEGS - 1u) / MI_SPLAT_SEGS, 1u);   // MI_SPLAT_SEGS segments of equal capacity
-            want = seg_cap * MI_SPLAT_SEGS;
-            q.tiles_x = (s->ds.crop_w + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE; q.tiles_y = (s->ds.crop_h + MI_SPLAT_TILE - 1) / MI_SPLAT_TILE;
-            const uint32_t n_tiles = q.tiles_x * q.tiles_y;
-            if (s->rec_capacity < want) {
-                for (void *b : { (void *) s->d_rec_a, (void *) s->d_srt_a, (void *) s->d_rec_b, (void *) s->d_srt_b }) if (b) HIP_TRY(hipFree(b));
-                s->d_rec_a = s->d_srt_a = nullptr; s->d_rec_b = s->d_srt_b = nullptr; s->rec_capacity = 0;
-                HIP_TRY(hipMalloc((void **) &s->d_rec_a, want * sizeof(float4))); HIP_TRY(hipMalloc((void **) &s->d_srt_a, want * sizeof(float4)));
-                HIP_TRY(hipMalloc((void **) &s->d_rec_b, want * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_srt_b, want * sizeof(float)));
-                s->rec_capacity = (uint32_t) want;
-            }
-            const size_t n_cnt = (size_t) MI_SPLAT_SEGS * MI_SPLAT_COUNTER_STRIDE;
-            if (s->tile_capacity < n_tiles) {                               // [segment counters | hist n | offsets n + 1 | cursor n]
-                if (s->d_tile_u32) HIP_TRY(hipFree(s->d_tile_u32));
-                s->d_tile_u32 = nullptr; s->tile_capacity = 0;
-                HIP_TRY(hipMalloc((void **) &s->d_tile_u32, (n_cnt + 3 * (size_t) n_tiles + 1) * sizeof(uint32_t))); s->tile_capacity = n_tiles;
-            }
-            q.rec_a = s->d_rec_a; q.rec_b = s->d_rec_b; q.cap = (uint32_t) want; q.seg_cap = (uint32_t) seg_cap; q.count = s->d_tile_u32; q.hist = s->d_tile_u32 + n_cnt;
-            HIP_TRY(hipMemsetAsync(s->d_tile_u32, 0, (n_cnt + (size_t) n_tiles) * sizeof(uint32_t), st));
-        }
+        SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, false, q))) return rc;
         if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
         else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
         HIP_TRY(hipGetLastError());
-        if (q.cap) {
-            const uint32_t n_tiles = q.tiles_x * q.tiles_y;
-            uint32_t *offsets = q.hist + n_tiles, *cursor = offsets + n_tiles + 1;
-            const uint32_t chunks = std::min<uint32_t>(MI_SPLAT_SEGS * ((q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK), 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
-            hipLaunchKernelGGL(k_splat_hist, dim3(chunks), dim3(256), n_tiles * sizeof(uint32_t), st, s->ds, q, n_tiles);
-            hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles);
-            hipLaunchKernelGGL(k_splat_scatter, dim3(chunks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b, n_tiles);
-            hipLaunchKernelGGL(k_splat_tiles, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b, d_film_rgbw, n_tiles);
-            HIP_TRY(hipGetLastError());
-        }
+        if ((rc = splat_queue_flush(s, q, st, false, d_film_rgbw))) return rc;
         if ((rc = tm.end())) return rc;
         s->n_gen += a.n_local;
         return MI355_OK;
@@ -2313,10 +2404,11 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
         ntan = s->d_ntan;
     }
     GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel, ntan };
-    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
-    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt);
+    SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, true, q))) return rc;
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q);
+    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q);
     HIP_TRY(hipGetLastError());
-    return MI355_OK;
+    return splat_queue_flush(s, q, st, true, d_film_rgbw);
 }
 static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream);
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,
@@ -2401,7 +2493,7 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         const uint32_t static_lds = (bvh ? WAVES * STACK_WORDS * 4u : 256u) + 3u * BLOCK * 4u + 64u;
         uint32_t copy_shift = 5;                                            // 32 copies (one per LDS bank) while they fit in 8 KB
         while (copy_shift > 0 && (n_small << copy_shift) > 2048u) --copy_shift;
-        const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u;
+        const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u + (((n_small << copy_shift) + 1u) / 2u) * 16u;   // fp32 accumulators + their 64-bit twins
         const uint32_t lds_budget = (full ? 163840u / 3u : 163840u / MI_MIN_WAVES_1P);   // FULL: three workgroups per CU (its launch bounds), 54 KB each
         if (static_lds + small_bytes + 256u + 64u * 16u > lds_budget) return fail(MI355_ERR_UNSUPPORTED, "no LDS left for the gradient record queue");
         uint32_t q_granules = (lds_budget - 256u - static_lds - small_bytes) / 16u;

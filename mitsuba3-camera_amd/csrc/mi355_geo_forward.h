@@ -169,10 +169,36 @@ MI_DEV void film_put_dual(const DScene &sc, float *gfilm, Df px, Df py, D3 V) {
         }
 }
 
+// The same splat, deferred (film_put_deferred): the record carries what the tile pass needs to re-evaluate the dual weights --
+// (x, y, dV.rgb | V.rgb, dx, dy) = 40 bytes in two halves.  One wave-aggregated counter atomic per wave; a full queue falls back to
+// the direct atomics above.  Called from inside the connection branch: the ballot covers exactly the lanes that splat.
+MI_DEV void film_put_deferred_dual(const DScene &sc, const SplatQueue &q, float *gfilm, Df px, Df py, D3 V) {
+    bool put;
+    {
+        int n = sc.rfilter == MI355_RFILTER_BOX ? 0 : (int) ceilf(sc.filter_radius - .5f);
+        int32_t cx = (int32_t) floorf(px.v) - (int32_t) sc.crop_x, cy = (int32_t) floorf(py.v) - (int32_t) sc.crop_y;
+        put = cx + n >= 0 && cy + n >= 0 && cx - n < (int32_t) sc.crop_w && cy - n < (int32_t) sc.crop_h;
+    }
+    const unsigned long long m = __ballot(put);
+    if (!put) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+    const uint32_t leader = (uint32_t) __ffsll((long long) m) - 1u;
+    uint32_t base = 0;
+    const uint32_t seg = blockIdx.x % MI_SPLAT_SEGS;
+    if ((threadIdx.x & 63u) == leader) base = atomicAdd(q.count + seg * MI_SPLAT_COUNTER_STRIDE, (uint32_t) __popcll(m));
+    base = (uint32_t) __builtin_amdgcn_readlane((int) base, (int) leader);
+    const uint32_t local = base + rank;
+    if (local < q.seg_cap && base <= 0xffffffffu - 64u) {
+        const uint32_t idx = seg * q.seg_cap + local;
+        q.rec_a[idx] = make_float4(px.v, py.v, V.x.d, V.y.d); q.rec_b[idx] = V.z.d;
+        q.rec_c[idx] = make_float4(V.x.v, V.y.v, V.z.v, px.d); q.rec_d[idx] = py.d;
+    } else film_put_dual(sc, gfilm, px, py, V);
+}
+
 // One light sample: the control flow of ptracer_sample (same sampler calls, same decisions), with the geometry duals alongside.
 template <bool FULL>
 MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                               float sample_scale, float *gfilm, uint32_t *stk) {
+                               float sample_scale, float *gfilm, uint32_t *stk, const SplatQueue *queue = nullptr) {
     const bool timed = sc.shutter_open_time > 0.f;
     if (max_depth != 0 && !hide_emitters) {                                // sample_visible_emitters: static emitter, static sensor -> no derivative,
         if (timed) (void) next_1d(rng);                                     // but the sampler stream advances exactly as in ptracer_sample
@@ -240,7 +266,8 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
                     Df correction = dabs((wi.z * wo_dot_geo_n) / (local_d.z * wi_dot_geo_n));
                     Df lobe = local_d.z * MI_INV_PI * correction * sw * sample_scale;
                     D3 V = (T * D3c(refl)) * lobe;
-                    film_put_dual(sc, gfilm, px, py, V);
+                    if (queue) film_put_deferred_dual(sc, *queue, gfilm, px, py, V);
+                    else film_put_dual(sc, gfilm, px, py, V);
                 }
             }
             // ---- BSDF sampling: the primal decides, the duals follow

@@ -1214,6 +1214,30 @@ def test_particle_tracer_vertex_forward_mode(mi, torch_cuda, case):
         integ.render_forward_geometry(scene, "light" if case == "diffuse-floor" else "screen", np.zeros((0, 3), dtype=np.float32), seed=1, spp=4)
 
 
+@pytest.mark.parametrize("rfilter", ["gaussian", "tent", "box"])
+def test_forward_mode_derivative_film_deferred_equals_direct(mi, torch_cuda, rfilter):
+    """The derivative film of the vertex / IOR forward mode goes through the deferred, tile-sorted splat as the primal film does
+    (40-byte records: position, colour tangent | colour, position tangent; k_splat_tiles<true> re-evaluates the dual filter weights);
+    MI355_FLAG_DIRECT_SPLAT keeps the plain float atomics.  Same film up to summation order -- also when the queue overflows and part of
+    the records takes the direct path."""
+    scene = mi.load_dict(_geo_lens_scene(mi, 1.0, "glass", rfilter=rfilter))
+    tangent = (_icosphere(2)[0] * 0.5).astype(np.float32)
+    films = {}
+    for name, direct, cap in (("direct", True, 0), ("deferred", False, 0), ("overflow", False, 4096)):
+        integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 100}); integ.direct_splat = direct
+        mi.abi.check(mi.abi.lib().mi355_debug_set_splat_capacity(scene.handle(), cap))
+        films[name] = integ.render_forward_geometry(scene, "lens", tangent, seed=1, spp=64).cpu().numpy().astype(np.float64)
+        both = integ.render_forward_design(scene, shape="lens", vertex_tangent=tangent, bsdf="glass", d_int_ior=0.3, seed=1, spp=64).cpu().numpy().astype(np.float64)
+        films[name + "+ior"] = both
+    mi.abi.check(mi.abi.lib().mi355_debug_set_splat_capacity(scene.handle(), 0))
+    for suffix in ("", "+ior"):
+        ref = films["direct" + suffix]; scale = np.abs(ref).max()
+        assert scale > 0 and np.isfinite(ref).all()
+        for name in ("deferred", "overflow"):
+            assert np.abs(films[name + suffix] - ref).max() < 2e-5 * scale, (name, suffix, np.abs(films[name + suffix] - ref).max() / scale)
+    scene.release()
+
+
 def test_degenerate_scenes_and_budgets(mi, orc, torch_cuda):
     """Edge cases of the domain: a scene without shapes, a scene without emitters, max_depth = 0 and 1, a single sample per
     pixel, an empty shard, and a sample budget beyond 2^32 lanes (integrator.cpp:247-265 splits such renders into passes; the
