@@ -1657,3 +1657,41 @@ def test_reduce_hook(mi, torch_cuda):
     mi.abi.check(lib.mi355_render(h, C.byref(p), C.c_void_p(film2.data_ptr()), C.c_void_p(img2.data_ptr()), None)); torch.cuda.synchronize()
     assert torch.allclose(film2, film, rtol=1e-5, atol=1e-6)
     scene.release()
+
+
+def test_adjoint_fixed_point_accumulators(mi, orc, torch_cuda):
+    """The one-pass adjoint sums its small-parameter gradients in 64-bit fixed point per workgroup (exponent from the workgroup's largest
+    |dL|, fp32 fallback for outliers and non-finite values).  The result must not depend on that: image adjoints spanning 13 decades,
+    an all-zero adjoint, one with huge isolated pixels, and one with a NaN give what the oracle and the two-pass kernel (fp32 sums) give."""
+    torch = torch_cuda
+    d = small_cbox(mi, 32)
+    tex = np.random.default_rng(1).uniform(0.2, 0.8, (8, 8, 3)).astype(np.float32)
+    d["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}
+    d["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+    scene = mi.load_dict(d); o = orc.OracleScene(scene, mi.abi)
+    rng = np.random.default_rng(7)
+    wide = (np.exp(rng.normal(0, 5, (32, 32, 3))) * rng.choice([-1.0, 1.0], (32, 32, 3))).astype(np.float32)
+    spikes = rng.normal(size=(32, 32, 3)).astype(np.float32); spikes[5, 7] = 1e20; spikes[20, 3] = -3e25
+    for name, gin in (("wide", wide), ("zero", np.zeros((32, 32, 3), np.float32)), ("spikes", spikes)):
+        res = {}
+        for two_pass in (False, True):
+            integ = mi.PRBIntegrator({"max_depth": 5, "rr_depth": 3}); integ.two_pass = two_pass
+            params = mi.traverse(scene)
+            res[two_pass] = integ.render_backward(scene, params, torch.tensor(gin), seed=11, spp=16).cpu().numpy().astype(np.float64)
+        ref = o.render_backward(o.params(mi.PRBIntegrator({"max_depth": 5, "rr_depth": 3}), 11, 16), gin).astype(np.float64)
+        assert np.isfinite(res[False]).all()
+        if name == "zero":
+            assert (res[False] == 0).all() and (ref == 0).all()
+            continue
+        lay, _ = o.param_layout()
+        for kind, index, off, size in lay:                               # per parameter: the spikes dominate the largest one only
+            a, b, c = res[False][off:off + size], res[True][off:off + size], ref[off:off + size]
+            if np.abs(c).max() == 0:
+                assert np.abs(a).max() == 0
+                continue
+            assert grad_close(a, c, 1e-3, "%s kind %d index %d vs oracle" % (name, kind, index)) and grad_close(a, b, 1e-3, "%s kind %d index %d vs two-pass" % (name, kind, index))
+    bad = rng.normal(size=(32, 32, 3)).astype(np.float32); bad[10, 10, 1] = np.nan
+    integ = mi.PRBIntegrator({"max_depth": 5, "rr_depth": 3})
+    g = integ.render_backward(scene, mi.traverse(scene), torch.tensor(bad), seed=11, spp=16).cpu().numpy()
+    assert np.isnan(g).any()                                              # a NaN adjoint reaches the gradient, as it does through fp32 sums
+    scene.release()
