@@ -34,7 +34,9 @@ def lib(abi):
         return _lib
     if not os.path.exists(LIB):
         build()
-    l = C.CDLL(LIB)
+    # MI355_ORACLE_LIB: another build of the same source, e.g. oracle/liboracle_asan.so (`make -C oracle asan`; run the CPU tests with
+    # LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 MI355_ORACLE_LIB=oracle/liboracle_asan.so)
+    l = C.CDLL(os.environ.get("MI355_ORACLE_LIB", LIB))
     l.orc_scene_create.restype = C.c_void_p
     l.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
     l.orc_scene_destroy.argtypes = [C.c_void_p]
