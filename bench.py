@@ -421,7 +421,8 @@ def main():
                     pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
             pl.update(); il.render(scl, seed=0, spp=1)
         r_ms, r_k = timed_l(lambda: il.render(scl, seed=0, spp=256))
-        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True))
+        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=False))   # what a design step asks for
+        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True))    # + reflectances / radiances
         c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False))
         u_ms, _ = timed_l(upd)
         losses = [prob.step(it) for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
@@ -430,7 +431,7 @@ def main():
         lens = {"metric": "lens doublet (BASELINE configs[4]): ptracer 128^2, render @256 spp + render_backward @128 spp over all vertices and IORs",
                 "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
                 "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
-                "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
+                "render_backward_geometry_and_colour_ms": a_ms, "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
                 "light_paths_per_s_backward": round(128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
         scl.release()
 

@@ -187,6 +187,10 @@ typedef struct mi355_scene_desc {
                                           slots -- the reverse-mode geometry / IOR adjoint of the light paths (one extra walk per light path with a
                                           path tape in HBM; DESIGN.md "geometry adjoint").  Perspective sensor, finite max_depth <= 32 */
 
+#define MI355_FLAG_SKIP_COLOUR_GRADS 128u /* with MI355_FLAG_GEOMETRY_GRADS: leave the reflectance / texture / radiance slots untouched -- the colour
+                                          walk of the light tracer's render_backward is skipped (a lens-design step differentiates geometry and IORs
+                                          only: dr.backward() reaches only the parameters whose gradients are enabled) */
+
 #define MI355_FLAG_DIRECT_SPLAT   32u  /* particle tracer: splat every connection with direct float atomics instead of the default deferred,
                                           tile-sorted splat (same film up to summation order; a debugging / comparison switch -- Gaussian
                                           filter 234.6 ms against 7.1 ms on the Cornell box 512^2 x 64 spp) */

@@ -2436,9 +2436,11 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         while (cs > 0 && (n_small_pt << cs) > 2048u) --cs;
         const uint32_t all = (p->flags & MI355_FLAG_EMITTER_GRADS_ONLY) ? 0u : 1u;
         const size_t dyn = (size_t) (n_small_pt << cs) * sizeof(float);
-        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
-        else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
-        HIP_TRY(hipGetLastError());
+        if (!((p->flags & MI355_FLAG_GEOMETRY_GRADS) && (p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))) {      // (a lens-design step asks for geometry / IOR gradients only)
+            if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
+            else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
+            HIP_TRY(hipGetLastError());
+        }
         if (p->flags & MI355_FLAG_GEOMETRY_GRADS) {                         // vertex positions and IORs: forward walk onto the path tape, backward sweep
             if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "geometry gradients are built for the perspective sensor");
             if (p->max_depth < 0 || p->max_depth > MI_TAPE_MAX_VERTS + 1) return fail(MI355_ERR_UNSUPPORTED, "geometry gradients need a finite max_depth <= 33 (the path tape holds max_depth - 1 vertices)");

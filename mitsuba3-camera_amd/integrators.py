@@ -367,15 +367,19 @@ class ParticleTracerIntegrator(Integrator):
         """render_forward_design with a vertex tangent only."""
         return self.render_forward_design(scene, shape=shape, vertex_tangent=vertex_tangent, sensor=sensor, seed=seed, spp=spp)
 
-    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None, geometry=None):
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, shard=None, group=None, geometry=None, colour=None):
         """Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp: gradients of every differentiable parameter of this build
         (emitter radiances, diffuse reflectances, reflectance textures) by path replay of the light paths; the reference's own test
         value for the radiance (test_ptracer.py:204-225) is reproduced.  When `params` holds radiance keys only (params.keep), the
         cheaper single-walk kernel runs.  `geometry`: also fill the `vertex_positions` and IOR slots (the reverse-mode geometry adjoint,
-        MI355_FLAG_GEOMETRY_GRADS); None = when one of those parameters asks for a gradient (a tensor with requires_grad)."""
+        MI355_FLAG_GEOMETRY_GRADS); None = when one of those parameters asks for a gradient (a tensor with requires_grad).  `colour`:
+        fill the reflectance / texture / radiance slots; None = yes, unless gradients are requested for geometry / IOR parameters ONLY
+        (the lens-design step: dr.backward() would not visit the colours either) -- then the colour walk is skipped."""
         torch = _torch()
         if geometry is None:
             geometry = params is not None and params.wants_geometry()
+        if colour is None:
+            colour = not (geometry and params is not None and params.wants_geometry() and not params.wants_colour())
         radiance_only = (not geometry) and params is not None and all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
         be = self.backend
         dev = be.device(scene)
@@ -390,6 +394,8 @@ class ParticleTracerIntegrator(Integrator):
             p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
         if geometry:
             p.flags |= abi.FLAG_GEOMETRY_GRADS
+            if not colour:
+                p.flags |= abi.FLAG_SKIP_COLOUR_GRADS
         grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(be.param_total(scene), 1), dtype=torch.float32, device=dev)
         multi = shard is not None and shard[1] > 1
         local = torch.zeros_like(grads) if multi else grads
@@ -477,6 +483,11 @@ class SceneParameters:
         """True when a geometry / IOR parameter of this set carries a gradient request (a tensor with requires_grad), i.e. when the
         particle tracer's render_backward must run its geometry adjoint too."""
         return any(self._entries[k][0] in (abi.PARAM_VERTEX_POSITIONS, abi.PARAM_BSDF_IOR) and getattr(self._values[k], "requires_grad", False)
+                   for k in self._entries)
+
+    def wants_colour(self):
+        """True when a reflectance / texture / radiance parameter of this set carries a gradient request (a tensor with requires_grad)."""
+        return any(self._entries[k][0] in (abi.PARAM_BSDF_REFLECTANCE, abi.PARAM_TEXTURE_DATA, abi.PARAM_EMITTER_RADIANCE) and getattr(self._values[k], "requires_grad", False)
                    for k in self._entries)
 
     def keep(self, keys):

@@ -41,6 +41,12 @@ def _cap_lens_scene(mi, res=32, subdiv=2, rfilter="gaussian"):
                        'film': {'type': 'hdrfilm', 'width': res, 'height': res, 'pixel_format': 'rgb', 'rfilter': {'type': rfilter}}}}
 
 
+def scene_layout(mi, scene):
+    """(kind, index, offset, size) of every gradient slot (mi355_scene_param_layout)."""
+    import importlib
+    return mi.scene_param_layout(scene)[0]
+
+
 def _shape_index(scene, sid):
     return [i for i, s in enumerate(scene.shapes) if s.id == sid][0]
 
@@ -133,6 +139,19 @@ def test_geometry_backward_is_the_transpose_of_the_forward_mode(mi, torch_cuda):
     lhs = float((gin * ji).sum()); rhs = float(params.grad("lens.bsdf.int_ior")[0] - 0.5 * params.grad("lens.bsdf.ext_ior")[0])
     assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), abs(rhs)), (lhs, rhs)
     assert g.numel() == params._total
+    # geometry / IOR gradients only (MI355_FLAG_SKIP_COLOUR_GRADS, what a lens-design step asks for): the same geometry slots, colour slots untouched
+    full = g.clone()
+    params.zero_grad()
+    only = integ.render_backward(scene, params, gin, seed=seed, spp=spp, geometry=True, colour=False)
+    lay = scene_layout(mi, scene)
+    colour_full = 0.0
+    for kind, index, off, size in lay:
+        if kind in (mi.abi.PARAM_VERTEX_POSITIONS, mi.abi.PARAM_BSDF_IOR):
+            assert torch.allclose(only[off:off + size], full[off:off + size], rtol=1e-4, atol=1e-6 * float(full[off:off + size].abs().max() + 1e-30))
+        else:
+            assert float(only[off:off + size].abs().max()) == 0.0
+            colour_full = max(colour_full, float(full[off:off + size].abs().max()))
+    assert colour_full > 0.0
 
 
 @pytest.mark.parametrize("integrator_name", ["path", "ptracer"])
