@@ -98,10 +98,11 @@ MI_DEV void tape_store(const GeoTape &tp, uint32_t lane, uint32_t k, const Ray &
     b[16 * s] = __uint_as_float(hit.prim); b[17 * s] = __uint_as_float((hit.shape << 4) | flags);
 }
 
-// One light sample: forward walk (tape), backward sweep (gradients).  Mirrors ptracer_sample call for call.
+// One light sample, forward walk: mirrors ptracer_sample call for call and writes one tape record per vertex.  Returns the number of
+// vertices on the tape.
 template <bool FULL>
-MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                                   float sample_scale, uint32_t *stk, const GeoTape &tp, uint32_t lane, const GeoBwdSink &sink) {
+MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
+                                 uint32_t *stk, const GeoTape &tp, uint32_t lane) {
     const bool timed = sc.shutter_open_time > 0.f;
     if (max_depth != 0 && !hide_emitters) {                                // sample_visible_emitters: static emitter and sensor -> no derivative;
         if (timed) (void) next_1d(rng);                                     // the stream advances exactly as in ptracer_sample
@@ -177,7 +178,11 @@ MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_dep
         }
         if (was_active && nv < MI_TAPE_MAX_VERTS) { tape_store(tp, lane, nv, in_ray, T_in, in_hit, W, rr, flags); nv++; }
     }
-    // ---------------------------------------------------------------- backward sweep
+    return nv;
+}
+// Backward sweep over the `nv` tape records of one light sample, last vertex first: gradients into the sink.  No ray is traced here.
+template <bool FULL>
+MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, const GeoBwdSink &sink) {
     gv3 lo = ga::mk<float>(0.f, 0.f, 0.f), ld = lo, lT = lo;               // lambda: adjoint of the ray / throughput LEAVING the current vertex
     ga::Sensor<float> se;
     {
@@ -271,6 +276,14 @@ MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_dep
         }
         lo = ao; ld = ad; lT = aT;
     }
+}
+
+// Walk + sweep in one call (the fused kernel: samples_per_pass > 1 re-uses the tape pass after pass).
+template <bool FULL>
+MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
+                                   float sample_scale, uint32_t *stk, const GeoTape &tp, uint32_t lane, const GeoBwdSink &sink) {
+    const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, max_depth, rr_depth, hide_emitters, lane_on, stk, tp, lane);
+    ptracer_geo_sweep<FULL>(sc, sample_scale, tp, lane, nv, sink);
 }
 
 // ---- vertex normals: Mesh::recompute_vertex_normals (mesh.cpp:376-413, JIT branch), as a per-vertex GATHER over the incident
