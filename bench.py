@@ -394,7 +394,7 @@ def main():
 
     # ---- BASELINE configs[4]: the lens doublet of notebooks/doublet_full_optim.ipynb -- ptracer + reverse-mode geometry adjoint -----------
     lens = None
-    if not args.no_lens and world == 1:
+    if not args.no_lens:
         ld = mi.lens_design
         surfs = [{'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 140, 'z0': 48}, {'radial_extent': 8.0, 'K': 0.0, 'c': -1 / 24, 'z0': 49}, {'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 24, 'z0': 52}]
         mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
@@ -403,6 +403,8 @@ def main():
         prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, init_camera_z=0.1, fov=100.0).prepare()
         build_s = time.perf_counter() - t0
         scl, pl = prob.scene, prob.params
+        lshard = (rank, world) if world > 1 else None
+        prob.shard = lshard                                        # N > 1: sharded light-sample grid, film + gradient all-reduce inside the calls
         il = scl.integrator(); il.timing = True
         system.update(pl, prob.optimizer); pl.update()
         gin_l = torch.ones((128, 128, 3), dtype=torch.float32, device=dev)
@@ -419,16 +421,20 @@ def main():
             for e in system.elements:                   # SceneParameters.update of the six meshes: refit + normals on the device
                 for key in (e.lens_key, e.baffle_key):
                     pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
-            pl.update(); il.render(scl, seed=0, spp=1)
-        r_ms, r_k = timed_l(lambda: il.render(scl, seed=0, spp=256))
-        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=False))   # what a design step asks for
-        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True))    # + reflectances / radiances
-        c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False))
+            pl.update(); il.render(scl, seed=0, spp=1, shard=lshard)
+        r_ms, r_k = timed_l(lambda: il.render(scl, seed=0, spp=256, shard=lshard))
+        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
+        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances
+        c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False, shard=lshard))
         u_ms, _ = timed_l(upd)
         losses = [prob.step(it) for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
         t0 = time.perf_counter(); losses += [prob.step(it) for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
         info = scl.info()
+        if dist is not None:                            # (host timers: the slowest rank's)
+            tt = torch.tensor([r_ms, b_ms, a_ms, c_ms, u_ms, it_ms], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
         lens = {"metric": "lens doublet (BASELINE configs[4]): ptracer 128^2, render @256 spp + render_backward @128 spp over all vertices and IORs",
+                "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",
                 "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
                 "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
                 "render_backward_geometry_and_colour_ms": a_ms, "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),

@@ -457,7 +457,9 @@ class DesignProblem:
         take the optimizer step.  Returns the loss (mm^2 x 10000, as the notebook scales it)."""
         from .integrators import render
         self.lens_system.update(self.params, self.optimizer)
-        image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp)
+        # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
+        # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
+        image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, shard=getattr(self, "shard", None), group=getattr(self, "group", None))
         loss = 10000.0 * self.field_source.evaluate_rms_loss(image)
         loss.backward()
         self.optimizer.step()
