@@ -337,10 +337,14 @@ def test_veach_lane_radiance(mi, orc, torch_cuda, veach64, integrator_name, max_
     ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
     got = integ.lane_radiance(veach64, seed, spp, 0, n).cpu().numpy()
     assert np.isfinite(got).all()
-    # glossy lobes amplify ulp-level differences (expf / erff / sincos of gfx950 vs glibc): looser per-lane tolerance, tight means
-    close = np.isclose(got[:, :3], ref[:, :3], rtol=2e-3, atol=1e-4).all(axis=1) & (got[:, 3] == ref[:, 3])
-    assert close.mean() > 0.995, "diverged lanes: %g" % (1 - close.mean())
-    assert np.allclose(got[:, :3].mean(0), ref[:, :3].mean(0), rtol=2e-2)
+    # glossy lobes amplify ulp-level differences (v_exp / v_rcp / v_rsq / sincos of gfx950 vs glibc).  Measured (tools/lane_parity.py,
+    # profiles/r02_lane_parity.txt): 99.98 % of the lanes within rtol 2e-4, every lane within 2e-3, means equal to 5 digits; a
+    # -DMI_EXACT_MATH build is listed next to it.
+    same = got[:, 3] == ref[:, 3]
+    tight = np.isclose(got[:, :3], ref[:, :3], rtol=2e-4, atol=1e-5).all(axis=1) & same
+    loose = np.isclose(got[:, :3], ref[:, :3], rtol=2e-3, atol=1e-4).all(axis=1) & same
+    assert tight.mean() > 0.999 and loose.mean() > 0.9999, "diverged lanes: %g / %g" % (1 - tight.mean(), 1 - loose.mean())
+    assert np.allclose(got[:, :3].mean(0), ref[:, :3].mean(0), rtol=1e-3)
 
 
 def test_veach_repacking_modes_agree(mi, orc, torch_cuda, veach64):
