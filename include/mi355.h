@@ -373,6 +373,17 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
    out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres, 4: realisticlens sensor; any bit -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
 
+/* ---- device memory the engine allocates on its own (per scene handle, lazily, kept until mi355_scene_destroy) ---------------------
+   Besides the scene replica (vertex / index / texture buffers, BVH: 128 B per 4-wide node, 36 B per triangle) a handle owns scratch
+   that is sized by the LARGEST call it has served:
+     path / prb         grad_in / W scratch 16 B per pixel; one redo flag (4 B) per workgroup of 256 lanes
+     ptracer render     deferred-splat record queue: 40 B per queued connection (unsorted + sorted copy of a 20-byte record), at most
+                        min(lanes * min(max_depth, 8), 128 Mi) records = 5.4 GB; connections beyond the capacity are splatted with direct
+                        atomics (same film).  mi355_ptracer_forward_design: twice that (records carry a second half).
+     ptracer backward   with MI355_FLAG_GEOMETRY_GRADS: the path tape, 72 B per vertex and lane, for chunks of at most 4 Mi lanes:
+                        (max_depth - 1) * 72 B * min(lanes, 4 Mi) <= 9.7 GB at max_depth 33; 12 B per mesh vertex of normal adjoints
+   Nothing else grows with the job; all of it is coarse-grained device memory of the handle's device. */
+
 /* ---- multi-GPU exchange ------------------------------------------------------------------------------------------
    One process per GPU, every rank holds the whole scene and renders its shard (pixel range, interleaved tiles or spp slice of
    mi355_render_params).  The only exchange of the path is a SUM over the ranks of (a) the RGBW film accumulator before develop,
