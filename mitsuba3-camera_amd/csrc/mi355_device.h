@@ -52,6 +52,17 @@ struct DTri { float p0[3], e1[3], e2[3]; };               // mesh.h:438: e1 = p1
 //   rectangle shape : m = the shape's to_object, bounds s,t in [-1,1]               (rectangle.cpp:446-468, same formula)
 //   two coplanar triangles that form a parallelogram (cube faces, OBJ quads): bounds s,t in [0,1]
 //   single triangle : Es = e1, Et = e2, (s,t) are its barycentrics, bounds s,t >= 0, s+t <= 1
+// Device order of m[0..7] (MI_PRIM_INTERLEAVE, default): the s-row and the t-row interleaved -- m0 m4 m1 m5 m2 m6 m3 m7 -- so that the pairs
+// the packed-math instructions want (v_pk_fma_f32 on (s, t) at once) are ADJACENT, even-aligned SGPRs straight out of the s_load; in row
+// order the compiler builds every pair with s_mov (4 per primitive test).  Host code writes rows; prims_for_device() permutes at upload.
+#ifndef MI_PRIM_INTERLEAVE
+#define MI_PRIM_INTERLEAVE 1
+#endif
+#if MI_PRIM_INTERLEAVE
+#define MI_PM(i) ((i) < 8 ? (((i) & 3) * 2 + ((i) >> 2)) : (i))
+#else
+#define MI_PM(i) (i)
+#endif
 struct DPrim {
     float m[12];
     float lo;        // lower bound of s and t (-1 or 0)
@@ -403,11 +414,11 @@ template <typename T> MI_DEV MI_K(T) *as_const_table(const T *p) { return (MI_K(
 template <typename P>
 MI_DEV bool prim_test(P pr, const Ray &ray, float tlim, float &t, float &s, float &u) {
     auto m = pr->m;
-    float os = fmaf(m[2], ray.o.z, fmaf(m[1], ray.o.y, fmaf(m[0], ray.o.x, m[3])));
-    float ot = fmaf(m[6], ray.o.z, fmaf(m[5], ray.o.y, fmaf(m[4], ray.o.x, m[7])));
+    float os = fmaf(m[MI_PM(2)], ray.o.z, fmaf(m[MI_PM(1)], ray.o.y, fmaf(m[MI_PM(0)], ray.o.x, m[MI_PM(3)])));
+    float ot = fmaf(m[MI_PM(6)], ray.o.z, fmaf(m[MI_PM(5)], ray.o.y, fmaf(m[MI_PM(4)], ray.o.x, m[MI_PM(7)])));
     float oh = fmaf(m[10], ray.o.z, fmaf(m[9], ray.o.y, fmaf(m[8], ray.o.x, m[11])));
-    float ds = fmaf(m[2], ray.d.z, fmaf(m[1], ray.d.y, m[0] * ray.d.x));
-    float dt = fmaf(m[6], ray.d.z, fmaf(m[5], ray.d.y, m[4] * ray.d.x));
+    float ds = fmaf(m[MI_PM(2)], ray.d.z, fmaf(m[MI_PM(1)], ray.d.y, m[MI_PM(0)] * ray.d.x));
+    float dt = fmaf(m[MI_PM(6)], ray.d.z, fmaf(m[MI_PM(5)], ray.d.y, m[MI_PM(4)] * ray.d.x));
     float dh = fmaf(m[10], ray.d.z, fmaf(m[9], ray.d.y, m[8] * ray.d.x));
     t = -oh * rcp_(dh);
     s = fmaf(ds, t, os); u = fmaf(dt, t, ot);
@@ -446,11 +457,11 @@ MI_DEV void prim_wait_issue(PrimRegs &cur, PrimRegs &nxt, MI_K(DPrim) *p) {
 }
 MI_DEV void prim_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 MI_DEV bool prim_test_regs(const PrimRegs &r, const Ray &ray, float tlim, float &t, float &s, float &u) {
-    float os = fmaf(r.a[2], ray.o.z, fmaf(r.a[1], ray.o.y, fmaf(r.a[0], ray.o.x, r.a[3])));
-    float ot = fmaf(r.a[6], ray.o.z, fmaf(r.a[5], ray.o.y, fmaf(r.a[4], ray.o.x, r.a[7])));
+    float os = fmaf(r.a[MI_PM(2)], ray.o.z, fmaf(r.a[MI_PM(1)], ray.o.y, fmaf(r.a[MI_PM(0)], ray.o.x, r.a[MI_PM(3)])));
+    float ot = fmaf(r.a[MI_PM(6)], ray.o.z, fmaf(r.a[MI_PM(5)], ray.o.y, fmaf(r.a[MI_PM(4)], ray.o.x, r.a[MI_PM(7)])));
     float oh = fmaf(r.b[2], ray.o.z, fmaf(r.b[1], ray.o.y, fmaf(r.b[0], ray.o.x, r.b[3])));
-    float ds = fmaf(r.a[2], ray.d.z, fmaf(r.a[1], ray.d.y, r.a[0] * ray.d.x));
-    float dt = fmaf(r.a[6], ray.d.z, fmaf(r.a[5], ray.d.y, r.a[4] * ray.d.x));
+    float ds = fmaf(r.a[MI_PM(2)], ray.d.z, fmaf(r.a[MI_PM(1)], ray.d.y, r.a[MI_PM(0)] * ray.d.x));
+    float dt = fmaf(r.a[MI_PM(6)], ray.d.z, fmaf(r.a[MI_PM(5)], ray.d.y, r.a[MI_PM(4)] * ray.d.x));
     float dh = fmaf(r.b[2], ray.d.z, fmaf(r.b[1], ray.d.y, r.b[0] * ray.d.x));
     t = -oh * rcp_(dh);
     s = fmaf(ds, t, os); u = fmaf(dt, t, ot);

@@ -1456,6 +1456,12 @@ static uint32_t bvh4_collapse(const std::vector<BinNode> &bn, int32_t b, std::ve
     return id;
 }
 // builds s->bvh, s->tris / tri_face / tri_shape (leaf order) and the refit level lists from the host mirrors of the BVH shapes
+// DPrim::m in device order (MI_PRIM_INTERLEAVE, mi355_device.h): the host builds rows, the kernels read interleaved (s, t) pairs
+static std::vector<DPrim> prims_for_device(const std::vector<DPrim> &in) {
+    std::vector<DPrim> out(in);
+    for (size_t k = 0; k < in.size(); ++k) for (int i = 0; i < 12; ++i) out[k].m[MI_PM(i)] = in[k].m[i];
+    return out;
+}
 static int build_scene_bvh(mi355_scene *s) {
     Phase ph(PHASE_INIT_ACCEL);
     s->bvh.clear(); s->tris.clear(); s->tri_face.clear(); s->tri_shape.clear(); s->bvh_levels.clear(); s->bvh_level_off.assign(1, 0u);
@@ -1888,7 +1894,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_normals, s->normals))) return rc;
     if ((rc = upload(&s->d_texcoords, s->texcoords))) return rc;
     if ((rc = upload(&s->d_bvh, s->bvh))) return rc;
-    if ((rc = upload(&s->d_prims, s->prims))) return rc;
+    if ((rc = upload(&s->d_prims, prims_for_device(s->prims)))) return rc;
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
@@ -2001,7 +2007,7 @@ static int rebuild_flat_tables(mi355_scene *s) {
         }
     }
     int rc;
-    if ((rc = reupload(&s->d_prims, &s->cap_prims, s->prims))) return rc;
+    if ((rc = reupload(&s->d_prims, &s->cap_prims, prims_for_device(s->prims)))) return rc;
     if ((rc = reupload(&s->d_fins, &s->cap_fins, s->fins))) return rc;
     if ((rc = reupload(&s->d_boxes, &s->cap_boxes, s->boxes))) return rc;
     s->ds.prims = s->d_prims; s->ds.fins = s->d_fins; s->ds.boxes = s->d_boxes;
