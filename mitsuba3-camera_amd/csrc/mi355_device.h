@@ -532,7 +532,7 @@ MI_DEV bool sphere_intersect(P sp, const Ray &ray, float tlim, float &t) {
 #define MI_BOX_FLAG 0x40000000u
 #define MI_SPHERE_FLAG 0x20000000u
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
-template <bool FULL>
+template <int FULL>
 MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
     Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
@@ -605,14 +605,14 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
             hit.u = b1; hit.v = b2;
         }
     }
-    if (FULL && sc.n_bvh_shapes) {                                          // (a scene with BVH meshes runs the FULL kernels: features bit 3)
+    if (FULL == 1 && sc.n_bvh_shapes) {                                          // (a scene with BVH meshes runs the FULL kernels: features bit 3)
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
         bvh_closest(sc, ray, inv_d, hit, active, stk);
     }
     return hit;
 }
 // Scene::ray_test (scene.cpp:201-210): any hit.
-template <bool FULL>
+template <int FULL>
 MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32_t *stk) {
     bool occluded = false;
     if (!__any(active)) return false;                                      // nobody in this wave asked
@@ -650,7 +650,7 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
         float t;
         if (sphere_intersect(spheres + k, ray, tlim, t)) { occluded = true; tlim = 0.f; }
     }
-    if (FULL && sc.n_bvh_shapes) {
+    if (FULL == 1 && sc.n_bvh_shapes) {
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
         occluded = bvh_any(sc, ray, inv_d, active && !occluded, stk) || occluded;
     }
@@ -660,7 +660,7 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
 // PreliminaryIntersection::compute_surface_interaction (interaction.h:642-668) ->
 // Rectangle / Mesh::compute_surface_interaction (rectangle.cpp:497-567 IsDiff branch, mesh.cpp:1375-1548)
 // -> finalize_surface_interaction (interaction.h:464-484).  Caller guarantees hit.t != inf.
-template <bool FULL>
+template <int FULL>
 MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
     SI si; si.t = hit.t; si.shape = (int32_t) hit.shape; si.prim = hit.prim;
     const DShape &sh = sc.shapes[hit.shape];                               // per-lane gather (divergent index)
@@ -971,12 +971,12 @@ MI_DEV void conductor_sample(const DBsdf &b, v3 wi, bool active, BSample &bs, v3
     v3 F = V3(fresnel_conductor_(wi.z, b.eta[0], b.k[0]), fresnel_conductor_(wi.z, b.eta[1], b.k[1]), fresnel_conductor_(wi.z, b.eta[2], b.k[2]));
     weight = active ? ld3(b.reflectance) * F : V3(0.f, 0.f, 0.f);
 }
-template <bool FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
+template <int FULL> MI_DEV void bsdf_eval_pdf(const DBsdf &b, v3 refl, v3 wi, v3 wo, bool active, v3 &val, float &pdf) {
     if (!FULL || b.type == MI355_BSDF_DIFFUSE) diffuse_eval_pdf(refl, wi, wo, active, val, pdf);
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_eval_pdf(b, wi, wo, active, val, pdf);
     else { val = V3(0.f, 0.f, 0.f); pdf = 0.f; }
 }
-template <bool FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, float s1, float s2x, float s2y, bool active, BSample &bs, v3 &weight,
+template <int FULL> MI_DEV void bsdf_sample(const DBsdf &b, v3 refl, v3 wi, float s1, float s2x, float s2y, bool active, BSample &bs, v3 &weight,
                                              bool importance = false) {
     if (!FULL || b.type == MI355_BSDF_DIFFUSE) { diffuse_sample(refl, wi, s2x, s2y, active, bs.wo, bs.pdf, weight); bs.eta = 1.f; bs.delta = false; }
     else if (b.type == MI355_BSDF_ROUGHCONDUCTOR) roughconductor_sample(b, wi, s2x, s2y, active, bs, weight);
@@ -1010,7 +1010,7 @@ MI_DEV void mesh_sample_position(const DScene &sc, const DShape &sh, float sx, f
     nn = normalize3(nn);
     n = (sh.flags & DSHAPE_FLIP) ? -nn : nn; pdf = norm;
 }
-template <bool FULL>
+template <int FULL>
 MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, float sy, bool active, DS &ds, v3 &spec, Ray &shadow) {
     ds.p = ds.n = ds.d = V3(0.f, 0.f, 0.f); ds.pdf = 0.f; ds.dist = 0.f; ds.emitter = -1; spec = V3(0.f, 0.f, 0.f);
     if (sc.n_emitters == 0) return false;
@@ -1074,7 +1074,7 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
     return active;                                                         // true: a shadow ray must be tested
 }
 // Scene::pdf_emitter_direction (scene.cpp:355-366) -> area.cpp:170-197 -> shape.cpp:377-388
-template <bool FULL>
+template <int FULL>
 MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 ref_p, v3 d, v3 n, float dist) {
     const DShape &sh = sc.shapes[sc.emitters[emitter].shape];
     float dp = dot3(d, n);
@@ -1257,7 +1257,7 @@ MI_DEV float radical_inverse(uint32_t base, uint32_t index) {
     return fminf(0.99999994f, (float) value * factor);
 }
 // render_sample head (integrator.cpp:433-455): pixel jitter, aperture sample when the sensor needs one, ray + ray weight
-template <bool FULL>
+template <int FULL>
 MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, float &pos_x, float &pos_y, Ray &ray) {
     pos_x = (float) px + next_1d(rng); pos_y = (float) py + next_1d(rng);                  // integrator.cpp:435
     if (FULL && sc.sensor_type == MI355_SENSOR_REALISTICLENS) {
@@ -1309,7 +1309,7 @@ MI_DEV void path_init(PathState &st, const Ray &ray, const Pcg32 &rng) {
 }
 // One iteration of the loop of path.cpp:142-281 at depth `it`.  Returns whether the lane continues; `hit_any` reports
 // a valid surface hit (feeds valid_ray, path.cpp:256).
-template <bool FULL>
+template <int FULL>
 MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
                       bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
     PROF_START(cnt);
@@ -1378,7 +1378,7 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
 // sampler call inside the loop of path.cpp:142-281 is UNMASKED and the loop masks by `active` alone, so a lane draws its six numbers
 // (next_2d, next_1d, next_2d, next_1d: :196, :212-213, :272) in EVERY iteration it enters -- also in the one where its ray leaves the
 // scene or reaches max_depth, where path_step (rightly, for a single pass) draws nothing.
-template <bool FULL>
+template <int FULL>
 MI_DEV void path_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth,
                         bool active, uint32_t *stk, v3 &result_out, bool &valid_out, Counters3 &cnt, bool keep_stream = false) {
     PathState st; path_init(st, ray, rng);
@@ -1412,7 +1412,7 @@ struct GradSink { float *s_grad; float *g_grad; float *q; uint32_t *qn; uint32_t
 // FWD (with BACKWARD): prb.py in dr.ADMode.Forward, driven by RBIntegrator.render_forward (common.py:498-629).  The same second walk
 // with L = state_in, but every d(Le + Lr_dir + Lr_ind)/d(theta) is contracted with the parameter TANGENT (sink.g_grad, laid out like the
 // gradient buffer; sink.small_map resolves the constant parameters) and summed into the lane's dL, returned in L_out.
-template <bool BACKWARD, bool FULL, bool FWD = false>
+template <bool BACKWARD, int FULL, bool FWD = false>
 MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                        bool active, uint32_t *stk, v3 dL, v3 state_in, GradSink sink,
                        v3 &L_out, bool &valid_out, Counters3 &cnt) {
@@ -1590,7 +1590,7 @@ MI_DEV void prb_sample(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth
 // One bounce of PRBIntegrator.sample in PRIMAL mode (prb.py:59-257, same arithmetic as prb_sample<false>) on the path
 // integrator's state record (throughput = beta, result = L), so that the re-packing kernel serves both integrators.
 // For a live path the loop counter is its depth (prb.py:249).
-template <bool FULL>
+template <int FULL>
 MI_DEV bool prb_primal_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth,
                             bool active, uint32_t *stk, bool &hit_any, Counters3 &cnt) {
     Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
@@ -1694,7 +1694,7 @@ MI_DEV float fix_to_float(unsigned long long v, float inv_scale) { return (float
 MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {
     const uint32_t c = threadIdx.x & ((1u << sink.copy_shift) - 1u);
     const uint32_t at = (((uint32_t) slot) << sink.copy_shift) + c, step = 1u << sink.copy_shift;
-    if ((fabsf(g.x) < sink.fix_limit) & (fabsf(g.y) < sink.fix_limit) & (fabsf(g.z) < sink.fix_limit)) {   // (false for NaN, and always when fix_limit = 0)
+    if (((int) (fabsf(g.x) < sink.fix_limit) & (int) (fabsf(g.y) < sink.fix_limit) & (int) (fabsf(g.z) < sink.fix_limit)) != 0) {   // (false for NaN, and always when fix_limit = 0)
         unsigned long long *fb = sink.s_fix + at;
         atomicAdd(fb, fix_from_float(g.x * sink.fix_scale)); atomicAdd(fb + step, fix_from_float(g.y * sink.fix_scale)); atomicAdd(fb + 2u * step, fix_from_float(g.z * sink.fix_scale));
     } else {
@@ -1760,7 +1760,7 @@ MI_DEV void radiance_grad_add(Prb1State &st, const GradSink1 &sink, int32_t slot
     st.rad = st.rad + g;
 }
 // `lane_tag` = the workgroup slot the path STARTED in (records and the published L_total * dL are keyed by it).
-template <bool FULL>
+template <int FULL>
 MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                       bool active, uint32_t *stk, const GradSink1 &sink, uint32_t lane_tag, Counters3 &cnt) {
     Hit hit = scene_intersect<FULL>(sc, st.ray, active, stk);
@@ -1877,7 +1877,7 @@ MI_DEV bool prb1_step(const DScene &sc, Prb1State &st, uint32_t it, uint32_t max
     cnt.shadow += wave_count(shadow_req);
     return alive;
 }
-template <bool FULL>
+template <int FULL>
 MI_DEV void prb_sample_1p(const DScene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool hide_emitters,
                           bool active, uint32_t *stk, v3 dL, GradSink1 sink, v3 &L_out, Counters3 &cnt) {
     Prb1State st; prb1_init(st, ray, rng, dL);
@@ -1951,7 +1951,7 @@ MI_DEV bool lens_sample_direction(const DScene &sc, v3 ref_p, float sx_, float s
     return true;
 }
 // PerspectiveCamera::sample_direction + importance, perspective.cpp:282-386
-template <bool FULL>
+template <int FULL>
 MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, float sx_, float sy_, v2 &uv, v3 &ds_p, float &weight) {
     const float *tw = sc.cam_to_world;
     v3 rel = p - V3(tw[3], tw[7], tw[11]);                                  // inverse of the rigid camera frame
@@ -1976,7 +1976,7 @@ MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, float sx_, float sy_
     return true;
 }
 // Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229
-template <bool FULL>
+template <int FULL>
 MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
     if (sh.type == MI355_SHAPE_MESH) { mesh_sample_position(sc, sh, sx, sy, p, n, pdf); return; }
     if (!FULL || sh.type == MI355_SHAPE_RECTANGLE) {
@@ -2098,7 +2098,7 @@ MI_DEV void pt_grad_add(const PtGradSink &sink, int32_t slot, v3 g) {
 }
 // connect_sensor, ptracer.cpp:286-371; `bsdf` = nullptr for a point on an emitter.  Returns whether a visibility ray was cast.
 // GRAD: `weight_unit` = weight / radiance of `emitter`; nothing is splatted, the gathered image adjoint goes to the sink.
-template <bool FULL, bool GRAD = false>
+template <int FULL, bool GRAD = false>
 MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bool seen, v2 uv, v3 ds_p, v3 weight, float sample_scale,
                            float *film, uint32_t *stk, v3 weight_unit = V3(0.f, 0.f, 0.f), uint32_t emitter = 0u, const PtGradSink *sink = nullptr,
                            const SplatQueue *queue = nullptr, bool add_radiance = true, v3 *dv_out = nullptr) {
@@ -2148,7 +2148,7 @@ MI_DEV SI si_from_position(v3 p, v3 n, int32_t shape) {                     // S
     si.wi = V3(0.f, 0.f, 1.f); si.prim = 0; si.shape = shape;
     return si;
 }
-template <bool FULL, bool GRAD = false>
+template <int FULL, bool GRAD = false>
 MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                            float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr, const SplatQueue *queue = nullptr,
                            int walk = 1, v3 *S = nullptr) {

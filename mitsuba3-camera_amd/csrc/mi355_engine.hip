@@ -96,9 +96,12 @@ constexpr const char *PHASE_INIT_SCENE = "Scene initialization", *PHASE_INIT_ACC
 // (only the FULL kernels traverse a BVH -- scenes with BVH meshes set features bit 3 -- so only they reserve the traversal stack:
 // the all-diffuse flat-primitive kernels keep their 27 KB and five workgroups per CU)
 #define REGION_BASIC CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS(false) * BLOCK)
-#define REGION_FLOATS(FULL) ((FULL) ? CMAX(CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS(true) * BLOCK), WAVES * STACK_WORDS) : REGION_BASIC)
-#define STACK_FLOATS(FULL) ((FULL) ? WAVES * STACK_WORDS : 64)
-#define STK_PTR(base, FULL, wave, lane_id) (reinterpret_cast<uint32_t *>(base) + ((FULL) ? (wave) * STACK_WORDS + (lane_id) : 0u))
+// FULL is a three-way switch: 0 = BASIC (diffuse, flat primitives), 1 = every feature INCLUDING the BVH traversal (its LDS stack, its
+// registers), 2 = every feature but no BVH in the scene (`features` bit 3 clear) -- the traversal costs the regen kernel 52 VGPRs and
+// half its occupancy on scenes that have no mesh to traverse (the Veach arrangement: spheres and rectangles only).
+#define REGION_FLOATS(FULL) ((FULL) ? CMAX(CMAX(WAVES * WAVE_FLOATS, CSTATE_WORDS(true) * BLOCK), (FULL) == 1 ? WAVES * STACK_WORDS : 0) : REGION_BASIC)
+#define STACK_FLOATS(FULL) ((FULL) == 1 ? WAVES * STACK_WORDS : 64)
+#define STK_PTR(base, FULL, wave, lane_id) (reinterpret_cast<uint32_t *>(base) + ((FULL) == 1 ? (wave) * STACK_WORDS + (lane_id) : 0u))
 
 struct RenderArgs {
     uint32_t seed, spp_total, max_depth, rr_depth, flags;
@@ -202,7 +205,7 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
     if (threadIdx.x < 3 && g_counters) atomicAdd(&g_counters[1 + threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
 }
 
-template <int INTEGRATOR, int OUT, bool FULL>
+template <int INTEGRATOR, int OUT, int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScen
 // Waves run independent trip counts: no workgroup barrier inside the loop, only wave-scope fences.
 // ---------------------------------------------------------------------------------------------------------------
 #define RING 128                            // records per wave: 63 waiting + 64 new at most
-#define RG_WAVE_WORDS(FULL) ((FULL) ? CMAX(STACK_WORDS, WAVE_FLOATS) : WAVE_FLOATS)   // per wave and private: BVH stack | splat staging (never live together)
+#define RG_WAVE_WORDS(FULL) ((FULL) == 1 ? CMAX(STACK_WORDS, WAVE_FLOATS) : WAVE_FLOATS)   // per wave and private: BVH stack | splat staging (never live together)
 MI_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -323,8 +326,8 @@ MI_DEV void ring_flush(const DScene &sc, float *stage, const float *ring, uint32
     }
 }
 
-template <bool FULL>
-__global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
+template <int FULL>
+__global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? 4 : MI_MIN_WAVES)) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS(FULL)];
     __shared__ float s_ring[WAVES * 5 * RING];
     __shared__ uint32_t s_cnt[4];
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_regen
 // from "6 bounces x 4 waves" to "sum over bounces of ceil(alive / 64)".  Final radiance returns to the lane's ORIGINAL
 // slot (`fin`) so that the per-pixel LDS film reduction still sees all samples of a pixel side by side.
 // ---------------------------------------------------------------------------------------------------------------
-template <int INTEGRATOR, bool FULL>
+template <int INTEGRATOR, int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
@@ -538,7 +541,7 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
 
 // RBIntegrator.render_forward (common.py:498-629): primal walk for L, forward-mode walk (same sampler stream) contracting every
 // d(Le + Lr_dir + Lr_ind)/d(theta) with the parameter tangents, dL splatted with weight 1 like a radiance sample.
-template <bool FULL>
+template <int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_render_forward(DScene sc, RenderArgs a, const float *tangent, const uint32_t *small_map,
                                                                                       float *film, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_render_f
     flush_counters(s_cnt, cnt, g_counters);
 }
 
-template <bool FULL>
+template <int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters, const uint32_t *redo) {
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_back
 // BVH = the scene has meshes that need the per-lane traversal stack (20 KB of LDS).  The small-parameter accumulators and
 // the record queue live in dynamic LDS: the host hands over whatever is left of 40 KB (four workgroups per CU) --
 // ~36 KB of queue on the Cornell box, ~16 KB with a traversal stack.
-template <bool FULL, bool BVH>
+template <int FULL, bool BVH>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backward_1p(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters, uint32_t *redo, uint32_t q_granules, uint32_t copy_shift) {
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 // GRAD (render_backward): the same lanes, but every connection GATHERS dL/dimage at its splat taps.  Radiance gradients need one walk;
 // with `all_params` every sample is walked twice from the same sampler state (see PtGradSink) for the albedo / texture gradients.
 // The small-parameter accumulators live in dynamic LDS: (n_small << copy_shift) floats.
-template <bool FULL, bool GRAD>
+template <int FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
 // Forward-mode derivative of the light-traced film with respect to the vertex positions of one mesh (mi355_geo_forward.h): the lanes
 // and sampler streams of k_ptracer, dual numbers alongside; the derivative splats are deferred like the primal ones (40-byte records,
 // k_splat_tiles<true>) unless MI355_FLAG_DIRECT_SPLAT asks for plain float atomics.
-template <bool FULL>
+template <int FULL>
 __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 // ---- geometry / IOR adjoint of the particle tracer (mi355_geo_backward.h) -----------------------------------------------------------
 // Lanes [lane_first, lane_first + n_chunk) of the shard: forward walk onto the HBM path tape, backward sweep into the gradient buffer.
 // Dynamic LDS: 2 floats per bsdf for the IOR adjoints (n_ior_lds = 2 * n_bsdfs, or 0 -> global atomics).
-template <bool FULL>
+template <int FULL>
 __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
                                                                GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
@@ -2266,6 +2269,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
+    const bool flat = full && s->ds.n_bvh_shapes == 0u;                      // every feature, but nothing to traverse: the <2> instantiations
     float *nof = nullptr;
     if (p->integrator == MI355_INTEGRATOR_PTRACER) {
         if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
@@ -2273,7 +2277,8 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         // Reconstruction filters with more than one tap: deferred, tile-sorted splat (see film_put_deferred).  The queue holds every
         // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
         SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, false, q))) return rc;
-        if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
+        if (flat) hipLaunchKernelGGL((k_ptracer<2, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
+        else if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
         else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
         HIP_TRY(hipGetLastError());
         if ((rc = splat_queue_flush(s, q, st, false, d_film_rgbw))) return rc;
@@ -2294,17 +2299,21 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PRB, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     } else if (p->integrator == MI355_INTEGRATOR_PRB) {
-        if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        if (flat) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, 2>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     } else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN) && p->mode != MI355_MODE_WAVEFRONT) {       // enough samples per pixel to keep a wave's pool full
         uint32_t n_waves = (a.pixel_count + a.ppw - 1) / a.ppw; dim3 rgrid((n_waves + WAVES - 1) / WAVES);
-        if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        if (flat) hipLaunchKernelGGL(k_render_regen<2>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL(k_render_regen<false>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     }
     else if (p->mode != MI355_MODE_STATIC) {
-        if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        if (flat) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, 2>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
+        else if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PATH, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
     }
+    else if (flat) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, 2>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     else if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
     HIP_TRY(hipGetLastError());

@@ -100,7 +100,7 @@ MI_DEV void tape_store(const GeoTape &tp, uint32_t lane, uint32_t k, const Ray &
 
 // One light sample, forward walk: mirrors ptracer_sample call for call and writes one tape record per vertex.  Returns the number of
 // vertices on the tape.
-template <bool FULL>
+template <int FULL>
 MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                                  uint32_t *stk, const GeoTape &tp, uint32_t lane) {
     const bool timed = sc.shutter_open_time > 0.f;
@@ -181,7 +181,7 @@ MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth
     return nv;
 }
 // Backward sweep over the `nv` tape records of one light sample, last vertex first: gradients into the sink.  No ray is traced here.
-template <bool FULL>
+template <int FULL>
 MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, const GeoBwdSink &sink) {
     gv3 lo = ga::mk<float>(0.f, 0.f, 0.f), ld = lo, lT = lo;               // lambda: adjoint of the ray / throughput LEAVING the current vertex
     ga::Sensor<float> se;
@@ -279,7 +279,7 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
 }
 
 // Walk + sweep in one call (the fused kernel: samples_per_pass > 1 re-uses the tape pass after pass).
-template <bool FULL>
+template <int FULL>
 MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                                    float sample_scale, uint32_t *stk, const GeoTape &tp, uint32_t lane, const GeoBwdSink &sink) {
     const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, max_depth, rr_depth, hide_emitters, lane_on, stk, tp, lane);

@@ -72,7 +72,7 @@ struct GeoTangent { uint32_t shape; const float *vtan; uint32_t bsdf; float d_re
 
 // Dual hit record at a primal hit (hit, si): point, geometric normal, shading normal, tangent frame, all as functions of the dual ray.
 struct DualHit { D3 p, ng, ns, sh_s, sh_t; };
-template <bool FULL>
+template <int FULL>
 MI_DEV DualHit dual_hit(const DScene &sc, const GeoTangent &gt, const Hit &hit, const SI &si, D3 o, D3 d) {
     DualHit h;
     const DShape &sh = sc.shapes[hit.shape];
@@ -196,7 +196,7 @@ MI_DEV void film_put_deferred_dual(const DScene &sc, const SplatQueue &q, float 
 }
 
 // One light sample: the control flow of ptracer_sample (same sampler calls, same decisions), with the geometry duals alongside.
-template <bool FULL>
+template <int FULL>
 MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                                float sample_scale, float *gfilm, uint32_t *stk, const SplatQueue *queue = nullptr) {
     const bool timed = sc.shutter_open_time > 0.f;
