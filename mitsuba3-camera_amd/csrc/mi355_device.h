@@ -2129,7 +2129,7 @@ MI_DEV bool connect_sensor(const DScene &sc, const SI &si, const DBsdf *bsdf, bo
         } else {
         v3 result = (weight * surface_weight) * sample_scale;
         const bool lit = result.x != 0.f || result.y != 0.f || result.z != 0.f;   // (a black splat changes nothing)
-        if (queue) film_put_deferred(sc, *queue, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result, lit);
+        if (queue && queue->cap) film_put_deferred(sc, *queue, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result, lit);
         else if (lit) film_put_normalized(sc, film, uv.x + (float) sc.crop_x, uv.y + (float) sc.crop_y, result);
         }
     }

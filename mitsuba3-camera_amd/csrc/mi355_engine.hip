@@ -868,7 +868,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, Rend
             ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, nullptr, 1, &S);
             ptracer_sample<FULL, GRAD>(sc, replay, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, nullptr, 2, &S);
         } else
-            ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, (!GRAD && queue.cap) ? &queue : nullptr);
+            ptracer_sample<FULL, GRAD>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, hide, on, sample_scale, film, stk, cnt, &sink, GRAD ? nullptr : &queue);   // (a compile-time choice: a run-time select of the pointer sends the by-value kernel argument to scratch and its pointers to the flat address space)
     }
     __syncthreads();
     if (GRAD) {
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs 
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     for (uint32_t pass = 0; pass < a.passes; ++pass)
-        ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk, queue.cap ? &queue : nullptr);
+        ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk, &queue);
 }
 
 // ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------

@@ -266,7 +266,7 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
                     Df correction = dabs((wi.z * wo_dot_geo_n) / (local_d.z * wi_dot_geo_n));
                     Df lobe = local_d.z * MI_INV_PI * correction * sw * sample_scale;
                     D3 V = (T * D3c(refl)) * lobe;
-                    if (queue) film_put_deferred_dual(sc, *queue, gfilm, px, py, V);
+                    if (queue && queue->cap) film_put_deferred_dual(sc, *queue, gfilm, px, py, V);
                     else film_put_dual(sc, gfilm, px, py, V);
                 }
             }
