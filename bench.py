@@ -245,7 +245,7 @@ def main():
         copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
     lanes_launch = cnt["n_gen"] / launches
-    roofline = valu_roofline(KERNEL_NAME, {"k_render_compact": "k_render_compact<0, false>", "k_render_regen": "k_render_regen<false>"}.get(KERNEL_NAME, "k_render<0, 1, false>"),
+    roofline = valu_roofline(KERNEL_NAME, {"k_render_compact": "k_render_compact<0, 0>", "k_render_regen": "k_render_regen<0>"}.get(KERNEL_NAME, "k_render<0, 1, 0>"),
                              kernel_ms, lanes_launch, alg)
     roofline["launches"] = int(launches)
     roofline["events_per_lane"] = {k: round(cnt[k] / max(cnt["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")}
@@ -317,7 +317,7 @@ def main():
         prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
                "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
                "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
-               "roofline": valu_roofline("k_prepare_grad + k_prb_backward_1p (+ redo)", "k_prb_backward_1p<false, false>",
+               "roofline": valu_roofline("k_prepare_grad + k_prb_backward_1p (+ redo)", "k_prb_backward_1p<0, false>",
                                          c3["kernel_ms"] / max(c3["kernel_launches"], 1), c3["n_gen"] / max(c3["kernel_launches"], 1),
                                          # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
                                          ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
