@@ -23,6 +23,13 @@
  *   ParticleTracerIntegrator::sample under                src/integrators/ptracer.cpp:77-371,
  *     AdjointIntegrator::render (+ render_backward)       src/render/integrator.cpp:545-745, :65-84
  *   Film::sample_border, samples_per_pass                 src/render/film.cpp:32, src/render/integrator.cpp:133-150,319-329
+ *   Mesh::parameters_changed (vertex_positions: bbox,     src/render/mesh.cpp:96-163, :321-413,
+ *     vertex normals, area pmf) + Scene::parameters_changed src/render/scene.cpp:481-529  -> device-side refit, no rebuild
+ *   dr.backward() through ptracer onto vertex_positions   notebooks/scripts/lens_design/lens.py:505-565, design_problem.py:403-428, :481-584
+ *     and IORs (reverse-mode geometry adjoint)              (AD in the reference; src/bsdfs/dielectric.cpp:236-239, :343-351)
+ *   the film / weight / gradient all-reduce of a           -- (the reference is single-GPU): mi355_set_reduce_hook
+ *     multi-GPU job
+ *   ProfilerPhase ranges                                   include/mitsuba/core/profiler.h:15-113 -> roctx ranges of the same names
  *
  * Conventions
  *   - plain C, no torch / HIP types in any signature; `void *stream` is a hipStream_t
