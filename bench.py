@@ -66,6 +66,36 @@ def microbench_cycles(waves=5):
     return None
 
 
+def microbench(op, waves=8):
+    """cycles (wall time x nominal clock) per VALU instruction of one stream of profiles/r02_valu_issue.json"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) as f:
+            for r in json.load(f)["results"]:
+                if r["op"].startswith(op) and r["waves_per_simd"] == waves:
+                    return r["cyc_per_inst_wall"]
+    except Exception:
+        pass
+    return None
+
+
+def issue_model(c):
+    """All-instruction issue model from the microbenchmark: on this chip a SIMD issues ONE instruction of any kind per ~2.2 cycles -- a
+    scalar instruction interleaved with every v_fma doubles the stream's time (4.46 vs 2.29 cycles per VALU instruction at 8 waves) -- and
+    a transcendental in a v_fma stream costs ~12.7.  Modelled SIMD cycles of a launch = (instructions - transcendentals) * c_any +
+    transcendentals * c_trans, spread over the 1024 SIMDs; returned with the instruction counts it was built from."""
+    fma, pair, mix = microbench("v_fma_f32", 8), microbench("v_fma_f32 + s_add_u32", 8), microbench("7 v_fma_f32 + 1 v_rcp_f32", 8)
+    if not (fma and pair and mix) or "SQ_INSTS_VALU" not in c:
+        return None
+    c_any = pair / 2.0                                     # a (VALU, SALU) pair costs `pair`
+    c_trans = 8.0 * mix - 7.0 * fma                        # what the one v_rcp in eight instructions costs
+    n_all = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
+    n_trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    cycles = ((n_all - n_trans) * c_any + n_trans * c_trans) / N_SIMD
+    return {"instructions_all": int(n_all), "transcendentals": int(n_trans), "cycles_per_instruction_any": round(c_any, 3), "cycles_per_transcendental": round(c_trans, 2),
+            "modelled_ms_at_nominal_clock": round(cycles / (PEAK_CLOCK_GHZ * 1e6), 3),
+            "note": "issue-slot model from tools/valu_issue_bench.hip (profiles/r02_valu_issue.json): every instruction of a wave -- scalar ones too -- takes a SIMD issue slot"}
+
+
 def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes):
     """roofline block of a fused path kernel: bound = wave64 VALU issue.  Instruction count and HBM traffic per launch are read from
     the committed PMC pass (scaled by lanes when this launch covers a different number of lanes than the profiled one), the time is the
@@ -85,6 +115,12 @@ def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes)
                             "cycles_per_inst_pmc": (round(c["GRBM_GUI_ACTIVE"] / 8 * N_SIMD / c["SQ_INSTS_VALU"], 3) if c.get("GRBM_GUI_ACTIVE") else None),
                             "waves": c.get("SQ_WAVES"), "insts_per_wave": {k[9:].lower(): round(c[k] / c["SQ_WAVES"], 1) for k in
                                 ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if k in c and c.get("SQ_WAVES")}}})
+        im = issue_model(c)
+        if im is not None:
+            im["modelled_ms_at_nominal_clock"] = round(im["modelled_ms_at_nominal_clock"] * scale, 3)
+            im["instructions_all"] = int(im["instructions_all"] * scale); im["transcendentals"] = int(im["transcendentals"] * scale)
+            im["frac_of_model"] = round(im["modelled_ms_at_nominal_clock"] / kernel_ms, 4)
+            out["issue_model"] = im
         if "hbm_write_bytes" in rec and "hbm_read_bytes" in rec:
             traffic = (rec["hbm_read_bytes"][1] + rec["hbm_write_bytes"]) * scale        # read side: the x2-corrected upper bound
             out["traffic"] = int(traffic)

@@ -13,7 +13,8 @@
 //   cyc_per_inst_wall       kernel wall time (HIP events) * clock / (k * instructions): the same from outside, clock = the value
 //                           returned by hipDeviceGetAttribute(ClockRate); under load the chip may clock lower (DVFS), which makes
 //                           this figure read HIGH -- s_memtime counts shader cycles and is the one to use.
-// Also a transcendental stream (v_rcp_f32) for the 2 : 1 mix weight.
+// Also a transcendental stream (v_rcp_f32), a stream with one independent SALU instruction after every VALU one (n_inst still counts the
+// VALU instructions only: the excess over the plain stream is what a scalar instruction costs the wave / the SIMD), and a 7 : 1 fma : rcp mix.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void k_issue(float *out, int iters, unsigned l
     extern __shared__ float pad[];
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float b = 0.999f, c = 1e-3f;
+    unsigned s0 = blockIdx.x, s1 = blockIdx.x + 1u;
     if (iters < 0) pad[threadIdx.x] = a0;                                   // keeps the LDS allocation alive
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -38,17 +40,27 @@ __global__ __launch_bounds__(256) void k_issue(float *out, int iters, unsigned l
                 asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
-            } else {
+            } else if (OP == 1) {
                 asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
                              "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 2) {                                           // every v_fma followed by an independent scalar add: does a SALU instruction cost the wave a VALU issue slot?
+                asm volatile("v_fma_f32 %0, %0, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %1, %1, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             "v_fma_f32 %2, %2, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %3, %3, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             "v_fma_f32 %4, %4, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             "v_fma_f32 %6, %6, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %7, %7, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1) : "v"(b), "v"(c) : "scc");
+            } else {                                                        // the forward kernel's transcendental share: 1 v_rcp per 7 v_fma
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_rcp_f32 %3, %3\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float) (s0 + s1);
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -60,13 +72,13 @@ int main() {
     const double n_inst = (double) iters * 128.0;
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"instructions_per_wave\": %.0f, \"results\": [", prop.name, prop.gcnArchName, cus, clock_khz, n_inst);
     bool first = true;
-    for (int op = 0; op < 2; ++op)
+    for (int op = 0; op < 4; ++op)
         for (int k : { 1, 2, 3, 4, 5, 6, 8 }) {
             const int blocks = cus * k;
             const size_t lds = 0;
             float *out; unsigned long long *cyc;
             CHECK(hipMalloc((void **) &out, (size_t) blocks * 256 * 4)); CHECK(hipMalloc((void **) &cyc, (size_t) blocks * 4 * 8));
-            auto kern = op == 0 ? k_issue<0> : k_issue<1>;
+            auto kern = op == 0 ? k_issue<0> : (op == 1 ? k_issue<1> : (op == 2 ? k_issue<2> : k_issue<3>));
             CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, out, iters, cyc);   // warm-up
@@ -80,7 +92,7 @@ int main() {
             std::sort(h.begin(), h.end());
             const double med = (double) h[h.size() / 2], lo = (double) h[h.size() / 20], hi = (double) h[h.size() - 1 - h.size() / 20];
             printf("%s\n  {\"op\": \"%s\", \"waves_per_simd\": %d, \"workgroups\": %d, \"kernel_ms\": %.4f, \"cyc_per_inst_smemtime\": %.3f, \"p05\": %.3f, \"p95\": %.3f, \"cyc_per_inst_wall\": %.3f}",
-                   first ? "" : ",", op == 0 ? "v_fma_f32" : "v_rcp_f32", k, blocks, ms, med / (k * n_inst), lo / (k * n_inst), hi / (k * n_inst),
+                   first ? "" : ",", op == 0 ? "v_fma_f32" : (op == 1 ? "v_rcp_f32" : (op == 2 ? "v_fma_f32 + s_add_u32 (per VALU instruction)" : "7 v_fma_f32 + 1 v_rcp_f32 (per instruction)")), k, blocks, ms, med / (k * n_inst), lo / (k * n_inst), hi / (k * n_inst),
                    ms * 1e-3 * clock_khz * 1e3 / (k * n_inst));
             first = false;
             CHECK(hipFree(out)); CHECK(hipFree(cyc));
