@@ -308,3 +308,35 @@ def _surface_z(element, name, value, x0, y0):
         return element.surface.compute_z(x0, y0)
     finally:
         element.surface.params[name] = keep
+
+
+def test_parameter_updates_are_validated(mi, torch_cuda):
+    """Error behaviour of the geometry / IOR parameters at the C ABI (the counterpart of Mesh::parameters_changed refusing a changed vertex
+    count, mesh.cpp:96-104): wrong sizes, wrong kinds of target, non-positive indices and non-finite positions fail with MI355_ERR_INVALID
+    and leave the scene as it was."""
+    import ctypes as C
+    torch = torch_cuda
+    scene = mi.load_dict(_cap_lens_scene(mi, 32)); lib = mi.abi.lib(); h = scene.handle()
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5})
+    before = integ.render(scene, seed=2, spp=16).clone()
+    lens = _shape_index(scene, "lens"); screen = [i for i, sh in enumerate(scene.shapes) if sh.type != mi.abi.SHAPE_MESH][0]
+    nv = scene.shapes[lens].vertex_positions.shape[0]
+    good = np.ascontiguousarray(scene.shapes[lens].vertex_positions, dtype=np.float32).reshape(-1)
+    f32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    E = mi.abi.ERR_INVALID
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, lens, f32(good[:-3].copy()), 3 * (nv - 1)) == E       # vertex count changed
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, screen, f32(good), good.size) == E                    # not a mesh
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, 10 ** 6, f32(good), good.size) == E                   # no such shape
+    bad = good.copy(); bad[7] = np.nan
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, lens, f32(bad), bad.size) == E                        # non-finite position
+    glass = [i for i, b in enumerate(scene.bsdfs) if b.type == mi.abi.BSDF_DIELECTRIC][0]
+    other = [i for i, b in enumerate(scene.bsdfs) if b.type != mi.abi.BSDF_DIELECTRIC][0]
+    two = np.array([1.5, 1.0], dtype=np.float32)
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_BSDF_IOR, other, f32(two), 2) == E                                      # not a dielectric
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_BSDF_IOR, glass, f32(two), 3) == E                                      # wrong size
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_BSDF_IOR, glass, f32(np.array([0.0, 1.0], dtype=np.float32)), 2) == E   # non-positive index
+    assert b"" != lib.mi355_last_error()
+    after = integ.render(scene, seed=2, spp=16)
+    assert torch.allclose(after, before, rtol=1e-5, atol=1e-7)                                                               # nothing was applied (float-atomic order aside)
+    assert lib.mi355_scene_set_param(h, mi.abi.PARAM_BSDF_IOR, glass, f32(two), 2) == 0 and lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, lens, f32(good), good.size) == 0
+    scene.release()
