@@ -2079,11 +2079,20 @@ static int set_geometry_param(mi355_scene *s, uint32_t kind, uint32_t index, con
         // the host mirror is what the flat tables and the emitter tables are rebuilt from; a mesh in the scene BVH that is not sampled
         // is refitted entirely on the device and needs no host copy (no D2H transfer, no synchronisation)
         bool need_host = sh.bvh_root < 0 || sh.emitter >= 0; for (const DEmitter &e : s->emitters) need_host = need_host || e.shape == index;
-        if (device_src) {
-            HIP_TRY(hipMemcpyAsync(d, values, count * 4, hipMemcpyDeviceToDevice, st));
-            if (need_host) { HIP_TRY(hipMemcpyAsync(h, values, count * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
-        } else { memcpy(h, values, count * 4); HIP_TRY(hipMemcpy(d, values, count * 4, hipMemcpyHostToDevice)); }
-        if (need_host || !device_src) for (uint64_t k = 0; k < count; ++k) if (!std::isfinite(h[k])) return fail(MI355_ERR_INVALID, "vertex_positions contains a non-finite value");
+        // values that reach the host are validated BEFORE anything is applied (a failed update leaves the scene as it was); a device-to-device
+        // update of a BVH-only mesh is not read back -- its values are the caller's responsibility (a non-finite vertex gives its triangles
+        // an empty box: they are never hit)
+        std::vector<float> staged;
+        const float *src_host = device_src ? nullptr : values;
+        if (device_src && need_host) {
+            staged.resize(count);
+            HIP_TRY(hipMemcpyAsync(staged.data(), values, count * 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+            src_host = staged.data();
+        }
+        if (src_host) for (uint64_t k = 0; k < count; ++k) if (!std::isfinite(src_host[k])) return fail(MI355_ERR_INVALID, "vertex_positions contains a non-finite value");
+        if (device_src) HIP_TRY(hipMemcpyAsync(d, values, count * 4, hipMemcpyDeviceToDevice, st));
+        else HIP_TRY(hipMemcpy(d, values, count * 4, hipMemcpyHostToDevice));
+        if (src_host) memcpy(h, src_host, count * 4);
         s->dirty[index] = 1; s->geom_dirty = true;
         return MI355_OK;
     }
