@@ -340,3 +340,36 @@ def test_parameter_updates_are_validated(mi, torch_cuda):
     assert torch.allclose(after, before, rtol=1e-5, atol=1e-7)                                                               # nothing was applied (float-atomic order aside)
     assert lib.mi355_scene_set_param(h, mi.abi.PARAM_BSDF_IOR, glass, f32(two), 2) == 0 and lib.mi355_scene_set_param(h, mi.abi.PARAM_VERTEX_POSITIONS, lens, f32(good), good.size) == 0
     scene.release()
+
+
+def test_geometry_backward_shards_add_up(mi, torch_cuda):
+    """Multi-GPU decomposition of BASELINE configs[4]: the light-sample grid cut into 16-row tiles dealt to 3 ranks (ragged: 40 rows),
+    into pixel bands and into spp slices -- the geometry / IOR gradients of the shards add up to the gradient of the whole job (global
+    lane ids: the same light paths whoever traces them)."""
+    import ctypes as C
+    torch = torch_cuda
+    res, spp, seed = 40, 32, 5
+    scene = mi.load_dict(_cap_lens_scene(mi, res))
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5})
+    params = mi.traverse(scene)
+    gin = torch.tensor(np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32), device="cuda")
+    whole = integ.render_backward(scene, params, gin, seed=seed, spp=spp, geometry=True, colour=True).clone()
+    assert float(whole.abs().max()) > 0
+    lib = mi.abi.lib(); h = scene.handle()
+    fw, fh = integ.lane_grid(scene.sensor.film)
+    decompositions = {"tiles": [dict(shard=mi.shard_tiles(fw, fh, r, 3)) for r in range(3)],
+                      "bands": [dict(shard=mi.shard_pixels(fw * fh, r, 4)) for r in range(4)],
+                      "spp": [dict(spp_shard=(s0, 8)) for s0 in range(0, spp, 8)]}
+    for name, parts in decompositions.items():
+        acc = torch.zeros_like(whole)
+        for kw in parts:
+            p = integ._params(scene, seed, spp, **kw); p.flags |= mi.abi.FLAG_GEOMETRY_GRADS
+            mi.abi.check(lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), None, C.c_void_p(acc.data_ptr()), None))
+        torch.cuda.synchronize()
+        err = float((acc - whole).abs().max()) / float(whole.abs().max())
+        assert err < 2e-4, (name, err)
+    # the path tape bounds max_depth: an unbounded light path cannot be differentiated this way
+    p = mi.ParticleTracerIntegrator({"max_depth": -1, "rr_depth": 5})._params(scene, seed, spp); p.flags |= mi.abi.FLAG_GEOMETRY_GRADS
+    acc = torch.zeros_like(whole)
+    assert lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), None, C.c_void_p(acc.data_ptr()), None) == mi.abi.ERR_UNSUPPORTED
+    scene.release()
