@@ -373,3 +373,32 @@ def test_geometry_backward_shards_add_up(mi, torch_cuda):
     acc = torch.zeros_like(whole)
     assert lib.mi355_render_backward(h, C.byref(p), C.c_void_p(gin.data_ptr()), None, C.c_void_p(acc.data_ptr()), None) == mi.abi.ERR_UNSUPPORTED
     scene.release()
+
+
+def test_geometry_adjoint_with_samples_per_pass(mi, torch_cuda):
+    """`samples_per_pass` (AdjointIntegrator::render, integrator.cpp:700-726): one seeding, every stream continued over the passes.  The
+    geometry adjoint walks the passes of a stream in one launch and re-uses its tape slot pass after pass; the transpose identity with the
+    forward mode (which walks the same passes) must hold, and the gradient must differ from the one-pass gradient (different streams)."""
+    torch = torch_cuda
+    res, spp, seed = 32, 64, 7
+    scene = mi.load_dict(_cap_lens_scene(mi, res))
+    params = mi.traverse(scene)
+    pos = params["lens.vertex_positions"].reshape(-1, 3).clone(); pos[:, 2] = 1.0 + (pos[:, 2] - 1.0) * 1.03
+    params["lens.vertex_positions"] = pos.reshape(-1); params.update()
+    rng = np.random.default_rng(3)
+    gin = torch.tensor(rng.uniform(0.5, 1.5, (res, res, 3)).astype(np.float32), device="cuda")
+    vt = torch.tensor(rng.normal(size=tuple(pos.shape)).astype(np.float32) * 0.1, device="cuda")
+    grads = {}
+    for per in (-1, 16):
+        integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5, "samples_per_pass": per})
+        params.zero_grad()
+        integ.render_backward(scene, params, gin, seed=seed, spp=spp, geometry=True)
+        gv = params.grad("lens.vertex_positions").reshape(-1, 3).clone()
+        jv = integ.render_forward_design(scene, shape="lens", vertex_tangent=vt, seed=seed, spp=spp)
+        lhs, rhs = float((gin * jv).sum()), float((gv * vt).sum())
+        assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), abs(rhs)), (per, lhs, rhs)
+        grads[per] = gv
+    assert float((grads[-1] - grads[16]).abs().max()) > 1e-3 * float(grads[-1].abs().max())       # 4 passes of 16 are other streams than 1 pass of 64
+    rel = float((grads[-1] - grads[16]).norm() / grads[-1].norm())
+    assert rel < 0.5, rel                                                                          # ... of the same estimator
+    scene.release()
