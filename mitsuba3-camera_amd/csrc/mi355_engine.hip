@@ -842,8 +842,11 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 // GRAD (render_backward): the same lanes, but every connection GATHERS dL/dimage at its splat taps.  Radiance gradients need one walk;
 // with `all_params` every sample is walked twice from the same sampler state (see PtGradSink) for the albedo / texture gradients.
 // The small-parameter accumulators live in dynamic LDS: (n_small << copy_shift) floats.
+#ifndef MI_PT_WAVES_FULL
+#define MI_PT_WAVES_FULL 4                  // k_ptracer forward, FULL: 128 VGPRs with 16 spilled beat 143 unspilled at 3 waves (lens doublet render 9.88 -> 8.23 ms)
+#endif
 template <int FULL, bool GRAD>
-__global__ __launch_bounds__(BLOCK, FULL ? 3 : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
+__global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? 3 : MI_PT_WAVES_FULL) : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
@@ -1102,8 +1105,11 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 // ---- geometry / IOR adjoint of the particle tracer (mi355_geo_backward.h) -----------------------------------------------------------
 // Lanes [lane_first, lane_first + n_chunk) of the shard: forward walk onto the HBM path tape, backward sweep into the gradient buffer.
 // Dynamic LDS: 2 floats per bsdf for the IOR adjoints (n_ior_lds = 2 * n_bsdfs, or 0 -> global atomics).
+#ifndef MI_GEO_BWD_WAVES
+#define MI_GEO_BWD_WAVES 3                 // 168 VGPRs + 116 B of scratch at 3 waves beat 219 unspilled at 2 (lens doublet 9.15 -> 7.96 ms)
+#endif
 template <int FULL>
-__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
+__global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
                                                                GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     extern __shared__ float s_ior_dyn[];
