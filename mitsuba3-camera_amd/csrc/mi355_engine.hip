@@ -845,8 +845,14 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 #ifndef MI_PT_WAVES_FULL
 #define MI_PT_WAVES_FULL 4                  // k_ptracer forward, FULL: 128 VGPRs with 16 spilled beat 143 unspilled at 3 waves (lens doublet render 9.88 -> 8.23 ms)
 #endif
+#ifndef MI_PT_WAVES_GRAD_FULL
+#define MI_PT_WAVES_GRAD_FULL 4             // (same trade as the forward kernel: lens doublet colour backward 10.09 -> 8.37 ms)
+#endif
+#ifndef MI_PT_WAVES_GRAD_BASIC
+#define MI_PT_WAVES_GRAD_BASIC 5            // (Cornell box, all parameters: 10.08 -> 9.54 ms)
+#endif
 template <int FULL, bool GRAD>
-__global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? 3 : MI_PT_WAVES_FULL) : 4) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
+__global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT_WAVES_FULL) : (GRAD ? MI_PT_WAVES_GRAD_BASIC : 4)) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
@@ -887,8 +893,11 @@ __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? 3 : MI_PT_WAVES_FULL) : 4) vo
 // Forward-mode derivative of the light-traced film with respect to the vertex positions of one mesh (mi355_geo_forward.h): the lanes
 // and sampler streams of k_ptracer, dual numbers alongside; the derivative splats are deferred like the primal ones (40-byte records,
 // k_splat_tiles<true>) unless MI355_FLAG_DIRECT_SPLAT asks for plain float atomics.
+#ifndef MI_GEO_FWD_WAVES
+#define MI_GEO_FWD_WAVES 3                 // (forward design mode 12.1 -> 11.0 ms)
+#endif
 template <int FULL>
-__global__ __launch_bounds__(BLOCK, 2) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue) {
+__global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
