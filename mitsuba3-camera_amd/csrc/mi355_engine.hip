@@ -326,8 +326,11 @@ MI_DEV void ring_flush(const DScene &sc, float *stage, const float *ring, uint32
     }
 }
 
+#ifndef MI_REGEN_WAVES_FLAT
+#define MI_REGEN_WAVES_FLAT 4
+#endif
 template <int FULL>
-__global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? 4 : MI_MIN_WAVES)) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
+__global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? MI_REGEN_WAVES_FLAT : MI_MIN_WAVES)) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS(FULL)];
     __shared__ float s_ring[WAVES * 5 * RING];
     __shared__ uint32_t s_cnt[4];
