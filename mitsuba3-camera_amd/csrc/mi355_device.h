@@ -351,6 +351,125 @@ MI_DEV void bvh4_sort(Bvh4Hits &h) {                                       // ne
     MI_CSWAP(0, 1) MI_CSWAP(2, 3) MI_CSWAP(0, 2) MI_CSWAP(1, 3) MI_CSWAP(1, 2)
 #undef MI_CSWAP
 }
+// PHASED traversal (MI_BVH_PHASED, default): the straightforward loop below tests the triangles of a node's leaf children inside the
+// node step, so one lane that has reached the bottom of the tree holds its wave for up to 16 triangle tests per trip while the other
+// lanes still walk inner nodes -- on incoherent rays (the light tracer's samples are independent per lane) 27 % of the VALU lanes were
+// busy (profiles/r02_pmc_lens_summary.txt).  Here the two kinds of work are separated in TIME, in the manner of Aila & Laine's
+// "while-while" loop: phase A walks inner nodes only and POSTPONES every leaf child it accepts into a per-lane FIFO (the top end of the
+// lane's LDS stack; the inner-node stack grows from the bottom), and it keeps going -- speculatively, for lanes that already hold a
+// leaf -- until every lane that can still walk holds at least one; phase B then tests the postponed triangles, ONE per lane and trip,
+// until all FIFOs are empty; then A again.  Closest-hit semantics are unchanged (every accepted leaf is tested, the nearest t wins; the
+// test ORDER differs, so an exact tie between two triangles may resolve to the other one).
+#ifndef MI_BVH_PHASED
+#define MI_BVH_PHASED 1
+#endif
+#define MI_QSTK(i) stk[(MI_BVH_STACK - 1 - (i)) * 64]
+#if MI_BVH_PHASED
+MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
+    int sp = 0, qh = 0, qt = 0;                                            // inner stack [0, sp) from the bottom; leaf FIFO [qh, qt) from the top
+    uint32_t node = active ? 0u : MI_BVH_EMPTY, tri = 0u, left = 0u;
+    if (active) BVH_STAT(0, 1);
+    for (;;) {
+        for (;;) {                                                         // ---- phase A: inner nodes
+            const bool can = node != MI_BVH_EMPTY, empty = qh == qt;
+            if (!__any(can && empty)) break;                               // every lane that can still walk holds a leaf (or none can walk)
+            const bool room = sp + qt + 7 <= MI_BVH_STACK;                 // 3 pushes + 4 leaves
+            if (can && (room || empty)) {
+                Bvh4Hits h = bvh4_node(sc, node, ray, inv_d, ray.maxt);
+                BVH_STAT(1, 1);
+                bvh4_sort(h);
+                uint32_t next = MI_BVH_EMPTY;
+#pragma unroll
+                for (int c = 3; c >= 0; --c)
+                    if (h.tn[c] != MI_INF && !(h.e[c] & MI_BVH_LEAF)) { if (next != MI_BVH_EMPTY && sp + qt < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (h.tn[c] <= ray.maxt && (h.e[c] & MI_BVH_LEAF)) {
+                        if (room) { MI_QSTK(qt) = h.e[c]; qt++; }
+                        else {                                             // (a stack this deep is all but unreachable: test the leaf on the spot)
+                            const uint32_t first = h.e[c] & 0x1fffffffu, count = ((h.e[c] >> 29) & 3u) + 1u;
+                            BVH_STAT(2, count);
+                            for (uint32_t k = 0; k < count; ++k) {
+                                float t, u, v;
+                                if (tri_intersect(sc.tris[first + k], ray, t, u, v) && t < hit.t) {
+                                    hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[first + k]; hit.shape = sc.tri_shape[first + k]; ray.maxt = t;
+                                }
+                            }
+                        }
+                    }
+                if (next != MI_BVH_EMPTY) node = next;
+                else if (sp > 0) { --sp; node = MI_STK(sp); }
+                else node = MI_BVH_EMPTY;
+            }
+        }
+        while (__any(left != 0u || qh != qt)) {                            // ---- phase B: one postponed triangle per lane and trip
+            if (left == 0u && qh != qt) {
+                const uint32_t e = MI_QSTK(qh); qh++;
+                tri = e & 0x1fffffffu; left = ((e >> 29) & 3u) + 1u;
+                if (qh == qt) qh = qt = 0;
+            }
+            if (left != 0u) {
+                float t, u, v;
+                BVH_STAT(2, 1);
+                if (tri_intersect(sc.tris[tri], ray, t, u, v) && t < hit.t) {
+                    hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[tri]; hit.shape = sc.tri_shape[tri]; ray.maxt = t;
+                }
+                tri++; left--;
+            }
+        }
+        if (!__any(node != MI_BVH_EMPTY)) break;
+    }
+}
+MI_DEV bool bvh_any(const DScene &sc, const Ray &ray, v3 inv_d, bool active, uint32_t *stk) {
+    bool occluded = false;
+    int sp = 0, qh = 0, qt = 0;
+    uint32_t node = active ? 0u : MI_BVH_EMPTY, tri = 0u, left = 0u;
+    if (active) BVH_STAT(0, 1);
+    for (;;) {
+        for (;;) {
+            const bool can = node != MI_BVH_EMPTY, empty = qh == qt;
+            if (!__any(can && empty)) break;
+            const bool room = sp + qt + 7 <= MI_BVH_STACK;
+            if (can && (room || empty)) {
+                const Bvh4Hits h = bvh4_node(sc, node, ray, inv_d, ray.maxt);
+                BVH_STAT(1, 1);
+                uint32_t next = MI_BVH_EMPTY;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (h.tn[c] == MI_INF) continue;
+                    if (h.e[c] & MI_BVH_LEAF) {
+                        if (room) { MI_QSTK(qt) = h.e[c]; qt++; }
+                        else {
+                            const uint32_t first = h.e[c] & 0x1fffffffu, count = ((h.e[c] >> 29) & 3u) + 1u;
+                            BVH_STAT(2, count);
+                            for (uint32_t k = 0; k < count; ++k) { float t, u, v; if (tri_intersect(sc.tris[first + k], ray, t, u, v)) occluded = true; }
+                        }
+                    } else { if (next != MI_BVH_EMPTY && sp + qt < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
+                }
+                if (next != MI_BVH_EMPTY) node = next;
+                else if (sp > 0) { --sp; node = MI_STK(sp); }
+                else node = MI_BVH_EMPTY;
+                if (occluded) { node = MI_BVH_EMPTY; sp = 0; qh = qt = 0; }
+            }
+        }
+        while (__any(left != 0u || qh != qt)) {
+            if (left == 0u && qh != qt) {
+                const uint32_t e = MI_QSTK(qh); qh++;
+                tri = e & 0x1fffffffu; left = ((e >> 29) & 3u) + 1u;
+                if (qh == qt) qh = qt = 0;
+            }
+            if (left != 0u) {
+                float t, u, v;
+                BVH_STAT(2, 1);
+                if (tri_intersect(sc.tris[tri], ray, t, u, v)) { occluded = true; node = MI_BVH_EMPTY; sp = 0; qh = qt = 0; left = 1u; }
+                tri++; left--;
+            }
+        }
+        if (!__any(node != MI_BVH_EMPTY)) break;
+    }
+    return occluded;
+}
+#else
 MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
     int sp = 0; uint32_t node = 0u; bool have = active;
     if (active) BVH_STAT(0, 1);
@@ -403,6 +522,7 @@ MI_DEV bool bvh_any(const DScene &sc, const Ray &ray, v3 inv_d, bool active, uin
     }
     return occluded;
 }
+#endif
 
 // One flat primitive against one ray: 18 fma for the affine map, one v_rcp, two fma, then a branch-free
 // bounds test.  `tlim` is an EXCLUSIVE upper bound on t (next float above ray.maxt, or the closest hit so far).
