@@ -364,6 +364,9 @@ MI_DEV void bvh4_sort(Bvh4Hits &h) {                                       // ne
 #define MI_BVH_PHASED 1
 #endif
 #define MI_QSTK(i) stk[(MI_BVH_STACK - 1 - (i)) * 64]
+#ifndef MI_BVH_QCULL
+#define MI_BVH_QCULL 1                      // closest hit: keep a postponed leaf's entering distance and drop the leaf when a nearer hit was found meanwhile
+#endif
 #if MI_BVH_PHASED
 MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
     int sp = 0, qh = 0, qt = 0;                                            // inner stack [0, sp) from the bottom; leaf FIFO [qh, qt) from the top
@@ -373,7 +376,11 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
         for (;;) {                                                         // ---- phase A: inner nodes
             const bool can = node != MI_BVH_EMPTY, empty = qh == qt;
             if (!__any(can && empty)) break;                               // every lane that can still walk holds a leaf (or none can walk)
+#if MI_BVH_QCULL
+            const bool room = sp + 2 * qt + 11 <= MI_BVH_STACK;            // 3 pushes + 4 leaves of two words (entry, entering distance)
+#else
             const bool room = sp + qt + 7 <= MI_BVH_STACK;                 // 3 pushes + 4 leaves
+#endif
             if (can && (room || empty)) {
                 Bvh4Hits h = bvh4_node(sc, node, ray, inv_d, ray.maxt);
                 BVH_STAT(1, 1);
@@ -381,11 +388,15 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
                 uint32_t next = MI_BVH_EMPTY;
 #pragma unroll
                 for (int c = 3; c >= 0; --c)
-                    if (h.tn[c] != MI_INF && !(h.e[c] & MI_BVH_LEAF)) { if (next != MI_BVH_EMPTY && sp + qt < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
+                    if (h.tn[c] != MI_INF && !(h.e[c] & MI_BVH_LEAF)) { if (next != MI_BVH_EMPTY && sp + (MI_BVH_QCULL ? 2 : 1) * qt < MI_BVH_STACK) { MI_STK(sp) = next; sp++; } next = h.e[c]; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (h.tn[c] <= ray.maxt && (h.e[c] & MI_BVH_LEAF)) {
+#if MI_BVH_QCULL
+                        if (room) { MI_QSTK(2 * qt) = h.e[c]; MI_QSTK(2 * qt + 1) = __float_as_uint(h.tn[c]); qt++; }
+#else
                         if (room) { MI_QSTK(qt) = h.e[c]; qt++; }
+#endif
                         else {                                             // (a stack this deep is all but unreachable: test the leaf on the spot)
                             const uint32_t first = h.e[c] & 0x1fffffffu, count = ((h.e[c] >> 29) & 3u) + 1u;
                             BVH_STAT(2, count);
@@ -404,8 +415,13 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
         }
         while (__any(left != 0u || qh != qt)) {                            // ---- phase B: one postponed triangle per lane and trip
             if (left == 0u && qh != qt) {
+#if MI_BVH_QCULL
+                const uint32_t e = MI_QSTK(2 * qh); const float tn = __uint_as_float(MI_QSTK(2 * qh + 1)); qh++;
+                tri = e & 0x1fffffffu; left = tn <= ray.maxt ? ((e >> 29) & 3u) + 1u : 0u;      // a nearer hit was found since the leaf was postponed
+#else
                 const uint32_t e = MI_QSTK(qh); qh++;
                 tri = e & 0x1fffffffu; left = ((e >> 29) & 3u) + 1u;
+#endif
                 if (qh == qt) qh = qt = 0;
             }
             if (left != 0u) {
