@@ -302,7 +302,9 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
     return tn <= tf * 1.00001f + 1e-6f;
 }
 
-#define MI_BVH_STACK 32
+#ifndef MI_BVH_STACK
+#define MI_BVH_STACK 32                     // (overridable for tests of the deep-stack fallback: -DMI_BVH_STACK=12 -DMI_BVH_LEVELS=5)
+#endif
 #ifndef MI_PRIM_UNROLL
 #define MI_PRIM_UNROLL 1
 #endif
@@ -316,7 +318,10 @@ MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv
 // Closest hit: the hit children of a node are visited near to far (sorted by entry distance) -- leaves at once, so that a hit shrinks
 // ray.maxt before anything farther is looked at; inner children go on the stack far first.
 #define MI_STK(i) stk[(i) * 64]
+#ifndef MI_BVH_LEVELS
 #define MI_BVH_LEVELS 11    // 3 * (MI_BVH_LEVELS - 1) <= MI_BVH_STACK
+#endif
+static_assert(3 * (MI_BVH_LEVELS - 1) <= MI_BVH_STACK, "the traversal stack must hold three siblings per level");
 // MI_BVH_STATS (diagnostic builds only, tools/bvh_stats.py): traversal steps per ray -- [0] rays that entered the BVH, [1] nodes fetched, [2] triangles tested
 #ifdef MI_BVH_STATS
 static __device__ unsigned long long g_bvh_stats[4];
