@@ -461,3 +461,28 @@ def test_baseline_config_1_runs_at_its_stated_size(mi, orc):
     assert left[..., 0].mean() > 2 * left[..., 1].mean() and right[..., 1].mean() > 2 * right[..., 0].mean()
     a, _ = o.render(o.params(integ, 1, 8)); b, _ = o.render(o.params(integ, 2, 8))
     assert abs(a.mean() - b.mean()) < 0.02 * a.mean() and abs(0.5 * (a + b).mean() - img.mean()) < 0.02 * img.mean()
+
+
+def test_bench_roofline_reads_the_committed_pmc_pass():
+    """bench.py's roofline block is computed from the committed PMC pass (profiles/r02_pmc_summary.json) and the committed microbenchmark
+    (profiles/r02_valu_issue.json): the kernels it looks up must be in that file under the names the current build gives them, the VALU-issue
+    fraction must be physical (0 < frac <= 1) at the kernel times of the committed bench line, and the all-instruction issue model must
+    sit between the VALU-only figure and 1."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
+    for pmc_name, ms, lanes in (("k_render_compact<0, 0>", line["roofline"]["kernel_ms"], 512 * 512 * 256),
+                                ("k_prb_backward_1p<0, false>", line["prb"]["kernel_ms"], 512 * 512 * 64)):
+        assert bench.pmc_kernel(pmc_name) is not None, pmc_name
+        r = bench.valu_roofline(pmc_name, pmc_name, ms, lanes, 1.0)
+        assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and r["hbm"]["frac_of_peak"] < 1.0
+        assert abs(r["frac"] * r["cycles_per_inst_measured"] - bench.VALU_CYCLES_PEAK) < 0.01          # frac = peak cycles / measured cycles
+        im = r["issue_model"]
+        assert r["frac"] < im["frac_of_model"] <= 1.0 and im["instructions_all"] > r["insts_per_launch"]
+    # the committed line itself carries what the contract asks for
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["roofline"]["frac"] <= 1.0 and line["cpu_baseline"]["kind"] == "port" and line["config"]["workload"].startswith("Cornell box")
+    for leg in ("prb", "veach", "ptracer", "lens"):
+        assert leg in line, leg
