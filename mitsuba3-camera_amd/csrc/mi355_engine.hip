@@ -407,8 +407,11 @@ __global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? MI_REGEN_WAVES_FLAT 
 // from "6 bounces x 4 waves" to "sum over bounces of ceil(alive / 64)".  Final radiance returns to the lane's ORIGINAL
 // slot (`fin`) so that the per-pixel LDS film reduction still sees all samples of a pixel side by side.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef MI_COMPACT_WAVES_FLAT
+#define MI_COMPACT_WAVES_FLAT 5               // (Veach arrangement, re-packed: 3 / 4 / 5 waves per SIMD = 144 / 117 / 109 ms)
+#endif
 template <int INTEGRATOR, int FULL>
-__global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
+__global__ __launch_bounds__(BLOCK, FULL == 2 ? MI_COMPACT_WAVES_FLAT : (FULL ? 4 : MI_MIN_WAVES)) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
     __shared__ uint32_t s_cnt[4];
