@@ -1410,7 +1410,8 @@ MI_DEV float camera_ray(const DScene &sc, Pcg32 &rng, int32_t px, int32_t py, fl
     ray = sample_primary_ray(sc, pos_x, pos_y); return 1.f;
 }
 
-// MI_PROF (diagnostic builds only, tools/section_profile.py): per-wave s_memtime deltas per section of the path loop
+// MI_PROF (diagnostic builds only; printed by mi355_get_counters, tools/occupancy_ab.sh builds it): per-wave s_memtime deltas per section of the
+// path loop.  The hooks serialise the kernel (78 ms instead of 9: profiles/r02_occupancy_ab.txt) -- section SHARES of the instrumented kernel only.
 // Event counters are WAVE totals kept in SGPRs (ballot + s_bcnt1): no VGPR and no VALU instruction is spent on them.
 MI_DEV uint32_t wave_count(bool pred) { return (uint32_t) __popcll(__ballot(pred)); }
 #ifdef MI_PROF
