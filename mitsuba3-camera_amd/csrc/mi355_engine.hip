@@ -852,6 +852,9 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 #ifndef MI_PT_WAVES_FULL
 #define MI_PT_WAVES_FULL 4                  // k_ptracer forward, FULL: 128 VGPRs with 16 spilled beat 143 unspilled at 3 waves (lens doublet render 9.88 -> 8.23 ms)
 #endif
+#ifndef MI_PT_WAVES_BASIC
+#define MI_PT_WAVES_BASIC 4
+#endif
 #ifndef MI_PT_WAVES_GRAD_FULL
 #define MI_PT_WAVES_GRAD_FULL 4             // (same trade as the forward kernel: lens doublet colour backward 10.09 -> 8.37 ms)
 #endif
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 #define MI_PT_WAVES_GRAD_BASIC 5            // (Cornell box, all parameters: 10.08 -> 9.54 ms)
 #endif
 template <int FULL, bool GRAD>
-__global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT_WAVES_FULL) : (GRAD ? MI_PT_WAVES_GRAD_BASIC : 4)) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
+__global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT_WAVES_FULL) : (GRAD ? MI_PT_WAVES_GRAD_BASIC : MI_PT_WAVES_BASIC)) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
