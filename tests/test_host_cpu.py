@@ -479,7 +479,7 @@ def test_bench_roofline_reads_the_committed_pmc_pass():
         assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and r["hbm"]["frac_of_peak"] < 1.0
         assert abs(r["frac"] * r["cycles_per_inst_measured"] - bench.VALU_CYCLES_PEAK) < 0.01          # frac = peak cycles / measured cycles
         im = r["issue_model"]
-        assert r["frac"] < im["frac_of_model"] <= 1.0 and im["instructions_all"] > r["insts_per_launch"]
+        assert r["frac"] < im["frac_of_model"] <= 1.0 and im["valu"] == r["insts_per_launch"] and im["scalar"] > 0
     # the committed line itself carries what the contract asks for
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key

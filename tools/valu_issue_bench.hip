@@ -50,6 +50,14 @@ __global__ __launch_bounds__(256) void k_issue(float *out, int iters, unsigned l
                              "v_fma_f32 %4, %4, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %10, %11\n s_add_u32 %9, %9, 1\n"
                              "v_fma_f32 %6, %6, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %7, %7, %10, %11\n s_add_u32 %9, %9, 1\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1) : "v"(b), "v"(c) : "scc");
+            } else if (OP == 4) {                                           // 2 v_fma per s_add: separates "a scalar instruction takes an issue slot" (2 + 2/2 = 3 cycles per VALU)
+                asm volatile("v_fma_f32 %0, %0, %10, %11\n v_fma_f32 %1, %1, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %2, %2, %10, %11\n v_fma_f32 %3, %3, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             "v_fma_f32 %4, %4, %10, %11\n v_fma_f32 %5, %5, %10, %11\n s_add_u32 %8, %8, 1\n v_fma_f32 %6, %6, %10, %11\n v_fma_f32 %7, %7, %10, %11\n s_add_u32 %9, %9, 1\n"   // from "the CU's one scalar ALU is the limit" (max(2, 4/2) = 2)
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1) : "v"(b), "v"(c) : "scc");
+            } else if (OP == 5) {                                           // 4 v_fma per s_add (2.5 against 2)
+                asm volatile("v_fma_f32 %0, %0, %10, %11\n v_fma_f32 %1, %1, %10, %11\n v_fma_f32 %2, %2, %10, %11\n v_fma_f32 %3, %3, %10, %11\n s_add_u32 %8, %8, 1\n"
+                             "v_fma_f32 %4, %4, %10, %11\n v_fma_f32 %5, %5, %10, %11\n v_fma_f32 %6, %6, %10, %11\n v_fma_f32 %7, %7, %10, %11\n s_add_u32 %9, %9, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1) : "v"(b), "v"(c) : "scc");
             } else {                                                        // the forward kernel's transcendental share: 1 v_rcp per 7 v_fma
                 asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_rcp_f32 %3, %3\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -72,13 +80,13 @@ int main() {
     const double n_inst = (double) iters * 128.0;
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"instructions_per_wave\": %.0f, \"results\": [", prop.name, prop.gcnArchName, cus, clock_khz, n_inst);
     bool first = true;
-    for (int op = 0; op < 4; ++op)
+    for (int op = 0; op < 6; ++op)
         for (int k : { 1, 2, 3, 4, 5, 6, 8 }) {
             const int blocks = cus * k;
             const size_t lds = 0;
             float *out; unsigned long long *cyc;
             CHECK(hipMalloc((void **) &out, (size_t) blocks * 256 * 4)); CHECK(hipMalloc((void **) &cyc, (size_t) blocks * 4 * 8));
-            auto kern = op == 0 ? k_issue<0> : (op == 1 ? k_issue<1> : (op == 2 ? k_issue<2> : k_issue<3>));
+            auto kern = op == 0 ? k_issue<0> : (op == 1 ? k_issue<1> : (op == 2 ? k_issue<2> : (op == 3 ? k_issue<3> : (op == 4 ? k_issue<4> : k_issue<5>))));
             CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, out, iters, cyc);   // warm-up
@@ -92,7 +100,7 @@ int main() {
             std::sort(h.begin(), h.end());
             const double med = (double) h[h.size() / 2], lo = (double) h[h.size() / 20], hi = (double) h[h.size() - 1 - h.size() / 20];
             printf("%s\n  {\"op\": \"%s\", \"waves_per_simd\": %d, \"workgroups\": %d, \"kernel_ms\": %.4f, \"cyc_per_inst_smemtime\": %.3f, \"p05\": %.3f, \"p95\": %.3f, \"cyc_per_inst_wall\": %.3f}",
-                   first ? "" : ",", op == 0 ? "v_fma_f32" : (op == 1 ? "v_rcp_f32" : (op == 2 ? "v_fma_f32 + s_add_u32 (per VALU instruction)" : "7 v_fma_f32 + 1 v_rcp_f32 (per instruction)")), k, blocks, ms, med / (k * n_inst), lo / (k * n_inst), hi / (k * n_inst),
+                   first ? "" : ",", op == 0 ? "v_fma_f32" : (op == 1 ? "v_rcp_f32" : (op == 2 ? "v_fma_f32 + s_add_u32 (per VALU instruction)" : (op == 3 ? "7 v_fma_f32 + 1 v_rcp_f32 (per instruction)" : (op == 4 ? "2 v_fma_f32 + 1 s_add_u32 (per VALU instruction)" : "4 v_fma_f32 + 1 s_add_u32 (per VALU instruction)")))), k, blocks, ms, med / (k * n_inst), lo / (k * n_inst), hi / (k * n_inst),
                    ms * 1e-3 * clock_khz * 1e3 / (k * n_inst));
             first = false;
             CHECK(hipFree(out)); CHECK(hipFree(cyc));
