@@ -89,9 +89,9 @@ def main(iterations=25, res=64, spp=64, x0=-0.9, lr=0.01, verbose=True):
             x.grad.zero_()
         losses.append(float(loss.detach()))
         if verbose:
-            print("it %2d  x = %+.4f  spot second moment = %8.3f px^2  d/dx = %+8.3f" % (it, float(x), losses[-1], grad))
+            print("it %2d  x = %+.4f  spot second moment = %8.3f px^2  d/dx = %+8.3f" % (it, float(x.detach()), losses[-1], grad))
     scene.release()
-    return losses, float(x)
+    return losses, float(x.detach())
 
 
 if __name__ == "__main__":
