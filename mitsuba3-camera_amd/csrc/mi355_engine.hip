@@ -69,7 +69,9 @@ constexpr const char *PHASE_INIT_SCENE = "Scene initialization", *PHASE_INIT_ACC
                      *PHASE_PARAMS = "Scene::parameters_changed()";
 }
 
-#define BLOCK 256
+#ifndef BLOCK
+#define BLOCK 256                           // (128 measured: see profiles/r02_occupancy_ab.txt)
+#endif
 #define WAVES (BLOCK / 64)
 #ifndef MI_EXP
 #define MI_EXP 0                            // throw-away experiments (tools/*_ab.sh); 0 in every shipped build
