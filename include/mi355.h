@@ -30,6 +30,11 @@
  *   the film / weight / gradient all-reduce of a           -- (the reference is single-GPU): mi355_set_reduce_hook
  *     multi-GPU job
  *   ProfilerPhase ranges                                   include/mitsuba/core/profiler.h:15-113 -> roctx ranges of the same names
+ *   the `Sensor *sensor` argument of render / render_forward /  include/mitsuba/render/integrator.h:74-97, :104-215; Scene::sensors();
+ *     render_backward (any sensor of the scene per call)     src/python/python/util.py:410-523 (`sensor=` of mi.render)
+ *   PerspectiveCamera::traverse / parameters_changed /      src/sensors/perspective.cpp:155-199 (`x_fov`, `to_world`), Film size / crop
+ *     update_camera_transforms                                (src/render/film.cpp:59-98)  -> mi355_scene_set_param / mi355_scene_set_sensor
+ *   BasicPRBIntegrator.trace (the fork's geometric tracer)   src/python/python/ad/integrators/prb_basic.py:46-140 -> mi355_trace_rays
  *
  * Conventions
  *   - plain C, no torch / HIP types in any signature; `void *stream` is a hipStream_t
@@ -59,7 +64,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 8u
+#define MI355_ABI_VERSION 9u
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define MI355_OK                 0
@@ -174,7 +179,12 @@ typedef struct mi355_scene_desc {
     const mi355_bsdf_desc    *bsdfs;
     const mi355_emitter_desc *emitters;
     const mi355_texture_desc *textures;
-    mi355_sensor_desc         sensor;
+    /* Scene::sensors() (include/mitsuba/render/scene.h): every sensor of the scene, in the order the scene lists them.  A call picks one
+       with mi355_render_params.sensor -- the `Sensor *sensor` argument of Integrator::render / render_forward / render_backward
+       (integrator.h:74-97; mi.render(scene, params, sensor=i), util.py:410-523).  Sensors share the scene replica: choosing or editing one
+       touches no geometry, acceleration structure or scratch buffer.  At least one. */
+    uint32_t n_sensors;
+    const mi355_sensor_desc  *sensors;
 } mi355_scene_desc;
 
 /* ---- render parameters ---------------------------------------------------------------- */
@@ -242,6 +252,8 @@ typedef struct mi355_render_params {
        six numbers of every loop iteration it enters, path.cpp:196, :212-213, :272, so that the next pass starts where the reference's
        does).  prb.py renders in one pass: MI355_ERR_UNSUPPORTED. */
     uint32_t passes;
+    uint32_t sensor;                    /* index into mi355_scene_desc.sensors: the `Sensor *` argument of Integrator::render / render_forward /
+                                           render_backward (integrator.h:74-97, :104-215).  Film size, crop window, filter and lane grid are this sensor's */
 } mi355_render_params;
 
 /* Per-event device counters behind the algorithmic-byte formula of SURVEY.md 8(d). */
@@ -266,8 +278,14 @@ enum { MI355_PARAM_BSDF_REFLECTANCE = 0,   /* 3 floats      diffuse.cpp:97-99 / 
                                               kept), and a mesh that has vertex normals gets them recomputed from the new positions
                                               (recompute_vertex_normals, mesh.cpp:321-413, angle-weighted) -- from then on its shading normals are
                                               functions of the positions for the derivative passes as well, as under Dr.Jit's AD */
-       MI355_PARAM_BSDF_IOR         = 4 }; /* 2 floats (int_ior, ext_ior), index = bsdf: a `dielectric`'s indices (dielectric.cpp:236-239), or a
+       MI355_PARAM_BSDF_IOR         = 4,   /* 2 floats (int_ior, ext_ior), index = bsdf: a `dielectric`'s indices (dielectric.cpp:236-239), or a
                                               `dispersive` material's indices at 589.3 nm (dispersive_dielectric.cpp:236-239, :411-432 in RGB builds) */
+       /* Sensor parameters (PerspectiveCamera::traverse, perspective.cpp:155-161).  Settable, NOT part of the gradient layout: the reference
+          flags them Differentiable | Discontinuous, but no configuration on this path differentiates a camera (the lens-design loop moves and
+          zooms its cameras under dr.suspend_grad, design_problem.py:113-132).  Setting one is PerspectiveCamera::parameters_changed
+          (perspective.cpp:163-171 -> update_camera_transforms :173-199): host-side matrices only, no device work, no synchronisation. */
+       MI355_PARAM_SENSOR_TO_WORLD  = 5,   /* 12 floats (row-major 3x4 camera->world), index = sensor; a transform with scale is refused (:166-167) */
+       MI355_PARAM_SENSOR_X_FOV     = 6 }; /* 1 float, degrees, index = sensor (perspective only) */
 
 typedef struct mi355_param_info {
     uint32_t kind;                      /* MI355_PARAM_* */
@@ -295,6 +313,14 @@ int mi355_scene_set_param(mi355_scene *scene, uint32_t kind, uint32_t index,
 int mi355_scene_set_param_device(mi355_scene *scene, uint32_t kind, uint32_t index,
                                  const float *d_values, uint64_t count, void *stream);
 
+/* Replace the whole description of sensor `index` (same or another type, film size, crop window, filter): what a SceneParameters.update()
+   on `<sensor>.film.size` / `crop_size` / `crop_offset` (film.cpp:59-98; design_problem.py:594-617 re-renders at another resolution) or a
+   new `Sensor*` handed to Integrator::render amounts to.  Host-side only for a perspective camera; a realisticlens with sample_exit_pupil
+   re-traces its exit-pupil table (one kernel).  `index == n_sensors` appends a sensor.  Geometry, BVH and scratch buffers are untouched. */
+int mi355_scene_set_sensor(mi355_scene *scene, uint32_t index, const mi355_sensor_desc *sensor);
+/* Number of sensors of the replica. */
+int mi355_scene_sensor_count(const mi355_scene *scene);
+
 /* Layout of the concatenated parameter-gradient buffer.  Returns the number of
    parameters; fills at most `capacity` entries. */
 int mi355_scene_param_layout(const mi355_scene *scene, mi355_param_info *out, uint32_t capacity,
@@ -308,8 +334,8 @@ int mi355_scene_param_layout(const mi355_scene *scene, mi355_param_info *out, ui
 int mi355_render_accumulate(mi355_scene *scene, const mi355_render_params *p,
                             float *d_film_rgbw, void *stream);
 
-/* HDRFilm::develop (hdrfilm.cpp:304-409): rgb / (W==0 ? 1 : W) -> crop_h x crop_w x 3 (DEVICE). */
-int mi355_film_develop(mi355_scene *scene, const float *d_film_rgbw, float *d_image_rgb, void *stream);
+/* HDRFilm::develop (hdrfilm.cpp:304-409) of sensor `sensor`'s film: rgb / (W==0 ? 1 : W) -> crop_h x crop_w x 3 (DEVICE). */
+int mi355_film_develop(mi355_scene *scene, uint32_t sensor, const float *d_film_rgbw, float *d_image_rgb, void *stream);
 
 /* clear + accumulate + develop in one call: what Integrator::render returns.  d_image_rgb may be NULL: Integrator::render with
    develop = false (integrator.h:74-120) -- the film is accumulated and left undeveloped in d_film_rgbw. */
@@ -371,6 +397,19 @@ typedef struct mi355_design_tangent {
 int mi355_ptracer_forward_design(mi355_scene *scene, const mi355_render_params *p, const mi355_design_tangent *tangent,
                                  float *d_film_rgbw, void *stream);
 
+/* BasicPRBIntegrator.trace(scene, ray, num_lenses) of the fork (src/python/python/ad/integrators/prb_basic.py:46-140): the deterministic
+   geometric ray tracer the lens-design scripts use to place each field's camera on its central ray (design_problem.py:183-203) and to
+   check the lens meshes against the paraxial matrices (:430-472).  Every caller ray is walked through the scene taking, at each
+   interaction, the lobe bsdf.sample() returns for sample1 = 1.0, sample2 = (0, 0) -- a dielectric interface always refracts (it mirrors
+   only under total internal reflection), a black surface ends the ray -- until `num_lenses` surfaces were hit, max_depth is reached
+   (the integrator's `max_depth`: a vertex continues while depth + 1 < max_depth) or the ray leaves the scene.
+     d_rays = n x 8 (o.xyz, d.xyz, maxt, pad), as for mi355_debug_ray_intersect
+     d_out  = n x 12: [0..2] origin and [3..5] direction of the PENULTIMATE ray (the one that produced the last interaction),
+              [6..8] position of the last interaction (0 when the last ray hit nothing), [9] 1.0 iff that interaction is valid,
+              [10] number of surfaces hit, [11] 0
+   The reference's `valid` = si.is_valid() & dr.allclose(0, si.p.z) -- one verdict for the whole wavefront -- is formed by the caller from [8], [9]. */
+int mi355_trace_rays(mi355_scene *scene, const float *d_rays, uint32_t n, uint32_t num_lenses, int32_t max_depth, float *d_out, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 
@@ -408,7 +447,7 @@ int mi355_set_reduce_hook(mi355_scene *scene, mi355_reduce_fn fn, void *user);
 
 /* realisticlens with sample_exit_pupil: the 64 (min.x, min.y, max.x, max.y) exit-pupil bounds the scene was created with
    (compute_exit_pupil_bounds, realisticlens.cpp:1772-1806).  out = 256 floats of host memory. */
-int mi355_lens_exit_pupil_bounds(const mi355_scene *scene, float *out);
+int mi355_lens_exit_pupil_bounds(const mi355_scene *scene, uint32_t sensor, float *out);
 
 /* Per-lane radiance of lanes [lane_begin, lane_begin+count) of the whole job (no film):
    d_out = count x 4 (r,g,b,valid).  Used by the lane-exact parity tests

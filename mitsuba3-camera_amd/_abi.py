@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(HERE, "libmi355.so"))   # MI355_LIB: A/B builds of the same ABI
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -23,7 +23,7 @@ WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY, FLAG_DIRECT_SPLAT, FLAG_GEOMETRY_GRADS, FLAG_SKIP_COLOUR_GRADS = 1, 2, 4, 8, 16, 32, 64, 128
 MODE_FUSED, MODE_WAVEFRONT, MODE_STATIC = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_PRB, INTEGRATOR_PTRACER = 0, 1, 2
-PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE, PARAM_VERTEX_POSITIONS, PARAM_BSDF_IOR = 0, 1, 2, 3, 4
+PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE, PARAM_VERTEX_POSITIONS, PARAM_BSDF_IOR, PARAM_SENSOR_TO_WORLD, PARAM_SENSOR_X_FOV = 0, 1, 2, 3, 4, 5, 6
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -71,7 +71,7 @@ class SceneDesc(C.Structure):
                 ("n_emitters", C.c_uint32), ("n_textures", C.c_uint32),
                 ("shapes", C.POINTER(ShapeDesc)), ("bsdfs", C.POINTER(BsdfDesc)),
                 ("emitters", C.POINTER(EmitterDesc)), ("textures", C.POINTER(TextureDesc)),
-                ("sensor", SensorDesc)]
+                ("n_sensors", C.c_uint32), ("sensors", C.POINTER(SensorDesc))]
 
 
 class RenderParams(C.Structure):
@@ -79,7 +79,7 @@ class RenderParams(C.Structure):
                 ("flags", C.c_uint32), ("mode", C.c_uint32), ("integrator", C.c_uint32),
                 ("pixel_begin", C.c_uint32), ("pixel_count", C.c_uint32),
                 ("spp_begin", C.c_uint32), ("spp_count", C.c_uint32),
-                ("pixel_tile", C.c_uint32), ("pixel_tile_stride", C.c_uint32), ("passes", C.c_uint32)]
+                ("pixel_tile", C.c_uint32), ("pixel_tile_stride", C.c_uint32), ("passes", C.c_uint32), ("sensor", C.c_uint32)]
 
 
 class DesignTangent(C.Structure):
@@ -109,13 +109,16 @@ SYMBOLS = [
     ("mi355_scene_set_param_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("mi355_scene_param_layout", C.c_int, [C.c_void_p, C.POINTER(ParamInfo), C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mi355_render_accumulate", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
-    ("mi355_film_develop", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355_film_develop", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355_scene_set_sensor", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SensorDesc)]),
+    ("mi355_scene_sensor_count", C.c_int, [C.c_void_p]),
+    ("mi355_trace_rays", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("mi355_render", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_prb_splat_weights", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     ("mi355_render_backward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_get_counters", C.c_int, [C.c_void_p, C.POINTER(Counters), C.c_int]),
     ("mi355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
-    ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("mi355_lens_exit_pupil_bounds", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     ("mi355_debug_lane_radiance", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_ptracer_forward_design", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(DesignTangent), C.c_void_p, C.c_void_p]),
     ("mi355_render_forward", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1268,6 +1268,45 @@ __global__ __launch_bounds__(BLOCK) void k_debug_si(DScene sc, const float *rays
     o[15] = __uint_as_float((uint32_t) si.shape);
     o[16] = si.sh_s.x; o[17] = si.sh_s.y; o[18] = si.sh_s.z; o[19] = si.sh_t.x; o[20] = si.sh_t.y; o[21] = si.sh_t.z;
 }
+// BasicPRBIntegrator.trace (the fork's geometric ray tracer, src/python/python/ad/integrators/prb_basic.py:46-140): one lane per caller
+// ray; at every interaction the lobe bsdf.sample() returns for sample1 = 1.0 and sample2 = (0, 0) (:106-112) -- a dielectric refracts unless
+// the Fresnel term is 1 (dielectric.cpp:275: selected_r = sample1 <= r_i), a diffuse surface continues with its albedo as the weight, a
+// black one ends the ray (:123).  Loop state as in :64-77: ray, penultimate_ray, depth, throughput, active; `si` of the LAST iteration is
+// what the function returns (:134-140).  Scene records are read per lane (divergent caller rays); the FULL variant like k_debug_intersect.
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float *rays, uint32_t n, uint32_t num_lenses, uint32_t max_depth, float *out) {
+    __shared__ uint32_t smem[WAVES * STACK_WORDS];
+    uint32_t *stk = smem + (threadIdx.x >> 6) * STACK_WORDS + (threadIdx.x & 63);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x; const bool act = i < n; const uint32_t ii = act ? i : 0;
+    Ray ray; ray.o = ld3(rays + 8 * (size_t) ii); ray.d = ld3(rays + 8 * (size_t) ii + 3); ray.maxt = rays[8 * (size_t) ii + 6];
+    Ray pen = ray;
+    uint32_t depth = 0; v3 beta = V3(1.f, 1.f, 1.f), p_last = V3(0.f, 0.f, 0.f);
+    bool active = act, si_valid = false;
+    while (__any(active)) {                                                 // every live lane gains a surface or stops: at most num_lenses trips
+        Hit hit = scene_intersect<true>(sc, ray, active, stk);
+        if (active) {
+            const bool valid = hit.t != MI_INF;
+            bool active_next = valid && (depth + 1u < max_depth);           // :99
+            pen = ray; si_valid = valid; p_last = V3(0.f, 0.f, 0.f);        // :116
+            if (valid) {
+                SI si = compute_si<true>(sc, ray, hit);
+                p_last = si.p;
+                const DBsdf &bsdf = sc.bsdfs[sc.shapes[hit.shape].bsdf];
+                v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
+                BSample bs; v3 w; bsdf_sample<true>(bsdf, refl, si.wi, 1.0f, 0.f, 0.f, active_next, bs, w);   // :106-112
+                ray = spawn_ray(si.p, si.n, si_to_world(si, bs.wo));         // :119
+                beta = beta * w;                                             // :120
+                active_next = active_next && (beta.x != 0.f || beta.y != 0.f || beta.z != 0.f);   // :123
+                depth += 1u;                                                 // :126
+                active_next = active_next && depth < num_lenses;             // :129
+            }
+            active = active_next;
+        }
+    }
+    if (!act) return;
+    float *o = out + 12 * (size_t) i;
+    o[0] = pen.o.x; o[1] = pen.o.y; o[2] = pen.o.z; o[3] = pen.d.x; o[4] = pen.d.y; o[5] = pen.d.z;
+    o[6] = p_last.x; o[7] = p_last.y; o[8] = p_last.z; o[9] = si_valid ? 1.f : 0.f; o[10] = (float) depth; o[11] = 0.f;
+}
 __global__ __launch_bounds__(BLOCK) void k_debug_texture(DScene sc, uint32_t tex, const float *uv, uint32_t n, float *out) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -1360,13 +1399,22 @@ extern "C" void mi355_gaussian_coeffs(float stddev, float out_coeff[10]) {
 
 // ---- scene object --------------------------------------------------------------------------------
 #define MAX_EVENTS 64
+// One sensor of the scene (Scene::sensors()): its description and its share of the kernel argument.  `snap` is a DScene of which only the
+// sensor / film fields are meaningful (copy_sensor_fields lists them); selecting a sensor copies them into mi355_scene::ds -- DScene keeps
+// its field order, which the forward kernel's scalar loads are tuned to (mi355_device.h).
+struct SensorSlot {
+    mi355_sensor_desc desc;                     // desc.lens_data points into `lens`
+    DScene snap;
+    std::vector<float> lens, pupil; float *d_lens = nullptr, *d_pupil = nullptr;
+};
 struct mi355_scene {
     mi355_reduce_fn reduce_fn = nullptr; void *reduce_user = nullptr;      // mi355_set_reduce_hook: in-place SUM over the ranks of a device buffer
     int device = 0;
-    DScene ds;                                  // kernel argument (device pointers inside)
+    DScene ds;                                  // kernel argument (device pointers inside); its sensor fields are those of sensor `cur_sensor`
+    std::vector<SensorSlot> sensors; uint32_t cur_sensor = 0xffffffffu; uint32_t base_features = 0;   // feature bits of the scene without the sensor's (bit 2)
     std::vector<DShape> shapes; std::vector<DTri> tris; std::vector<uint32_t> tri_face;
     std::vector<uint32_t> faces; std::vector<float> positions, normals, texcoords;
-    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> lens, pupil, area_cdf;
+    std::vector<DPrim> prims; std::vector<DPrimFin> fins; std::vector<uint32_t> bvh_shapes; std::vector<DBox> boxes; std::vector<DSphere> spheres; std::vector<float> area_cdf;
     std::vector<float> ext_iors;                                            // per bsdf (the design forward mode turns IOR tangents into a tangent of rel_eta)
     // geometry updates (MI355_PARAM_VERTEX_POSITIONS): what Mesh::parameters_changed / Scene::parameters_changed need
     std::vector<uint32_t> vcount;                                           // per shape: vertex count (meshes)
@@ -1384,10 +1432,10 @@ struct mi355_scene {
     std::vector<uint32_t> small_map;
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
-    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_lens = nullptr; float *d_pupil = nullptr; float *d_area_cdf = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
+    DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_area_cdf = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
           *d_texcoords = nullptr; DBvh4 *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
-    float4 *d_gw = nullptr;                     // grad_in / W scratch (crop_h x crop_w)
+    float4 *d_gw = nullptr; size_t gw_pixels = 0;   // grad_in / W scratch (crop_h x crop_w of the largest film served)
     uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
     // deferred splat of the particle tracer: record queue (unsorted + sorted copy), tile histogram / offsets / cursors, record counter
     float4 *d_rec_a = nullptr, *d_srt_a = nullptr; float *d_rec_b = nullptr, *d_srt_b = nullptr; uint32_t rec_capacity = 0;
@@ -1695,8 +1743,18 @@ static bool try_make_box(mi355_scene *s, uint32_t shape_index, const mi355_shape
     return true;
 }
 
-static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
-    const mi355_sensor_desc &se = d->sensor;
+// The sensor / film share of DScene.  Everything else in DScene belongs to the scene replica and is never touched by a sensor change.
+static void copy_sensor_fields(DScene &dst, const DScene &src) {
+    memcpy(dst.sample_to_camera, src.sample_to_camera, sizeof(dst.sample_to_camera)); memcpy(dst.cam_to_world, src.cam_to_world, sizeof(dst.cam_to_world));
+    dst.near_clip = src.near_clip; dst.far_clip = src.far_clip;
+    dst.crop_w = src.crop_w; dst.crop_h = src.crop_h; dst.crop_x = src.crop_x; dst.crop_y = src.crop_y; dst.grid_w = src.grid_w; dst.grid_h = src.grid_h; dst.border = src.border;
+    dst.rfilter = src.rfilter; dst.filter_radius = src.filter_radius; memcpy(dst.filter_coeff, src.filter_coeff, sizeof(dst.filter_coeff));
+    dst.sensor_type = src.sensor_type; dst.lens_count = src.lens_count; dst.lens = src.lens; dst.film_px = src.film_px; dst.film_py = src.film_py;
+    dst.film_w = src.film_w; dst.film_h = src.film_h;
+    memcpy(dst.camera_to_sample, src.camera_to_sample, sizeof(dst.camera_to_sample)); memcpy(dst.image_rect, src.image_rect, sizeof(dst.image_rect)); dst.normalization = src.normalization;
+    dst.shutter_open_time = src.shutter_open_time; dst.sample_exit_pupil = src.sample_exit_pupil; dst.film_diagonal = src.film_diagonal; dst.pupil = src.pupil;
+}
+static int validate_sensor(const mi355_sensor_desc &se) {
     if (se.type != MI355_SENSOR_PERSPECTIVE && se.type != MI355_SENSOR_REALISTICLENS)
         return fail(MI355_ERR_UNSUPPORTED, "sensor type not supported by this build (perspective, realisticlens)");
     if (se.type == MI355_SENSOR_REALISTICLENS) {
@@ -1707,8 +1765,111 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
             if (!(L[0] == 0.f || L[0] == 1.f || L[0] == 2.f || L[0] == 3.f) || !(L[2] > 0.f) || !(L[4] > 0.f) || !(L[5] > 0.f) || (L[0] == 0.f && L[1] == 0.f))
                 return fail(MI355_ERR_INVALID, "malformed lens interface row");
         }
+    } else {
+        if (!(se.x_fov > 0.f && se.x_fov < 180.f)) return fail(MI355_ERR_INVALID, "The horizontal field of view must be in the range [0, 180]!");   // sensor.cpp:196-197
+        if (!(se.near_clip > 0.f && se.far_clip > se.near_clip)) return fail(MI355_ERR_INVALID, "clip planes must satisfy 0 < near_clip < far_clip");
     }
     if (!se.crop_width || !se.crop_height || !se.film_width || !se.film_height) return fail(MI355_ERR_INVALID, "empty film");
+    if (se.crop_offset_x + se.crop_width > se.film_width || se.crop_offset_y + se.crop_height > se.film_height) return fail(MI355_ERR_INVALID, "Invalid crop window specification!");   // film.cpp:77-84
+    if (se.rfilter != MI355_RFILTER_BOX && se.rfilter != MI355_RFILTER_GAUSSIAN && se.rfilter != MI355_RFILTER_TENT)
+        return fail(MI355_ERR_UNSUPPORTED, "reconstruction filter not supported (box, gaussian, tent)");
+    const float radius = se.rfilter == MI355_RFILTER_BOX ? 0.5f : (se.rfilter == MI355_RFILTER_GAUSSIAN ? 4.f * se.rfilter_param : se.rfilter_param);
+    if (se.rfilter != MI355_RFILTER_BOX && (!(radius > 0.f) || 2 * (int) ceilf(radius - .5f) + 1 > MI_MAX_TAPS))
+        return fail(MI355_ERR_UNSUPPORTED, "filter radius > 2.5 pixels is outside this build's splat footprint");
+    for (int k = 0; k < 12; ++k) if (!std::isfinite(se.to_world[k])) return fail(MI355_ERR_INVALID, "sensor to_world is not finite");
+    // "Scale factors in the camera-to-world transformation are not allowed!" (perspective.cpp:144-145, :166-167); Transform::has_scale,
+    // transform.h:325-337: M M^T must be the identity within 1e-3
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
+        float sum = 0.f; for (int k = 0; k < 3; ++k) sum += se.to_world[4 * i + k] * se.to_world[4 * j + k];
+        if (fabsf(sum - (i == j ? 1.f : 0.f)) > 1e-3f) return fail(MI355_ERR_INVALID, "Scale factors in the camera-to-world transformation are not allowed!");
+    }
+    return MI355_OK;
+}
+// PerspectiveCamera::update_camera_transforms (perspective.cpp:173-199) / the realisticlens constructor's film quantities: fill the slot's
+// share of DScene from its description.  The only device work is the exit-pupil table of a realisticlens that samples it.
+static int init_sensor_slot(mi355_scene *s, SensorSlot &slot, const mi355_sensor_desc &src) {
+    int rc = validate_sensor(src); if (rc) return rc;
+    slot.desc = src;
+    DScene &ds = slot.snap; memset(&ds, 0, sizeof(ds));
+    const mi355_sensor_desc &se = slot.desc;
+    int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
+            coff[2] = { (int32_t) se.crop_offset_x, (int32_t) se.crop_offset_y };
+    float c2s[16];
+    if (se.type == MI355_SENSOR_PERSPECTIVE) {
+        host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
+        memcpy(ds.camera_to_sample, c2s, sizeof(ds.camera_to_sample));
+        // m_image_rect / m_normalization, perspective.cpp:190-199: the corners of the sample square on the plane z = 1
+        auto proj = [&](float x, float y, float *o) {
+            float r[4]; for (int i = 0; i < 4; ++i) r[i] = fmaf(ds.sample_to_camera[i * 4 + 1], y, fmaf(ds.sample_to_camera[i * 4 + 0], x, ds.sample_to_camera[i * 4 + 3]));
+            float iw = 1.f / r[3]; o[0] = r[0] * iw; o[1] = r[1] * iw; o[2] = r[2] * iw; };
+        float pmin[3], pmax[3]; proj(0.f, 0.f, pmin); proj(1.f, 1.f, pmax);
+        float ax = pmin[0] / pmin[2], ay = pmin[1] / pmin[2], bx = pmax[0] / pmax[2], by = pmax[1] / pmax[2];
+        ds.image_rect[0] = std::min(ax, bx); ds.image_rect[1] = std::min(ay, by); ds.image_rect[2] = std::max(ax, bx); ds.image_rect[3] = std::max(ay, by);
+        ds.normalization = 1.f / ((ds.image_rect[2] - ds.image_rect[0]) * (ds.image_rect[3] - ds.image_rect[1]));
+        slot.lens.clear(); slot.desc.lens_data = nullptr; slot.desc.lens_count = 0;
+    } else {
+        slot.lens.assign(se.lens_data, se.lens_data + MI_LENS_ROW * (size_t) se.lens_count);
+        slot.desc.lens_data = slot.lens.data();
+        float aspect = (float) se.film_height / (float) se.film_width;       // Film::get_physical_size, film.h:193-198
+        float x = sqrtf(se.film_diagonal * se.film_diagonal / (1.f + aspect * aspect));
+        ds.film_px = x / 2; ds.film_py = aspect * x / 2; ds.lens_count = se.lens_count;
+    }
+    ds.sensor_type = se.type; ds.film_w = se.film_width; ds.film_h = se.film_height;
+    memcpy(ds.cam_to_world, se.to_world, 48);
+    ds.near_clip = se.near_clip; ds.far_clip = se.far_clip;
+    ds.crop_w = se.crop_width; ds.crop_h = se.crop_height; ds.crop_x = se.crop_offset_x; ds.crop_y = se.crop_offset_y;
+    {   // Film::sample_border: border_size = ceil(radius - 0.5 - 2 RayEps), rfilter.cpp:23
+        const float radius = se.rfilter == MI355_RFILTER_BOX ? 0.5f : (se.rfilter == MI355_RFILTER_GAUSSIAN ? 4.f * se.rfilter_param : se.rfilter_param);
+        ds.border = se.sample_border ? (uint32_t) std::max(0.f, ceilf(radius - .5f - 2.f * MI_RAY_EPS)) : 0u;
+        ds.grid_w = ds.crop_w + 2u * ds.border; ds.grid_h = ds.crop_h + 2u * ds.border;
+    }
+    ds.rfilter = se.rfilter;
+    if (se.rfilter == MI355_RFILTER_GAUSSIAN) { mi355_gaussian_coeffs(se.rfilter_param, ds.filter_coeff); ds.filter_radius = 4.f * se.rfilter_param; }
+    else if (se.rfilter == MI355_RFILTER_TENT) ds.filter_radius = se.rfilter_param;
+    else ds.filter_radius = .5f;
+    ds.shutter_open_time = se.shutter_open_time; ds.film_diagonal = se.film_diagonal;
+    ds.sample_exit_pupil = (se.type == MI355_SENSOR_REALISTICLENS && se.sample_exit_pupil) ? 1u : 0u;
+    if (slot.d_lens) { HIP_TRY(hipFree(slot.d_lens)); slot.d_lens = nullptr; }
+    if (slot.d_pupil) { HIP_TRY(hipFree(slot.d_pupil)); slot.d_pupil = nullptr; }
+    slot.pupil.clear();
+    if (se.type == MI355_SENSOR_REALISTICLENS) {
+        if ((rc = upload(&slot.d_lens, slot.lens))) return rc;
+        ds.lens = slot.d_lens;
+    }
+    if (ds.sample_exit_pupil) {                                             // compute_exit_pupil_bounds, realisticlens.cpp:1772-1806
+        uint32_t *d_keys = nullptr, h_keys[PUPIL_SEGMENTS * 5];
+        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) { h_keys[5 * i] = h_keys[5 * i + 1] = 0xffffffffu; h_keys[5 * i + 2] = h_keys[5 * i + 3] = h_keys[5 * i + 4] = 0u; }
+        HIP_TRY(hipMalloc((void **) &d_keys, sizeof(h_keys)));
+        HIP_TRY(hipMemcpy(d_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_exit_pupil, dim3(PUPIL_SEGMENTS * (PUPIL_RAYS / 256u)), dim3(256), 0, 0, slot.d_lens, se.lens_count, se.film_diagonal, d_keys);
+        hipError_t le = hipGetLastError(); if (le == hipSuccess) le = hipMemcpy(h_keys, d_keys, sizeof(h_keys), hipMemcpyDeviceToHost);
+        (void) hipFree(d_keys);
+        HIP_TRY(le);
+        const float rear_radius = slot.lens[2] * 1.5f, spacing = 4.f * rear_radius * sqrtf(2.f / (float) PUPIL_RAYS);
+        slot.pupil.assign(PUPIL_SEGMENTS * 4, 0.f);
+        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) {
+            float mnx = -rear_radius, mny = -rear_radius, mxx = rear_radius, mxy = rear_radius;      // nothing transmitted: the whole square
+            if (h_keys[5 * i + 4] != 0u) { mnx = key_float(h_keys[5 * i]); mny = key_float(h_keys[5 * i + 1]); mxx = key_float(h_keys[5 * i + 2]); mxy = key_float(h_keys[5 * i + 3]); }
+            slot.pupil[4 * i] = mnx - spacing; slot.pupil[4 * i + 1] = mny - spacing; slot.pupil[4 * i + 2] = mxx + spacing; slot.pupil[4 * i + 3] = mxy + spacing;
+        }
+        if ((rc = upload(&slot.d_pupil, slot.pupil))) return rc;
+        ds.pupil = slot.d_pupil;
+    }
+    return MI355_OK;
+}
+// Make sensor `index` the one the kernel argument describes (a handful of host-side copies; nothing on the device).
+static int select_sensor(mi355_scene *s, uint32_t index) {
+    if (index >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
+    if (s->cur_sensor == index) return MI355_OK;
+    copy_sensor_fields(s->ds, s->sensors[index].snap);
+    s->ds.features = s->base_features | (s->sensors[index].desc.type == MI355_SENSOR_REALISTICLENS ? 4u : 0u);
+    s->cur_sensor = index;
+    return MI355_OK;
+}
+
+static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
+    if (!d->n_sensors || !d->sensors) return fail(MI355_ERR_INVALID, "a scene needs at least one sensor");
+    for (uint32_t i = 0; i < d->n_sensors; ++i) { int rc_s = validate_sensor(d->sensors[i]); if (rc_s) return rc_s; }
     DScene &ds = s->ds; memset(&ds, 0, sizeof(ds));
     s->spheres.clear();
     // textures
@@ -1871,45 +2032,6 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     { int rc_bvh = build_scene_bvh(s); if (rc_bvh) return rc_bvh; }       // the scene BVH over the large meshes, its leaf-ordered triangles, the refit lists
     s->dirty.assign(s->shapes.size(), 0);
     if (s->small_map.size() > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant differentiable parameters for the LDS reducer");
-    // sensor / film
-    int32_t film[2] = { (int32_t) se.film_width, (int32_t) se.film_height }, crop[2] = { (int32_t) se.crop_width, (int32_t) se.crop_height },
-            coff[2] = { (int32_t) se.crop_offset_x, (int32_t) se.crop_offset_y };
-    float c2s[16];
-    if (se.type == MI355_SENSOR_PERSPECTIVE) {
-        host_perspective_projection(film, crop, coff, se.x_fov, se.near_clip, se.far_clip, c2s, ds.sample_to_camera);
-        memcpy(ds.camera_to_sample, c2s, sizeof(ds.camera_to_sample));
-        // m_image_rect / m_normalization, perspective.cpp:190-199: the corners of the sample square on the plane z = 1
-        auto proj = [&](float x, float y, float *o) {
-            float r[4]; for (int i = 0; i < 4; ++i) r[i] = fmaf(ds.sample_to_camera[i * 4 + 1], y, fmaf(ds.sample_to_camera[i * 4 + 0], x, ds.sample_to_camera[i * 4 + 3]));
-            float iw = 1.f / r[3]; o[0] = r[0] * iw; o[1] = r[1] * iw; o[2] = r[2] * iw; };
-        float pmin[3], pmax[3]; proj(0.f, 0.f, pmin); proj(1.f, 1.f, pmax);
-        float ax = pmin[0] / pmin[2], ay = pmin[1] / pmin[2], bx = pmax[0] / pmax[2], by = pmax[1] / pmax[2];
-        ds.image_rect[0] = std::min(ax, bx); ds.image_rect[1] = std::min(ay, by); ds.image_rect[2] = std::max(ax, bx); ds.image_rect[3] = std::max(ay, by);
-        ds.normalization = 1.f / ((ds.image_rect[2] - ds.image_rect[0]) * (ds.image_rect[3] - ds.image_rect[1]));
-    }
-    else {
-        s->lens.assign(se.lens_data, se.lens_data + MI_LENS_ROW * (size_t) se.lens_count);
-        float aspect = (float) se.film_height / (float) se.film_width;       // Film::get_physical_size, film.h:193-198
-        float x = sqrtf(se.film_diagonal * se.film_diagonal / (1.f + aspect * aspect));
-        ds.film_px = x / 2; ds.film_py = aspect * x / 2; ds.lens_count = se.lens_count;
-    }
-    ds.sensor_type = se.type; ds.film_w = se.film_width; ds.film_h = se.film_height;
-    if (se.type == MI355_SENSOR_REALISTICLENS) ds.features |= 4u;
-    memcpy(ds.cam_to_world, se.to_world, 48);
-    ds.near_clip = se.near_clip; ds.far_clip = se.far_clip;
-    ds.crop_w = se.crop_width; ds.crop_h = se.crop_height; ds.crop_x = se.crop_offset_x; ds.crop_y = se.crop_offset_y;
-    {   // Film::sample_border: border_size = ceil(radius - 0.5 - 2 RayEps), rfilter.cpp:23
-        const float radius = se.rfilter == MI355_RFILTER_BOX ? 0.5f : (se.rfilter == MI355_RFILTER_GAUSSIAN ? 4.f * se.rfilter_param : se.rfilter_param);
-        ds.border = se.sample_border ? (uint32_t) std::max(0.f, ceilf(radius - .5f - 2.f * MI_RAY_EPS)) : 0u;
-        ds.grid_w = ds.crop_w + 2u * ds.border; ds.grid_h = ds.crop_h + 2u * ds.border;
-    }
-    ds.rfilter = se.rfilter;
-    if (se.rfilter == MI355_RFILTER_GAUSSIAN) { mi355_gaussian_coeffs(se.rfilter_param, ds.filter_coeff); ds.filter_radius = 4.f * se.rfilter_param; }
-    else if (se.rfilter == MI355_RFILTER_TENT) ds.filter_radius = se.rfilter_param;
-    else if (se.rfilter == MI355_RFILTER_BOX) ds.filter_radius = .5f;
-    else return fail(MI355_ERR_UNSUPPORTED, "reconstruction filter not supported (box, gaussian, tent)");
-    if (se.rfilter != MI355_RFILTER_BOX && 2 * (int) ceilf(ds.filter_radius - .5f) + 1 > MI_MAX_TAPS)
-        return fail(MI355_ERR_UNSUPPORTED, "filter radius > 2.5 pixels is outside this build's splat footprint");
     ds.n_shapes = (uint32_t) s->shapes.size(); ds.n_bsdfs = (uint32_t) s->bsdfs.size(); ds.n_emitters = (uint32_t) s->emitters.size();
     ds.n_textures = (uint32_t) s->textures.size();
     ds.inv_emitter_count = ds.n_emitters ? 1.f / (float) ds.n_emitters : 0.f;
@@ -1928,31 +2050,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
-    if ((rc = upload(&s->d_lens, s->lens))) return rc;
-    ds.lens = s->d_lens;
     if ((rc = upload(&s->d_area_cdf, s->area_cdf))) return rc;
     ds.area_cdf = s->d_area_cdf;
-    ds.shutter_open_time = se.shutter_open_time; ds.film_diagonal = se.film_diagonal;
-    ds.sample_exit_pupil = (se.type == MI355_SENSOR_REALISTICLENS && se.sample_exit_pupil) ? 1u : 0u;
-    if (ds.sample_exit_pupil) {                                             // compute_exit_pupil_bounds, realisticlens.cpp:1772-1806
-        uint32_t *d_keys = nullptr, h_keys[PUPIL_SEGMENTS * 5];
-        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) { h_keys[5 * i] = h_keys[5 * i + 1] = 0xffffffffu; h_keys[5 * i + 2] = h_keys[5 * i + 3] = h_keys[5 * i + 4] = 0u; }
-        HIP_TRY(hipMalloc((void **) &d_keys, sizeof(h_keys)));
-        HIP_TRY(hipMemcpy(d_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_exit_pupil, dim3(PUPIL_SEGMENTS * (PUPIL_RAYS / 256u)), dim3(256), 0, 0, s->d_lens, se.lens_count, se.film_diagonal, d_keys);
-        hipError_t le = hipGetLastError(); if (le == hipSuccess) le = hipMemcpy(h_keys, d_keys, sizeof(h_keys), hipMemcpyDeviceToHost);
-        (void) hipFree(d_keys);
-        HIP_TRY(le);
-        const float rear_radius = s->lens[2] * 1.5f, spacing = 4.f * rear_radius * sqrtf(2.f / (float) PUPIL_RAYS);
-        s->pupil.assign(PUPIL_SEGMENTS * 4, 0.f);
-        for (uint32_t i = 0; i < PUPIL_SEGMENTS; ++i) {
-            float mnx = -rear_radius, mny = -rear_radius, mxx = rear_radius, mxy = rear_radius;      // nothing transmitted: the whole square
-            if (h_keys[5 * i + 4] != 0u) { mnx = key_float(h_keys[5 * i]); mny = key_float(h_keys[5 * i + 1]); mxx = key_float(h_keys[5 * i + 2]); mxy = key_float(h_keys[5 * i + 3]); }
-            s->pupil[4 * i] = mnx - spacing; s->pupil[4 * i + 1] = mny - spacing; s->pupil[4 * i + 2] = mxx + spacing; s->pupil[4 * i + 3] = mxy + spacing;
-        }
-        if ((rc = upload(&s->d_pupil, s->pupil))) return rc;
-        ds.pupil = s->d_pupil;
-    }
     if ((rc = upload(&s->d_bvh_shapes, s->bvh_shapes))) return rc;
     if ((rc = upload(&s->d_vadj_off, s->vadj_off))) return rc;
     if ((rc = upload(&s->d_vadj, s->vadj))) return rc;
@@ -1968,7 +2067,6 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_textures, s->textures))) return rc;
     if ((rc = upload(&s->d_texdata, s->texdata))) return rc;
     if ((rc = upload(&s->d_small_map, s->small_map))) return rc;
-    HIP_TRY(hipMalloc((void **) &s->d_gw, (size_t) se.crop_width * se.crop_height * sizeof(float4)));
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.tri_shape = s->d_tri_shape; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
@@ -1976,7 +2074,11 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     ds.spheres = s->d_spheres; ds.n_spheres = (uint32_t) s->spheres.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
-    return MI355_OK;
+    // the sensors: each keeps its own share of the kernel argument; sensor 0 is selected
+    s->base_features = ds.features;
+    s->sensors.resize(d->n_sensors);
+    for (uint32_t i = 0; i < d->n_sensors; ++i) if ((rc = init_sensor_slot(s, s->sensors[i], d->sensors[i]))) return rc;
+    return select_sensor(s, 0);
 }
 
 extern "C" int mi355_scene_create(const mi355_scene_desc *desc, int device, mi355_scene **out) {
@@ -1997,10 +2099,11 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
-                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_lens, s->d_redo, s->d_pupil, s->d_area_cdf,
+                     s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_redo, s->d_area_cdf,
                      s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_rec_c, s->d_srt_c, s->d_rec_d, s->d_srt_d, s->d_tile_u32,
                      s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape };
     for (void *b : bufs) if (b) (void) hipFree(b);
+    for (SensorSlot &sl : s->sensors) { if (sl.d_lens) (void) hipFree(sl.d_lens); if (sl.d_pupil) (void) hipFree(sl.d_pupil); }
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
     delete s; return MI355_OK;
 }
@@ -2088,7 +2191,9 @@ static int ensure_geometry(mi355_scene *s, hipStream_t st) {
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));                                      // the host copies below must not overtake kernels that still read the old tables
+    // the blocking host copies below must not overtake kernels that still read the old tables; a pure device-side refit (BVH meshes that are
+    // not sampled as emitters, normals already position-dependent) issues no copy and does not stall the host
+    if (reflatten || shapes_changed || cdf_changed) HIP_TRY(hipStreamSynchronize(st));
     int rc;
     if (reflatten && (rc = rebuild_flat_tables(s))) return rc;
     if (shapes_changed) HIP_TRY(hipMemcpy(s->d_shapes, s->shapes.data(), s->shapes.size() * sizeof(DShape), hipMemcpyHostToDevice));
@@ -2151,8 +2256,44 @@ static int param_target(mi355_scene *s, uint32_t kind, uint32_t index, uint64_t 
     }
     return fail(MI355_ERR_INVALID, "unknown parameter kind");
 }
+// PerspectiveCamera::parameters_changed (perspective.cpp:163-171): `to_world` / `x_fov` -> update_camera_transforms.  Host-side only.
+static int reinit_sensor(mi355_scene *s, uint32_t index, const mi355_sensor_desc &nd_in) {
+    mi355_sensor_desc nd = nd_in;
+    std::vector<float> lens_copy;                                           // (the description may point into the slot it replaces)
+    if (nd.type == MI355_SENSOR_REALISTICLENS && nd.lens_data && nd.lens_count && nd.lens_count <= 64) { lens_copy.assign(nd.lens_data, nd.lens_data + MI_LENS_ROW * (size_t) nd.lens_count); nd.lens_data = lens_copy.data(); }
+    int rc = validate_sensor(nd); if (rc) return rc;                         // a refused update leaves the sensor as it was
+    HIP_TRY(hipSetDevice(s->device));
+    if (index == s->sensors.size()) s->sensors.emplace_back();
+    if ((rc = init_sensor_slot(s, s->sensors[index], nd))) return rc;
+    if (s->cur_sensor == index) s->cur_sensor = 0xffffffffu;                // re-select on the next call
+    return MI355_OK;
+}
+static int set_sensor_param(mi355_scene *s, uint32_t kind, uint32_t index, const float *v, uint64_t count) {
+    if (index >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
+    mi355_sensor_desc nd = s->sensors[index].desc;
+    if (kind == MI355_PARAM_SENSOR_TO_WORLD) {
+        if (count != 12) return fail(MI355_ERR_INVALID, "sensor to_world is 12 floats (row-major 3x4)");
+        memcpy(nd.to_world, v, 48);
+    } else {
+        if (count != 1) return fail(MI355_ERR_INVALID, "sensor x_fov is one float");
+        if (nd.type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_INVALID, "x_fov is a parameter of the perspective sensor");
+        nd.x_fov = v[0];
+    }
+    return reinit_sensor(s, index, nd);
+}
+extern "C" int mi355_scene_set_sensor(mi355_scene *s, uint32_t index, const mi355_sensor_desc *sensor) {
+    Phase ph(PHASE_PARAMS);
+    if (!s || !sensor) return fail(MI355_ERR_INVALID, "null argument");
+    if (index > s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range (index == count appends)");
+    return reinit_sensor(s, index, *sensor);
+}
+extern "C" int mi355_scene_sensor_count(const mi355_scene *s) {
+    if (!s) return fail(MI355_ERR_INVALID, "null scene");
+    return (int) s->sensors.size();
+}
 extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t index, const float *values, uint64_t count) {
     if (!s || !values) return fail(MI355_ERR_INVALID, "null argument");
+    if (kind == MI355_PARAM_SENSOR_TO_WORLD || kind == MI355_PARAM_SENSOR_X_FOV) return set_sensor_param(s, kind, index, values, count);
     if (kind == MI355_PARAM_VERTEX_POSITIONS || kind == MI355_PARAM_BSDF_IOR) return set_geometry_param(s, kind, index, values, count, false, nullptr);
     float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
@@ -2163,6 +2304,12 @@ extern "C" int mi355_scene_set_param(mi355_scene *s, uint32_t kind, uint32_t ind
 extern "C" int mi355_scene_set_param_device(mi355_scene *s, uint32_t kind, uint32_t index, const float *d_values, uint64_t count, void *stream) {
     Phase ph(PHASE_PARAMS);
     if (!s || !d_values) return fail(MI355_ERR_INVALID, "null argument");
+    if (kind == MI355_PARAM_SENSOR_TO_WORLD || kind == MI355_PARAM_SENSOR_X_FOV) {      // a sensor is host-side state: fetch the few floats
+        float v[12]; if (count > 12) return fail(MI355_ERR_INVALID, "bad sensor parameter size");
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipMemcpyAsync(v, d_values, count * 4, hipMemcpyDeviceToHost, (hipStream_t) stream)); HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+        return set_sensor_param(s, kind, index, v, count);
+    }
     if (kind == MI355_PARAM_VERTEX_POSITIONS || kind == MI355_PARAM_BSDF_IOR) return set_geometry_param(s, kind, index, d_values, count, true, (hipStream_t) stream);
     float *h, *d; int rc = param_target(s, kind, index, count, &h, &d); if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
@@ -2178,8 +2325,9 @@ extern "C" int mi355_scene_param_layout(const mi355_scene *s, mi355_param_info *
     return (int) s->layout.size();
 }
 
-static int make_args(const mi355_scene *s, const mi355_render_params *p, RenderArgs *a) {
+static int make_args(mi355_scene *s, const mi355_render_params *p, RenderArgs *a) {
     if (!s || !p) return fail(MI355_ERR_INVALID, "null argument");
+    { int rc_s = select_sensor(s, p->sensor); if (rc_s) return rc_s; }      // the `Sensor *` argument of Integrator::render / render_backward
     // lanes cover the crop window, except for the particle tracer: the whole film (integrator.cpp:575-577)
     uint32_t npix = p->integrator == MI355_INTEGRATOR_PTRACER ? s->ds.film_w * s->ds.film_h : s->ds.grid_w * s->ds.grid_h;
     if (p->spp == 0) return fail(MI355_ERR_INVALID, "spp must be > 0");
@@ -2302,13 +2450,13 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
     if ((rc = ensure_geometry(s, st))) return rc;
+    if (p->integrator == MI355_INTEGRATOR_PTRACER && s->emitters.empty()) return MI355_OK;   // "no emitters found, returning black image", integrator.cpp:590-600
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     const bool full = (s->ds.features != 0u) != 0;
     const bool flat = full && s->ds.n_bvh_shapes == 0u;                      // every feature, but nothing to traverse: the <2> instantiations
     float *nof = nullptr;
     if (p->integrator == MI355_INTEGRATOR_PTRACER) {
-        if (s->emitters.empty()) return MI355_OK;                           // "no emitters found, returning black image", integrator.cpp:590-600
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         // Reconstruction filters with more than one tap: deferred, tile-sorted splat (see film_put_deferred).  The queue holds every
         // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
@@ -2370,22 +2518,24 @@ extern "C" int mi355_set_reduce_hook(mi355_scene *s, mi355_reduce_fn fn, void *u
     s->reduce_fn = fn; s->reduce_user = user;
     return MI355_OK;
 }
-extern "C" int mi355_film_develop(mi355_scene *s, const float *d_film_rgbw, float *d_image_rgb, void *stream) {
+extern "C" int mi355_film_develop(mi355_scene *s, uint32_t sensor, const float *d_film_rgbw, float *d_image_rgb, void *stream) {
     Phase ph(PHASE_DEVELOP);
     if (!s || !d_film_rgbw || !d_image_rgb) return fail(MI355_ERR_INVALID, "null argument");
+    if (sensor >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
     HIP_TRY(hipSetDevice(s->device));
-    uint32_t n = s->ds.crop_w * s->ds.crop_h;
+    uint32_t n = s->sensors[sensor].snap.crop_w * s->sensors[sensor].snap.crop_h;
     hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, d_film_rgbw, d_image_rgb, n);
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }
 extern "C" int mi355_render(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, float *d_image_rgb, void *stream) {
-    if (!s || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    if (!s || !p || !d_film_rgbw) return fail(MI355_ERR_INVALID, "null argument");
+    { int rc_s = select_sensor(s, p->sensor); if (rc_s) return rc_s; }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemsetAsync(d_film_rgbw, 0, (size_t) s->ds.crop_w * s->ds.crop_h * 16, (hipStream_t) stream));
     int rc = mi355_render_accumulate(s, p, d_film_rgbw, stream); if (rc) return rc;
     if ((rc = reduce_hook(s, d_film_rgbw, (uint64_t) s->ds.crop_w * s->ds.crop_h * 4u, stream))) return rc;   // the film of the whole job
-    if (d_image_rgb) return mi355_film_develop(s, d_film_rgbw, d_image_rgb, stream);
+    if (d_image_rgb) return mi355_film_develop(s, p->sensor, d_film_rgbw, d_image_rgb, stream);
     return MI355_OK;
 }
 extern "C" int mi355_prb_splat_weights(mi355_scene *s, const mi355_render_params *p, float *d_weight, void *stream) {
@@ -2432,8 +2582,8 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
         const float ext = s->ext_iors[t->bsdf], rel = s->bsdfs[t->bsdf].rel_eta;   // rel_eta = int_ior / ext_ior
         d_rel = t->d_int_ior / ext - rel * t->d_ext_ior / ext;
     }
-    if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "the design forward mode is built for the perspective sensor");
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
+    if (s->ds.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "the design forward mode is built for the perspective sensor");
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0 || s->emitters.empty()) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
@@ -2476,10 +2626,16 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
     if (a.n_local == 0) return MI355_OK;
     hipStream_t st = (hipStream_t) stream;
     if ((rc = ensure_geometry(s, st))) return rc;
+    if (pt && s->emitters.empty()) return MI355_OK;
+    if (pt && (p->flags & MI355_FLAG_GEOMETRY_GRADS)) {
+        // The geometry adjoint treats emitters as static (the emitter's sampled position and direction carry no derivative), so a gradient
+        // slot on an emitter-carrying mesh would silently miss the term AD includes: refuse, like the forward design mode does.
+        for (const DEmitter &e : s->emitters) if (e.shape < s->shapes.size() && s->shapes[e.shape].type == MI355_SHAPE_MESH && s->shapes[e.shape].grad_offset != 0xffffffffu)
+            return fail(MI355_ERR_UNSUPPORTED, "geometry gradients: a mesh that carries an emitter cannot be differentiated (its emitted rays are treated as static)");
+    }
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
     if (pt) {                                                               // Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp, radiances only
-        if (s->emitters.empty()) return MI355_OK;
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
         const dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
         const uint32_t n_small_pt = (uint32_t) s->small_map.size();
@@ -2528,6 +2684,11 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         return tm.end();
     }
     uint32_t npix = s->ds.crop_w * s->ds.crop_h;
+    if (s->gw_pixels < npix) {                                              // grad_in / W scratch, sized by the largest film this handle has served
+        if (s->d_gw) HIP_TRY(hipFree(s->d_gw));
+        s->d_gw = nullptr; s->gw_pixels = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_gw, (size_t) npix * sizeof(float4))); s->gw_pixels = npix;
+    }
     hipLaunchKernelGGL(k_prepare_grad, dim3((npix + 255) / 256), dim3(256), 0, st, d_grad_in, d_weight, s->d_gw, npix);
     const dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
     const uint32_t n_small = (uint32_t) s->small_map.size();
@@ -2583,10 +2744,12 @@ extern "C" int mi355_get_counters(mi355_scene *s, mi355_counters *out, int reset
     if (reset) { HIP_TRY(hipMemset(s->d_counters, 0, sizeof(h))); s->n_gen = s->n_splat = 0; s->ms_accum = 0.f; s->launches_accum = 0; }
     return MI355_OK;
 }
-extern "C" int mi355_lens_exit_pupil_bounds(const mi355_scene *s, float *out) {
+extern "C" int mi355_lens_exit_pupil_bounds(const mi355_scene *s, uint32_t sensor, float *out) {
     if (!s || !out) return fail(MI355_ERR_INVALID, "null argument");
-    if (s->pupil.empty()) return fail(MI355_ERR_INVALID, "the scene's sensor does not sample an exit pupil");
-    memcpy(out, s->pupil.data(), s->pupil.size() * sizeof(float));
+    if (sensor >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
+    const std::vector<float> &pupil = s->sensors[sensor].pupil;
+    if (pupil.empty()) return fail(MI355_ERR_INVALID, "the sensor does not sample an exit pupil");
+    memcpy(out, pupil.data(), pupil.size() * sizeof(float));
     return MI355_OK;
 }
 extern "C" int mi355_scene_info(const mi355_scene *s, uint32_t out[8]) {
@@ -2650,6 +2813,17 @@ extern "C" int mi355_debug_texture_eval(mi355_scene *s, uint32_t texture, const 
     HIP_TRY(hipSetDevice(s->device));
     if (!n) return MI355_OK;
     hipLaunchKernelGGL(k_debug_texture, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, texture, d_uv, n, d_rgb);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_trace_rays(mi355_scene *s, const float *d_rays, uint32_t n, uint32_t num_lenses, int32_t max_depth, float *d_out, void *stream) {
+    if (!s || !d_rays || !d_out) return fail(MI355_ERR_INVALID, "null argument");
+    if (max_depth < -1) return fail(MI355_ERR_INVALID, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (num_lenses == 0u || num_lenses > 4096u) return fail(MI355_ERR_INVALID, "num_lenses must lie in [1, 4096]");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!n) return MI355_OK;
+    { int rc = ensure_geometry(s, (hipStream_t) stream); if (rc) return rc; }
+    hipLaunchKernelGGL(k_trace, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, d_rays, n, num_lenses, (uint32_t) max_depth, d_out);
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

@@ -85,8 +85,8 @@ class HipBackend:
     def accumulate(self, scene, p, film):
         abi.check(abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), _stream_ptr(film.device)))
 
-    def develop(self, scene, film, img):
-        abi.check(abi.lib().mi355_film_develop(scene.handle(), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), _stream_ptr(film.device)))
+    def develop(self, scene, film, img, sensor=0):
+        abi.check(abi.lib().mi355_film_develop(scene.handle(), int(sensor), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), _stream_ptr(film.device)))
 
     def splat_weights(self, scene, p, weight):
         abi.check(abi.lib().mi355_prb_splat_weights(scene.handle(), C.byref(p), C.c_void_p(weight.data_ptr()), _stream_ptr(weight.device)))
@@ -143,10 +143,12 @@ class Integrator:
         return film.crop_width + 2 * b, film.crop_height + 2 * b
 
     # ---- parameter block for the C ABI -----------------------------------------------------------
-    def _params(self, scene, seed, spp, shard=None, spp_shard=None):
-        f = scene.sensor.film
+    def _params(self, scene, seed, spp, shard=None, spp_shard=None, sensor=0):
+        sensor = scene.sensor_index(sensor)
+        se = scene.sensors()[sensor]; f = se.film
         p = abi.RenderParams()
-        p.seed = (int(seed) + scene.sensor.base_seed) & 0xffffffff      # sampler.cpp:120: m_base_seed + seed
+        p.sensor = sensor                                               # the `Sensor *` argument of Integrator::render (integrator.h:74-97)
+        p.seed = (int(seed) + se.base_seed) & 0xffffffff                # sampler.cpp:120: m_base_seed + seed
         p.spp = int(spp)
         p.max_depth = self.max_depth; p.rr_depth = self.rr_depth
         p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0) | (abi.FLAG_REGEN if getattr(self, "regen", False) else 0) | (abi.FLAG_TWO_PASS if getattr(self, "two_pass", False) else 0) | (abi.FLAG_DIRECT_SPLAT if getattr(self, "direct_splat", False) else 0)
@@ -176,8 +178,8 @@ class Integrator:
             p.spp_begin, p.spp_count = spp_shard
         return p
 
-    def _resolve_spp(self, scene, spp):
-        return int(spp) if spp else scene.sensor.sample_count
+    def _resolve_spp(self, scene, spp, sensor=0):
+        return int(spp) if spp else scene.sensors()[scene.sensor_index(sensor)].sample_count      # integrator.cpp:140-141: the sensor's sampler
 
     # ---- Integrator::render -----------------------------------------------------------------------
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
@@ -187,13 +189,14 @@ class Integrator:
         torch = _torch()
         be = self.backend
         dev = be.device(scene)
-        f = scene.sensor.film
-        spp = self._resolve_spp(scene, spp)
+        sensor = scene.sensor_index(sensor)
+        f = scene.sensors()[sensor].film
+        spp = self._resolve_spp(scene, spp, sensor)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
         band = None
         if shard is not None:
             band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f))
-        p = self._params(scene, seed, spp, shard=band)
+        p = self._params(scene, seed, spp, shard=band, sensor=sensor)
         if band is None or band[1] > 0:
             be.accumulate(scene, p, film)
         if shard is not None and shard[1] > 1:
@@ -202,7 +205,7 @@ class Integrator:
         if not develop:
             return film
         img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
-        be.develop(scene, film, img)
+        be.develop(scene, film, img, sensor)
         if evaluate:
             be.synchronize(dev)
         return img
@@ -215,13 +218,14 @@ class Integrator:
         torch = _torch()
         be = self.backend
         dev = be.device(scene)
-        f = scene.sensor.film
-        spp = self._resolve_spp(scene, spp)
+        sensor = scene.sensor_index(sensor)
+        f = scene.sensors()[sensor].film
+        spp = self._resolve_spp(scene, spp, sensor)
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
         if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
             raise ValueError("grad_in must have shape (H, W, 3)")
         band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
-        p = self._params(scene, seed, spp, shard=band)
+        p = self._params(scene, seed, spp, shard=band, sensor=sensor)
         p.integrator = abi.INTEGRATOR_PRB
         weight = torch.zeros((f.crop_height, f.crop_width), dtype=torch.float32, device=dev)
         active = band is None or band[1] > 0
@@ -249,14 +253,15 @@ class Integrator:
         torch = _torch()
         be = self.backend
         dev = be.device(scene)
-        f = scene.sensor.film
-        spp = self._resolve_spp(scene, spp)
+        sensor = scene.sensor_index(sensor)
+        f = scene.sensors()[sensor].film
+        spp = self._resolve_spp(scene, spp, sensor)
         if params is None:
             raise PluginError("render_forward needs the SceneParameters carrying the tangents")
         tangent = params.tangent_buffer(dev)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
         band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
-        p = self._params(scene, seed, spp, shard=band)
+        p = self._params(scene, seed, spp, shard=band, sensor=sensor)
         p.integrator = abi.INTEGRATOR_PRB
         if band is None or band[1] > 0:
             abi.check(abi.lib().mi355_render_forward(scene.handle(), C.byref(p), C.c_void_p(tangent.data_ptr()), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
@@ -264,7 +269,7 @@ class Integrator:
             import torch.distributed as dist
             dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
         img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
-        be.develop(scene, film, img)
+        be.develop(scene, film, img, sensor)
         return img
 
     def counters(self, scene, reset=False):
@@ -272,12 +277,12 @@ class Integrator:
         abi.check(abi.lib().mi355_get_counters(scene.handle(), C.byref(c), 1 if reset else 0))
         return {k: getattr(c, k) for k, _ in abi.Counters._fields_}
 
-    def lane_radiance(self, scene, seed, spp, lane_begin, count):
+    def lane_radiance(self, scene, seed, spp, lane_begin, count, sensor=0):
         """Per-lane (r,g,b,valid) of global lanes [lane_begin, lane_begin+count) -- check_vectorization hook."""
         torch = _torch()
         h = scene.handle(); dev = torch.device("cuda", scene._device)
         out = torch.empty((count, 4), dtype=torch.float32, device=dev)
-        p = self._params(scene, seed, self._resolve_spp(scene, spp))
+        p = self._params(scene, seed, self._resolve_spp(scene, spp, sensor), sensor=sensor)
         abi.check(abi.lib().mi355_debug_lane_radiance(h, C.byref(p), int(lane_begin), int(count), C.c_void_p(out.data_ptr()), _stream_ptr(dev)))
         torch.cuda.current_stream(dev).synchronize()
         return out
@@ -342,8 +347,9 @@ class ParticleTracerIntegrator(Integrator):
         torch = _torch()
         be = self.backend
         dev = be.device(scene)
-        f = scene.sensor.film
-        spp = self._resolve_spp(scene, spp)
+        sensor = scene.sensor_index(sensor)
+        f = scene.sensors()[sensor].film
+        spp = self._resolve_spp(scene, spp, sensor)
         t = abi.DesignTangent(); t.shape = abi.NONE; t.bsdf = abi.NONE; t.d_vertex_tangent = None
         vt = None
         if shape is not None:
@@ -357,10 +363,10 @@ class ParticleTracerIntegrator(Integrator):
             t.bsdf = bsdf if isinstance(bsdf, int) else [i for i, b in enumerate(scene.bsdfs) if b.id == bsdf][0]
             t.d_int_ior = float(d_int_ior); t.d_ext_ior = float(d_ext_ior)
         film = torch.zeros((f.crop_height, f.crop_width, 4), dtype=torch.float32, device=dev)
-        p = self._params(scene, seed, spp)
+        p = self._params(scene, seed, spp, sensor=sensor)
         abi.check(abi.lib().mi355_ptracer_forward_design(scene.handle(), C.byref(p), C.byref(t), C.c_void_p(film.data_ptr()), _stream_ptr(dev)))
         img = torch.empty((f.crop_height, f.crop_width, 3), dtype=torch.float32, device=dev)
-        be.develop(scene, film, img)
+        be.develop(scene, film, img, sensor)
         return img
 
     def render_forward_geometry(self, scene, shape, vertex_tangent, sensor=0, seed=0, spp=0):
@@ -380,16 +386,17 @@ class ParticleTracerIntegrator(Integrator):
             geometry = params is not None and params.wants_geometry()
         if colour is None:
             colour = not (geometry and params is not None and params.wants_geometry() and not params.wants_colour())
-        radiance_only = (not geometry) and params is not None and all(params._entries[k][0] == abi.PARAM_EMITTER_RADIANCE for k in params.keys())
+        radiance_only = (not geometry) and params is not None and all(e[0] == abi.PARAM_EMITTER_RADIANCE for e in params._entries.values())
         be = self.backend
         dev = be.device(scene)
-        f = scene.sensor.film
-        spp = self._resolve_spp(scene, spp)
+        sensor = scene.sensor_index(sensor)
+        f = scene.sensors()[sensor].film
+        spp = self._resolve_spp(scene, spp, sensor)
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).contiguous()
         if tuple(grad_in.shape) != (f.crop_height, f.crop_width, 3):
             raise ValueError("grad_in must have shape (H, W, 3)")
         band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
-        p = self._params(scene, seed, spp, shard=band)
+        p = self._params(scene, seed, spp, shard=band, sensor=sensor)
         if radiance_only:
             p.flags |= abi.FLAG_EMITTER_GRADS_ONLY
         if geometry:
@@ -408,15 +415,59 @@ class ParticleTracerIntegrator(Integrator):
         return grads
 
 
+class BasicPRBIntegrator(Integrator):
+    """The fork's `prb_basic` (src/python/python/ad/integrators/prb_basic.py) as far as the path uses it: `trace()`, the deterministic
+    geometric ray tracer the lens-design scripts place their cameras with (design_problem.py:183-203, :415-417) and check their lens
+    meshes against (:430-472).  Its `sample()` -- a path tracer without next-event estimation -- is not on the path: the scripts render
+    with `ptracer` (design_problem.py:405-422)."""
+    integrator_id = abi.INTEGRATOR_PRB
+    name = "prb_basic"
+    default_max_depth = 6
+
+    def render(self, *a, **k):
+        raise PluginError("prb_basic: only trace() is built (the lens-design scripts render with `ptracer`, design_problem.py:405-422)")
+
+    render_backward = render_forward = render
+
+    def trace(self, scene, ray, num_lenses):
+        """BasicPRBIntegrator.trace(scene, ray, num_lenses) (prb_basic.py:46-140).  `ray`: a Ray-like object with `.o` and `.d` (n x 3 or 3)
+        or an n x 6 array (origin, direction); rays start with maxt = Largest like mi.Ray3f(o, d).  Returns (penultimate_o, penultimate_d,
+        valid, p) as torch tensors on the scene's device: origin / direction of the ray that produced the last interaction, the reference's
+        validity flag -- si.is_valid() & dr.allclose(0, si.p.z): as in the reference ONE verdict of the closeness test for the whole batch
+        (:138), ANDed with each ray's own hit flag -- and the last interaction's position (the film point)."""
+        torch = _torch()
+        dev = self.backend.device(scene)
+        if hasattr(ray, "o") and hasattr(ray, "d"):
+            o = torch.as_tensor(np.asarray(ray.o, dtype=np.float32)).reshape(-1, 3); d = torch.as_tensor(np.asarray(ray.d, dtype=np.float32)).reshape(-1, 3)
+        else:
+            a = torch.as_tensor(np.asarray(ray, dtype=np.float32)).reshape(-1, 6); o, d = a[:, :3], a[:, 3:]
+        n = o.shape[0]
+        rays = torch.zeros((n, 8), dtype=torch.float32)
+        rays[:, 0:3] = o; rays[:, 3:6] = d; rays[:, 6] = 3.4028234663852886e38       # dr::Largest<Float>: Ray3f's default maxt (ray.h:35)
+        rays = rays.to(dev)
+        out = torch.empty((n, 12), dtype=torch.float32, device=dev)
+        abi.check(abi.lib().mi355_trace_rays(scene.handle(), C.c_void_p(rays.data_ptr()), n, int(num_lenses), int(self.max_depth),
+                                              C.c_void_p(out.data_ptr()), _stream_ptr(dev)))
+        torch.cuda.current_stream(dev).synchronize()
+        p = out[:, 6:9]
+        hit = out[:, 9] != 0
+        z = p[:, 2].abs()
+        close = bool((z <= 1e-8 + 1e-5 * z).all().item())          # dr.allclose(0.0, si.p.z): |0 - z| <= atol + rtol |z|, over ALL lanes
+        self.penultimate_o, self.penultimate_d, self.valid = out[:, 0:3], out[:, 3:6], hit & close
+        return self.penultimate_o, self.penultimate_d, self.valid, p
+
+
 def make_integrator(props):
     t = props.get("type")
+    if t == "prb_basic":
+        return BasicPRBIntegrator(props)
     if t == "path":
         return PathIntegrator(props)
     if t == "prb":
         return PRBIntegrator(props)
     if t == "ptracer":
         return ParticleTracerIntegrator(props)
-    raise PluginError('integrator plugin "%s" is outside the path (path, prb, ptracer)' % t)
+    raise PluginError('integrator plugin "%s" is outside the path (path, prb, ptracer, prb_basic)' % t)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -472,6 +523,15 @@ class SceneParameters:
             else:                                      # dielectric.cpp:236-239 exposes eta (non-differentiable); the two indices are this build's parameters
                 self._add("%s.int_ior" % b.id, abi.PARAM_BSDF_IOR, i, torch.tensor([b.int_ior], dtype=torch.float32, device=dev), comp=0)
                 self._add("%s.ext_ior" % b.id, abi.PARAM_BSDF_IOR, i, torch.tensor([b.ext_ior], dtype=torch.float32, device=dev), comp=1)
+        # Sensor parameters (PerspectiveCamera::traverse, perspective.cpp:155-161; Film::traverse, film.cpp:100-104): host values, no gradient
+        # slot -- the lens-design loop moves and zooms its cameras under dr.suspend_grad (design_problem.py:113-132)
+        self._host = {}        # key -> (what, sensor index)
+        for i, se in enumerate(scene.sensors()):
+            self._host["%s.to_world" % se.id] = ("to_world", i)
+            if se.type == abi.SENSOR_PERSPECTIVE:
+                self._host["%s.x_fov" % se.id] = ("x_fov", i)
+            for what in ("size", "crop_size", "crop_offset"):
+                self._host["%s.film.%s" % (se.id, what)] = (what, i)
 
     def _add(self, key, kind, index, value, comp=-1):
         self._entries[key] = (kind, index, tuple(value.shape))
@@ -497,22 +557,62 @@ class SceneParameters:
         if not isinstance(keys, list):
             keys = [keys]
         regexps = [re.compile(k).match for k in keys]
-        wanted = [k for k in self._entries if any(r(k) for r in regexps)]
+        wanted = [k for k in self.keys() if any(r(k) for r in regexps)]
         for k in list(self._entries):
             if k not in wanted:
                 del self._entries[k]; del self._values[k]; self._dirty.discard(k); self._comp.pop(k, None)
+        for k in list(self._host):
+            if k not in wanted:
+                del self._host[k]; self._dirty.discard(k)
 
-    def keys(self): return self._entries.keys()
-    def __contains__(self, k): return k in self._entries
-    def __len__(self): return len(self._entries)
-    def __iter__(self): return iter(self._entries)
-    def items(self): return self._values.items()
+    def keys(self): return list(self._entries.keys()) + list(self._host.keys())
+    def __contains__(self, k): return k in self._entries or k in self._host
+    def __len__(self): return len(self._entries) + len(self._host)
+    def __iter__(self): return iter(self.keys())
+    def items(self): return [(k, self[k]) for k in self.keys()]
+
+    def _get_host(self, key):
+        what, i = self._host[key]; se = self.scene.sensors()[i]; f = se.film
+        if what == "to_world":
+            return se.to_world
+        if what == "x_fov":
+            return se.x_fov
+        return {"size": (f.width, f.height), "crop_size": (f.crop_width, f.crop_height), "crop_offset": (f.crop_offset_x, f.crop_offset_y)}[what]
+
+    def _set_host(self, key, value):
+        """PerspectiveCamera::parameters_changed (perspective.cpp:163-171) / Film::parameters_changed (film.cpp:59-98), applied to the host
+        object at once; the device replica follows at update()."""
+        from .transforms import Transform4f
+        what, i = self._host[key]; se = self.scene.sensors()[i]; f = se.film
+        if what == "to_world":
+            tw = value if isinstance(value, Transform4f) else Transform4f(np.asarray(value.detach().cpu() if hasattr(value, "detach") else value, dtype=np.float64).reshape(4, 4))
+            if tw.has_scale():
+                raise PluginError("Scale factors in the camera-to-world transformation are not allowed!")
+            se.to_world = tw
+        elif what == "x_fov":
+            v = float(value.detach().reshape(-1)[0]) if hasattr(value, "detach") else float(np.asarray(value).reshape(-1)[0])
+            if not 0.0 < v < 180.0:
+                raise PluginError("The horizontal field of view must be in the range [0, 180]!")
+            se.x_fov = float(np.float32(v))
+        else:
+            a, b = (int(x) for x in value)
+            if what == "size":                       # Film::set_size (film.cpp:59-65): the crop window is reset to the whole film
+                f.width, f.height = a, b; f.crop_width, f.crop_height, f.crop_offset_x, f.crop_offset_y = a, b, 0, 0
+            elif what == "crop_size":
+                f.crop_width, f.crop_height = a, b
+            else:
+                f.crop_offset_x, f.crop_offset_y = a, b
+        self._dirty.add(key)
 
     def __getitem__(self, key):
+        if key in self._host:
+            return self._get_host(key)
         return self._values[key]
 
     def __setitem__(self, key, value):
         torch = _torch()
+        if key in self._host:
+            return self._set_host(key, value)
         if key not in self._entries:
             raise KeyError(key)
         kind, index, shape = self._entries[key]
@@ -527,13 +627,36 @@ class SceneParameters:
         `skip`: keys the caller pushes itself (mi.render's differentiable parameters)."""
         if values is not None:
             for k, v in values.items():
-                if k in self._entries:
+                if k in self._entries or k in self._host:
                     self[k] = v
         out = sorted(k for k in self._dirty if k not in skip)
+        sensors = set()
         for key in out:
-            self._push(key, self._values[key])
+            if key in self._host:
+                sensors.add(self._host[key][1])
+            else:
+                self._push(key, self._values[key])
+        for i in sorted(sensors):                      # one description per changed sensor, whatever combination of its keys was set
+            self._push_sensor(i, [k for k in out if k in self._host and self._host[k][1] == i])
         self._dirty.difference_update(out)
         return out
+
+    def _push_sensor(self, index, keys):
+        """Hand a changed sensor to the device replica: `to_world` / `x_fov` alone go as parameters (MI355_PARAM_SENSOR_*), a film change
+        replaces the sensor's description (mi355_scene_set_sensor).  Either way the replica -- geometry, BVH, scratch -- stays."""
+        se = self.scene.sensors()[index]
+        whats = {self._host[k][0] for k in keys}
+        if self.scene._handle is None:
+            return
+        if whats <= {"to_world", "x_fov"}:
+            if "to_world" in whats:
+                m = np.ascontiguousarray(se.to_world.affine12(), dtype=np.float32)
+                abi.check(abi.lib().mi355_scene_set_param(self.scene.handle(), abi.PARAM_SENSOR_TO_WORLD, index, m.ctypes.data_as(abi.f32p), 12))
+            if "x_fov" in whats:
+                v = np.array([se.x_fov], dtype=np.float32)
+                abi.check(abi.lib().mi355_scene_set_param(self.scene.handle(), abi.PARAM_SENSOR_X_FOV, index, v.ctypes.data_as(abi.f32p), 1))
+        else:
+            self.scene.push_sensor(index)
 
     def _push(self, key, tensor):
         """Upload one parameter to the device replica and keep the host description coherent."""
@@ -636,11 +759,12 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     elif seed_grad == seed:
         raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
 
-    diff_keys = [k for k in (params.keys() if params is not None else []) if params[k].requires_grad]
+    diff_keys = [k for k in (params.keys() if params is not None else []) if getattr(params[k], "requires_grad", False)]
     if params is not None:
         params.update(skip=diff_keys)      # (the differentiable ones are pushed by the render op itself, every time: their tensors may be edited in place)
     if not diff_keys:
         return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
+    sensor = scene.sensor_index(sensor)
 
     class _RenderOp(torch.autograd.Function):
         @staticmethod

@@ -446,7 +446,7 @@ class DesignProblem:
         import torch
         self.scene = load_dict(self.scene_dict())
         self.params = traverse(self.scene)
-        dev = self.params[next(iter(self.params.keys()))].device
+        dev = self.params[next(iter(self.params._entries))].device
         self.optimizer = Adam(lr=self.lr)
         self.lens_system.save_init_state(self.params)
         self.lens_system.add_to_optimizer(self.optimizer, dev)

@@ -399,7 +399,8 @@ class Film:
 
 
 class Sensor:
-    def __init__(self, props):
+    def __init__(self, props, id="sensor"):
+        self.id = id
         t = props.get("type", "perspective")
         if t not in ("perspective", "realisticlens"):
             raise PluginError('sensor plugin "%s" is outside the path in this build (perspective, realisticlens)' % t)
@@ -439,14 +440,38 @@ class Sensor:
 class Scene:
     def __init__(self):
         self.shapes, self.bsdfs, self.emitters, self.textures = [], [], [], []
-        self.sensor = None
+        self._sensors = []               # Scene::sensors(): every sensor of the scene, in the order the scene lists them
         self.integrator_props = None
         self._handle = None
         self._device = None
         self._keep = []
 
     # ---- Mitsuba-like accessors ------------------------------------------------------------------
-    def sensors(self): return [self.sensor]
+    def sensors(self): return self._sensors
+
+    @property
+    def sensor(self):
+        """The first sensor -- what every `sensor=0` default of the reference's API means (util.py:410-523, integrator.h:74-97)."""
+        return self._sensors[0] if self._sensors else None
+
+    @sensor.setter
+    def sensor(self, value):
+        if self._sensors:
+            self._sensors[0] = value
+        else:
+            self._sensors.append(value)
+
+    def sensor_index(self, sensor):
+        """`sensor` as the reference's API takes it: an index into sensors(), or a Sensor object of this scene."""
+        if isinstance(sensor, Sensor):
+            for i, se in enumerate(self._sensors):
+                if se is sensor:
+                    return i
+            raise PluginError("the sensor does not belong to this scene")
+        i = int(sensor)
+        if not 0 <= i < len(self._sensors):
+            raise PluginError("Out-of-bound sensor index %d (the scene has %d sensors)" % (i, len(self._sensors)))     # util.py:489-491
+        return i
     def integrator(self):
         from .integrators import make_integrator
         return make_integrator(self.integrator_props) if self.integrator_props else None
@@ -493,23 +518,41 @@ class Scene:
         d.abi_version = abi.ABI_VERSION
         d.n_shapes, d.n_bsdfs, d.n_emitters, d.n_textures = len(self.shapes), len(self.bsdfs), len(self.emitters), len(self.textures)
         d.shapes, d.bsdfs, d.emitters, d.textures = sh, bs, em, tex
-        se, f = self.sensor, self.sensor.film
-        d.sensor.type = se.type
-        if se.lens_table is not None:
-            d.sensor.lens_count = se.lens_table.shape[0]
-            d.sensor.lens_data = se.lens_table.ctypes.data_as(abi.f32p); keep.append(se.lens_table)
-        d.sensor.film_diagonal = f.diagonal
-        d.sensor.to_world[:] = se.to_world.affine12().tolist()
-        d.sensor.shutter_open_time = se.shutter_open_time; d.sensor.sample_exit_pupil = 1 if se.sample_exit_pupil else 0
-        d.sensor.sample_border = 1 if se.film.sample_border else 0
-        d.sensor.x_fov, d.sensor.near_clip, d.sensor.far_clip = se.x_fov, se.near_clip, se.far_clip
-        d.sensor.film_width, d.sensor.film_height = f.width, f.height
-        d.sensor.crop_offset_x, d.sensor.crop_offset_y = f.crop_offset_x, f.crop_offset_y
-        d.sensor.crop_width, d.sensor.crop_height = f.crop_width, f.crop_height
-        d.sensor.rfilter, d.sensor.rfilter_param = f.rfilter, f.rfilter_param
-        keep += [tex, bs, em, sh]
+        sens = (abi.SensorDesc * max(len(self._sensors), 1))()
+        for i in range(len(self._sensors)):
+            self.sensor_desc(i, out=sens[i], keep=keep)
+        d.n_sensors, d.sensors = len(self._sensors), sens
+        keep += [tex, bs, em, sh, sens]
         self._keep = keep
         return d
+
+    def sensor_desc(self, index, out=None, keep=None):
+        """mi355_sensor_desc of sensor `index` (kept alive by the Sensor object's own buffers)."""
+        se = self._sensors[index]; f = se.film
+        d = abi.SensorDesc() if out is None else out
+        d.type = se.type
+        if se.lens_table is not None:
+            d.lens_count = se.lens_table.shape[0]
+            d.lens_data = se.lens_table.ctypes.data_as(abi.f32p)
+            if keep is not None:
+                keep.append(se.lens_table)
+        d.film_diagonal = f.diagonal
+        d.to_world[:] = se.to_world.affine12().tolist()
+        d.shutter_open_time = se.shutter_open_time; d.sample_exit_pupil = 1 if se.sample_exit_pupil else 0
+        d.sample_border = 1 if f.sample_border else 0
+        d.x_fov, d.near_clip, d.far_clip = se.x_fov, se.near_clip, se.far_clip
+        d.film_width, d.film_height = f.width, f.height
+        d.crop_offset_x, d.crop_offset_y = f.crop_offset_x, f.crop_offset_y
+        d.crop_width, d.crop_height = f.crop_width, f.crop_height
+        d.rfilter, d.rfilter_param = f.rfilter, f.rfilter_param
+        return d
+
+    def push_sensor(self, index):
+        """Sensor `index` changed on the host (film size, crop window, type ...): hand its new description to the device replica
+        (mi355_scene_set_sensor -- no geometry, BVH or scratch buffer is touched; without a replica yet there is nothing to do)."""
+        if self._handle is not None:
+            d = self.sensor_desc(index)
+            abi.check(abi.lib().mi355_scene_set_sensor(self._handle, int(index), C.byref(d)))
 
     # ---- engine handle ------------------------------------------------------------------------------
     def handle(self, device=None):
@@ -668,10 +711,10 @@ def load_dict(d):
         if key == "type" or not isinstance(v, dict):
             continue
         vt = v.get("type")
-        if vt in ("path", "prb", "ptracer"):
+        if vt in ("path", "prb", "ptracer", "prb_basic"):
             scene.integrator_props = dict(v)
         elif vt in ("perspective", "realisticlens"):
-            scene.sensor = Sensor(v)
+            scene._sensors.append(Sensor(v, id=key))
         elif vt in BSDF_PLUGINS:
             named[key] = _make_bsdf(scene, v, key)
         elif vt in ("rectangle", "cube", "obj", "ply", "mesh", "sphere", "disk"):
@@ -756,8 +799,8 @@ def load_dict(d):
             e.shape = shape; shape.emitter = e
             scene.emitters.append(e)
         scene.shapes.append(shape)
-    if scene.sensor is None:
-        scene.sensor = Sensor({"type": "perspective", "film": {"type": "hdrfilm"}})
+    if not scene._sensors:
+        scene._sensors.append(Sensor({"type": "perspective", "film": {"type": "hdrfilm"}}))
     return scene
 
 

@@ -298,11 +298,16 @@ typedef struct {
     float *lens; uint32_t lens_count; float film_px, film_py;   /* realisticlens: interface table, physical half extents */
     float pupil[64 * 4];                                          /* exit-pupil bounds (min.x, min.y, max.x, max.y) per film-radius segment */
     uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
+    /* Scene::sensors(): every sensor of the scene; the fields above (`sensor` ... `pupil`) are those of sensor `cur_sensor`, the one the
+       `Sensor *` argument of Integrator::render picks (mi355_render_params.sensor; integrator.h:74-97) */
+    mi355_sensor_desc *all_sensors; float **all_lens; float *all_pupil; int *pupil_done; uint32_t n_sensors, cur_sensor;
 } OScene;
 
 static void *dupmem(const void *p, size_t n) { if (!p || !n) return NULL; void *q = malloc(n); memcpy(q, p, n); return q; }
 
 static void exit_pupil_bounds(OScene *sc, float film_diagonal);
+ORC_API int orc_select_sensor(OScene *s, uint32_t index);
+ORC_API int orc_scene_set_sensor(OScene *s, uint32_t index, const mi355_sensor_desc *se);
 static void orc_bvh_build(OShape *sh);
 static void recompute_vertex_normals(OShape *sh);
 ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
@@ -363,37 +368,69 @@ ORC_API OScene *orc_scene_create(const mi355_scene_desc *d) {
             o->inv_area = rcpf_(4.f * ORC_PI * (o->radius * o->radius));
         } else { free(s); return NULL; }
     }
-    s->sensor = d->sensor;
-    int32_t film[2] = { (int32_t) d->sensor.film_width, (int32_t) d->sensor.film_height };
-    int32_t crop[2] = { (int32_t) d->sensor.crop_width, (int32_t) d->sensor.crop_height };
-    int32_t off[2] = { (int32_t) d->sensor.crop_offset_x, (int32_t) d->sensor.crop_offset_y };
-    perspective_projection(film, crop, off, d->sensor.x_fov, d->sensor.near_clip, d->sensor.far_clip,
-                           s->camera_to_sample, s->sample_to_camera);
-    if (d->sensor.type == MI355_SENSOR_REALISTICLENS) {
-        s->lens_count = d->sensor.lens_count;
-        s->lens = (float *) dupmem(d->sensor.lens_data, 64u * d->sensor.lens_count);
-        s->sensor.lens_data = s->lens;
-        float aspect = (float) d->sensor.film_height / (float) d->sensor.film_width;      /* Film::get_physical_size, film.h:193-198 */
-        float x = sqrtf(d->sensor.film_diagonal * d->sensor.film_diagonal / (1.f + aspect * aspect));
-        s->film_px = x / 2; s->film_py = aspect * x / 2;
-        if (d->sensor.sample_exit_pupil) exit_pupil_bounds(s, d->sensor.film_diagonal);
+    if (!d->n_sensors || !d->sensors) { free(s); return NULL; }
+    s->n_sensors = d->n_sensors; s->cur_sensor = 0xffffffffu;
+    s->all_sensors = (mi355_sensor_desc *) dupmem(d->sensors, sizeof(mi355_sensor_desc) * d->n_sensors);
+    s->all_lens = (float **) calloc(d->n_sensors, sizeof(float *));
+    s->all_pupil = (float *) calloc((size_t) d->n_sensors * 256, sizeof(float)); s->pupil_done = (int *) calloc(d->n_sensors, sizeof(int));
+    for (uint32_t i = 0; i < d->n_sensors; ++i) if (d->sensors[i].type == MI355_SENSOR_REALISTICLENS) {
+        s->all_lens[i] = (float *) dupmem(d->sensors[i].lens_data, 64u * d->sensors[i].lens_count); s->all_sensors[i].lens_data = s->all_lens[i];
     }
-    if (d->sensor.rfilter == MI355_RFILTER_GAUSSIAN) {
-        orc_gaussian_coeffs(d->sensor.rfilter_param, s->filter_coeff); s->filter_radius = 4.f * d->sensor.rfilter_param;
-    } else if (d->sensor.rfilter == MI355_RFILTER_TENT) s->filter_radius = d->sensor.rfilter_param;
+    orc_select_sensor(s, 0);
+    return s;
+}
+/* Makes sensor `index` the current one: PerspectiveCamera::update_camera_transforms (perspective.cpp:173-199), the film / filter
+   quantities, the realisticlens table and (once per sensor) its exit-pupil bounds. */
+ORC_API int orc_select_sensor(OScene *s, uint32_t index) {
+    if (index >= s->n_sensors) return -1;
+    if (s->cur_sensor == index) return 0;
+    const mi355_sensor_desc *se = &s->all_sensors[index];
+    s->sensor = *se; s->cur_sensor = index;
+    int32_t film[2] = { (int32_t) se->film_width, (int32_t) se->film_height };
+    int32_t crop[2] = { (int32_t) se->crop_width, (int32_t) se->crop_height };
+    int32_t off[2] = { (int32_t) se->crop_offset_x, (int32_t) se->crop_offset_y };
+    perspective_projection(film, crop, off, se->x_fov, se->near_clip, se->far_clip, s->camera_to_sample, s->sample_to_camera);
+    s->lens = NULL; s->lens_count = 0;
+    if (se->rfilter == MI355_RFILTER_GAUSSIAN) {
+        orc_gaussian_coeffs(se->rfilter_param, s->filter_coeff); s->filter_radius = 4.f * se->rfilter_param;
+    } else if (se->rfilter == MI355_RFILTER_TENT) s->filter_radius = se->rfilter_param;
     else s->filter_radius = 0.5f;
     {   /* rfilter.cpp:23: border_size = ceil(radius - 0.5 - 2 RayEps) */
         float bs = ceilf(s->filter_radius - .5f - 2.f * RAY_EPS);
-        s->border = d->sensor.sample_border ? (uint32_t) (bs > 0.f ? bs : 0.f) : 0u;
+        s->border = se->sample_border ? (uint32_t) (bs > 0.f ? bs : 0.f) : 0u;
     }
-    return s;
+    if (se->type == MI355_SENSOR_REALISTICLENS) {
+        s->lens_count = se->lens_count; s->lens = s->all_lens[index];
+        float aspect = (float) se->film_height / (float) se->film_width;      /* Film::get_physical_size, film.h:193-198 */
+        float x = sqrtf(se->film_diagonal * se->film_diagonal / (1.f + aspect * aspect));
+        s->film_px = x / 2; s->film_py = aspect * x / 2;
+        if (se->sample_exit_pupil) {
+            if (!s->pupil_done[index]) { exit_pupil_bounds(s, se->film_diagonal); memcpy(s->all_pupil + 256 * (size_t) index, s->pupil, sizeof(s->pupil)); s->pupil_done[index] = 1; }
+            else memcpy(s->pupil, s->all_pupil + 256 * (size_t) index, sizeof(s->pupil));
+        }
+    }
+    return 0;
+}
+/* mi355_scene_set_sensor: replace the description of sensor `index` (PerspectiveCamera::parameters_changed, perspective.cpp:163-171;
+   a film resize, film.cpp:59-98). */
+ORC_API int orc_scene_set_sensor(OScene *s, uint32_t index, const mi355_sensor_desc *se) {
+    if (index >= s->n_sensors) return -1;
+    float *lens = se->type == MI355_SENSOR_REALISTICLENS ? (float *) dupmem(se->lens_data, 64u * se->lens_count) : NULL;   /* (se may point into the slot) */
+    mi355_sensor_desc nd = *se; nd.lens_data = lens;
+    free(s->all_lens[index]); s->all_lens[index] = lens;
+    s->all_sensors[index] = nd;
+    s->pupil_done[index] = 0;
+    if (s->cur_sensor == index) { s->cur_sensor = 0xffffffffu; return orc_select_sensor(s, index); }
+    return 0;
 }
 ORC_API void orc_scene_destroy(OScene *s) {
     if (!s) return;
     for (uint32_t i = 0; i < s->n_shapes; ++i) { free(s->shapes[i].pos); free(s->shapes[i].nrm); free(s->shapes[i].uv); free(s->shapes[i].faces);
                                                  free(s->shapes[i].area_cdf); free(s->shapes[i].nrm_len); free(s->shapes[i].bvh); free(s->shapes[i].bvh_faces); }
     for (uint32_t i = 0; i < s->n_textures; ++i) free(s->textures[i].data);
-    free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s->lens); free(s);
+    for (uint32_t i = 0; i < s->n_sensors; ++i) free(s->all_lens[i]);
+    free(s->all_lens); free(s->all_sensors); free(s->all_pupil); free(s->pupil_done);
+    free(s->shapes); free(s->bsdfs); free(s->emitters); free(s->textures); free(s);
 }
 /* SceneParameters.update for one parameter: src/python/python/util.py:185-232 */
 ORC_API int orc_scene_set_param(OScene *s, uint32_t kind, uint32_t index, const float *v, uint64_t n) {
@@ -421,6 +458,12 @@ ORC_API int orc_scene_set_param(OScene *s, uint32_t kind, uint32_t index, const 
     }
     if (kind == MI355_PARAM_BSDF_IOR && index < s->n_bsdfs && s->bsdfs[index].type == MI355_BSDF_DIELECTRIC && n == 2) {
         s->bsdfs[index].int_ior = v[0]; s->bsdfs[index].ext_ior = v[1]; return 0;
+    }
+    if ((kind == MI355_PARAM_SENSOR_TO_WORLD && n == 12) || (kind == MI355_PARAM_SENSOR_X_FOV && n == 1)) {     /* perspective.cpp:155-171 */
+        if (index >= s->n_sensors) return -1;
+        mi355_sensor_desc nd = s->all_sensors[index];
+        if (kind == MI355_PARAM_SENSOR_TO_WORLD) memcpy(nd.to_world, v, 48); else nd.x_fov = v[0];
+        return orc_scene_set_sensor(s, index, &nd);
     }
     return -1;
 }
@@ -1930,6 +1973,7 @@ static uint32_t pt_shard_lane(const OScene *sc, const mi355_render_params *rp, u
 /* AdjointIntegrator::render: lanes = FILM size * spp (not crop), sample_scale = prod(crop) / (spp * prod(film)).  The
    accumulator is RGBW with W untouched = 0, so orc_film_develop divides by 1 (hdrfilm.cpp:396-400). */
 ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
+    orc_select_sensor(sc, rp->sensor);
     size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
     uint32_t passes = rp->passes ? rp->passes : 1u;
     if (rp->spp % passes) return 0;
@@ -1973,6 +2017,7 @@ static int64_t emitter_grad_offset(const OScene *sc, uint32_t e) {       /* orc_
    image IS the RGB accumulator because W = 0), grad_out the concatenated parameter-gradient buffer (orc_scene_param_layout); only
    the MI355_PARAM_EMITTER_RADIANCE slots are written (+=). */
 ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp, const float *grad_image, float *grad_out, int n_threads) {
+    orc_select_sensor(sc, rp->sensor);
     const int all_params = !(rp->flags & MI355_FLAG_EMITTER_GRADS_ONLY);
     mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
     int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1));
@@ -2089,6 +2134,7 @@ static void trace_lane(OScene *sc, const mi355_render_params *rp, uint32_t lane,
 }
 /* per-lane radiance for lanes [lane_begin, lane_begin+count): out = count x 4 (r,g,b,valid) */
 ORC_API void orc_lane_radiance(OScene *sc, const mi355_render_params *rp, uint32_t lane_begin, uint32_t count, float *out) {
+    orc_select_sensor(sc, rp->sensor);
     #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < (int64_t) count; ++i) {
         v3 rgb; int valid; v2 pos; Cnt c = { 0, 0, 0 };
@@ -2099,6 +2145,7 @@ ORC_API void orc_lane_radiance(OScene *sc, const mi355_render_params *rp, uint32
 /* SamplingIntegrator::render JIT branch (integrator.cpp:246-360): accumulate the shard's lanes
    into film_rgbw (H x W x 4, not cleared).  Returns the number of lanes traced. */
 ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp, float *film_rgbw, int n_threads) {
+    orc_select_sensor(sc, rp->sensor);
     uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
     size_t fsz = (size_t) sc->sensor.crop_width * sc->sensor.crop_height * 4;
 #ifdef _OPENMP
@@ -2171,6 +2218,7 @@ ORC_API int orc_param_layout(const OScene *sc, mi355_param_info *out, uint32_t c
 
 /* RBIntegrator.render_backward step 1a (common.py:741-758): W[p] = sum of filter weights */
 ORC_API void orc_prb_splat_weights(OScene *sc, const mi355_render_params *rp, float *weight_hw) {
+    orc_select_sensor(sc, rp->sensor);
     uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
     for (uint32_t q = 0; q < pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
         uint32_t lane = shard_pixel(rp, q) * rp->spp + s; pcg32 rng; sampler_seed(&rng, rp->seed, lane);
@@ -2195,6 +2243,7 @@ static v3 delta_L(const OScene *sc, v2 pos, const float *grad_in, const float *w
 /* RBIntegrator.render_backward steps 1b-3 (common.py:741-796); gradients are ACCUMULATED into grad */
 ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, const float *grad_in,
                                  const float *weight_hw, float *grad, int n_threads) {
+    orc_select_sensor(sc, rp->sensor);
     uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
     mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
     int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1)), *em_slot = (int32_t *) malloc(4 * (sc->n_emitters + 1));
@@ -2243,6 +2292,7 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
    with weight 1 into an RGBW accumulator whose develop() is the gradient image.  `tangent` = one float per differentiable scene
    float, laid out like the gradient buffer (orc_param_layout): what dr.set_grad() put on the parameters. */
 ORC_API uint64_t orc_render_forward(OScene *sc, const mi355_render_params *rp, const float *tangent, float *film_rgbw, int n_threads) {
+    orc_select_sensor(sc, rp->sensor);
     uint32_t p0, pn, s0, sn; shard_bounds(sc, rp, &p0, &pn, &s0, &sn);
     mi355_param_info layout[4096]; uint64_t total = 0; int np = orc_param_layout(sc, layout, 4096, &total);
     int32_t *bsdf_slot = (int32_t *) malloc(4 * (sc->n_bsdfs + 1)), *tex_slot = (int32_t *) malloc(4 * (sc->n_textures + 1)), *em_slot = (int32_t *) malloc(4 * (sc->n_emitters + 1));
@@ -2315,6 +2365,45 @@ ORC_API void orc_ray_intersect(OScene *sc, const float *rays, uint32_t n, float 
             o[16] = si.sh_s.x; o[17] = si.sh_s.y; o[18] = si.sh_s.z; o[19] = si.sh_t.x; o[20] = si.sh_t.y; o[21] = si.sh_t.z;
         }
     }
+}
+/* BasicPRBIntegrator.trace -- src/python/python/ad/integrators/prb_basic.py:46-140, the fork's geometric ray tracer (design_problem.py:183-203,
+   :415-417, :430-472).  Statement for statement: loop state (ray, penultimate_ray, depth, beta, active) :64-77; scene.ray_intersect :88;
+   active_next &= (depth + 1 < max_depth) & si.is_valid() :99; bsdf.sample(ctx, si, 1.0, (0, 0), active_next) :106-112 (sample1 = 1.0: "the
+   reflective path is never taken" unless the Fresnel reflectance is 1); penultimate_ray = ray :116; ray = si.spawn_ray(to_world(wo)) :119;
+   beta *= weight :120; active_next &= any(beta != 0) :123; depth[si.is_valid()] += 1 :126; active_next &= depth < num_lenses :129.
+   BSDFContext() is TransportMode::Radiance (the default), so the refracted weight carries eta_ti^2 -- only its being non-zero matters.
+   out: n x 12 = penultimate o3, d3, last si.p (0 when the last ray hit nothing), si.is_valid(), depth, 0 (mi355_trace_rays). */
+ORC_API void orc_trace(OScene *sc, const float *rays, uint32_t n, uint32_t num_lenses, int32_t max_depth_in, float *out) {
+    const uint32_t max_depth = (uint32_t) max_depth_in;
+    const int saved_mode = g_importance_mode; g_importance_mode = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray ray; ray.o = V3(rays[8*i], rays[8*i+1], rays[8*i+2]); ray.d = V3(rays[8*i+3], rays[8*i+4], rays[8*i+5]); ray.maxt = rays[8*i+6];
+        Ray pen = ray; uint32_t depth = 0; v3 beta = V3(1.f, 1.f, 1.f), p_last = V3(0.f, 0.f, 0.f); int active = 1, si_valid = 0;
+        while (active) {
+            PI pi = scene_intersect(sc, &ray);
+            int valid = pi.t != INFINITY;
+            int active_next = valid && (depth + 1u < max_depth);
+            pen = ray; si_valid = valid; p_last = V3(0.f, 0.f, 0.f);
+            if (valid) {
+                SI si = compute_si(sc, &ray, &pi);
+                p_last = si.p;
+                const mi355_bsdf_desc *bsdf = &sc->bsdfs[sc->shapes[si.shape].bsdf];
+                v3 refl = bsdf_reflectance(sc, bsdf, &si);
+                BSample bs; v3 w; v2 s2 = { 0.f, 0.f };
+                bsdf_sample(bsdf, refl, si.wi, 1.0f, s2, active_next, &bs, &w);
+                ray = spawn_ray(si.p, si.n, si_to_world(&si, bs.wo));
+                beta = mul3(beta, w);
+                active_next = active_next && (beta.x != 0.f || beta.y != 0.f || beta.z != 0.f);
+                depth += 1u;
+                active_next = active_next && depth < num_lenses;
+            }
+            active = active_next;
+        }
+        float *o = out + 12 * (size_t) i;
+        o[0] = pen.o.x; o[1] = pen.o.y; o[2] = pen.o.z; o[3] = pen.d.x; o[4] = pen.d.y; o[5] = pen.d.z;
+        o[6] = p_last.x; o[7] = p_last.y; o[8] = p_last.z; o[9] = si_valid ? 1.f : 0.f; o[10] = (float) depth; o[11] = 0.f;
+    }
+    g_importance_mode = saved_mode;
 }
 ORC_API void orc_primary_rays(OScene *sc, const float *sample_pos, uint32_t n, float *rays) {
     for (uint32_t i = 0; i < n; ++i) {

@@ -80,6 +80,11 @@ def lib(abi):
     l.orc_ptracer_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int]
     l.orc_radical_inverse.restype = C.c_float
     l.orc_radical_inverse.argtypes = [C.c_uint32, C.c_uint64]
+    l.orc_select_sensor.restype = C.c_int
+    l.orc_select_sensor.argtypes = [C.c_void_p, C.c_uint32]
+    l.orc_scene_set_sensor.restype = C.c_int
+    l.orc_scene_set_sensor.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.SensorDesc)]
+    l.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p]
     _lib = l
     return l
 
@@ -95,8 +100,30 @@ class OracleScene:
         self.h = self.l.orc_scene_create(C.byref(d))
         if not self.h:
             raise RuntimeError("oracle rejected the scene description")
-        f = scene.sensor.film
+        self.select_sensor(0)
+
+    def select_sensor(self, index):
+        """The `Sensor *` argument of Integrator::render: the film-shaped helpers below (render, develop, film_put, primary_rays ...) work on
+        this sensor; the render entry points pick theirs from mi355_render_params.sensor."""
+        assert self.l.orc_select_sensor(self.h, int(index)) == 0
+        f = self.scene.sensors()[int(index)].film
         self.W, self.H = f.crop_width, f.crop_height
+        self.sensor = int(index)
+
+    def set_sensor(self, index):
+        """Re-read sensor `index` from the host scene (after its to_world / x_fov / film changed)."""
+        d = self.scene.sensor_desc(int(index))
+        assert self.l.orc_scene_set_sensor(self.h, int(index), C.byref(d)) == 0
+        if getattr(self, "sensor", None) == int(index):
+            f = self.scene.sensors()[int(index)].film
+            self.W, self.H = f.crop_width, f.crop_height
+
+    def trace(self, rays, num_lenses, max_depth):
+        """BasicPRBIntegrator.trace (prb_basic.py:46-140) on caller rays (n x 8): n x 12, the layout of mi355_trace_rays."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.empty((rays.shape[0], 12), dtype=np.float32)
+        self.l.orc_trace(self.h, _p(rays), rays.shape[0], int(num_lenses), int(max_depth), _p(out))
+        return out
 
     def __del__(self):
         try:
@@ -105,8 +132,11 @@ class OracleScene:
         except Exception:
             pass
 
-    def params(self, integrator, seed, spp, shard=None, spp_shard=None):
-        return integrator._params(self.scene, seed, spp, shard=shard, spp_shard=spp_shard)
+    def params(self, integrator, seed, spp, shard=None, spp_shard=None, sensor=None):
+        s = self.sensor if sensor is None else int(sensor)
+        if s != self.sensor:
+            self.select_sensor(s)
+        return integrator._params(self.scene, seed, spp, shard=shard, spp_shard=spp_shard, sensor=s)
 
     def set_param(self, kind, index, values):
         v = np.ascontiguousarray(values, dtype=np.float32)

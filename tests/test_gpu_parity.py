@@ -635,7 +635,7 @@ def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
     params = mi.traverse(scene)
     lay, total = o.param_layout()
     v = rng.normal(size=total).astype(np.float32)
-    for key in params.keys():
+    for key in params._entries:
         kind, index, shape = params._entries[key]; off, size = params._slot(key)
         params.set_tangent(key, torch.tensor(v[off:off + size].reshape(shape)))
     gimg = integ.render_forward(scene, params, seed=5, spp=32).cpu().numpy()
@@ -659,7 +659,7 @@ def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
     assert (integ.render_forward(scene, params, seed=5, spp=8).cpu().numpy() == 0).all()
     if scene_name == "cbox-textured":       # finite differences of one wall colour with the roulette off: the estimator is polynomial in it
         integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 100})
-        key = [k for k in params.keys() if params._entries[k][0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
+        key = [k for k in params._entries if params._entries[k][0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
         t = torch.tensor([1.0, 0.5, -0.25], device="cuda")
         params.set_tangent(key, t)
         gimg = integ.render_forward(scene, params, seed=9, spp=256).cpu().numpy()
@@ -1002,7 +1002,7 @@ def test_particle_tracer_all_parameter_gradients(mi, orc, torch_cuda, scene_name
         gt = torch.tensor(gin, device="cuda").double()
         def loss():
             return float((integ.render(scene, seed=9, spp=64).double() * gt).sum())
-        key = [k for k in params.keys() if params._entries[k][0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
+        key = [k for k in params._entries if params._entries[k][0] == mi.abi.PARAM_BSDF_REFLECTANCE][0]
         kind, index, shape = params._entries[key]; off, size = params._layout[(kind, index)]
         base = params[key].clone(); eps = 1e-2
         for c in range(3):

@@ -35,7 +35,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi355_texture_desc), sizeof(mi355_bsdf_desc), sizeof(mi355_emitter_desc),
          sizeof(mi355_shape_desc), sizeof(mi355_sensor_desc), sizeof(mi355_scene_desc), sizeof(mi355_render_params),
          sizeof(mi355_counters), sizeof(mi355_param_info));
-  printf("%zu %zu %zu\n", offsetof(mi355_shape_desc, faces), offsetof(mi355_scene_desc, sensor), offsetof(mi355_sensor_desc, lens_data));
+  printf("%zu %zu %zu\n", offsetof(mi355_shape_desc, faces), offsetof(mi355_scene_desc, sensors), offsetof(mi355_sensor_desc, lens_data));
   return 0; }'''
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "t.c"), "w").write(src)
@@ -44,7 +44,7 @@ int main(void) {
     a = mi.abi
     sizes = [C.sizeof(x) for x in (a.TextureDesc, a.BsdfDesc, a.EmitterDesc, a.ShapeDesc, a.SensorDesc, a.SceneDesc, a.RenderParams, a.Counters, a.ParamInfo)]
     assert [int(x) for x in out[:9]] == sizes
-    assert [int(x) for x in out[9:]] == [a.ShapeDesc.faces.offset, a.SceneDesc.sensor.offset, a.SensorDesc.lens_data.offset]
+    assert [int(x) for x in out[9:]] == [a.ShapeDesc.faces.offset, a.SceneDesc.sensors.offset, a.SensorDesc.lens_data.offset]
 
 
 def test_no_gpu_means_loud_failure(mi):
@@ -241,7 +241,7 @@ def _worker(rank, world, port, out_dir, width=32, height=32, sample_border=False
         def device(self, scene): return torch.device("cpu")
         def accumulate(self, scene, p, film):
             film += torch.from_numpy((o.ptracer_render if p.integrator == mi.abi.INTEGRATOR_PTRACER else o.render)(p, threads=2, develop=False)[0])
-        def develop(self, scene, film, img): img.copy_(torch.from_numpy(o.develop(film.numpy())))
+        def develop(self, scene, film, img, sensor=0): img.copy_(torch.from_numpy(o.develop(film.numpy())))
         def splat_weights(self, scene, p, weight): weight += torch.from_numpy(o.splat_weights(p))
         def backward(self, scene, p, grad_in, weight, grads):
             if p.integrator == mi.abi.INTEGRATOR_PTRACER: grads += torch.from_numpy(o.ptracer_backward(p, grad_in.numpy(), threads=2))
