@@ -230,7 +230,7 @@ def main():
         if pending[b] is not None:
             pending[b].wait(); pending[b] = None                          # the compute stream waits for the collective (no host sync)
             if rank == 0:
-                mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(films[b].data_ptr()), C.c_void_p(img.data_ptr()), stream))
+                mi.abi.check(lib.mi355_film_develop(h, 0, C.c_void_p(films[b].data_ptr()), C.c_void_p(img.data_ptr()), stream))
 
     def step(seed):
         b = frame_no[0] % len(films); frame_no[0] += 1
@@ -240,7 +240,7 @@ def main():
         if world == 1:
             p = integ._params(scene, seed, args.spp)
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
-            mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
+            mi.abi.check(lib.mi355_film_develop(h, 0, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream))
         else:
             p = integ._params(scene, seed, args.spp, shard=my_shard)      # all of this rank's tiles in ONE launch
             mi.abi.check(lib.mi355_render_accumulate(h, C.byref(p), C.c_void_p(film.data_ptr()), stream))
@@ -309,7 +309,7 @@ def main():
         if dist is not None:
             lat["reduce_ms"] += timed_phase(lambda: dist.reduce(film, dst=0, op=dist.ReduceOp.SUM))
         if rank == 0:
-            lat["develop_ms"] += timed_phase(lambda: mi.abi.check(lib.mi355_film_develop(h, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream)))
+            lat["develop_ms"] += timed_phase(lambda: mi.abi.check(lib.mi355_film_develop(h, 0, C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), stream)))
         if dist is not None:
             dist.barrier()
     lat = {k: round(v / n_lat, 3) for k, v in lat.items()}
@@ -350,7 +350,7 @@ def main():
             tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
         fwd_ms = None
         if world == 1:                     # Integrator::render_forward on the same scene (timing only): tangent 1 on every parameter
-            for k_ in params.keys():
+            for k_ in params._entries:
                 params.set_tangent(k_, 1.0)
             prb_i.render_forward(scene3, params, seed=0, spp=args.prb_spp); torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -445,7 +445,11 @@ def main():
         mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
         t0 = time.perf_counter()
         system = ld.LensSystem([ld.EvenAsphericSurface(**sf) for sf in surfs], mats, subdiv_levels=args.lens_subdiv); system.disable_all_materials()
-        prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, init_camera_z=0.1, fov=100.0).prepare()
+        # cell 5 of the notebook: the rear surface constrained to a 50 mm focal length focused on the film; cell 7: three field sources
+        s1 = system.get_rear_surface_params(50.0)
+        system.elements[0].surface.params['c'] = float(s1['c']); system.elements[0].surface.params['z0'] = float(s1['z0']); system.compute_paraxial_quantities()
+        n_src = 3
+        prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, num_sources=n_src, max_field_angle=5.0, init_camera_z=0.1, fov=100.0).prepare()
         build_s = time.perf_counter() - t0
         scl, pl = prob.scene, prob.params
         lshard = (rank, world) if world > 1 else None
@@ -467,23 +471,34 @@ def main():
                 for key in (e.lens_key, e.baffle_key):
                     pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
             pl.update(); il.render(scl, seed=0, spp=1, shard=lshard)
-        r_ms, r_k = timed_l(lambda: il.render(scl, seed=0, spp=256, shard=lshard))
-        b_ms, b_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
-        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances
+        per_sensor = []
+        for sidx in range(n_src):                       # every field's camera: the iteration renders and differentiates all three
+            rs_ms, rs_k = timed_l(lambda: il.render(scl, sensor=sidx, seed=0, spp=256, shard=lshard))
+            bs_ms, bs_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=sidx, seed=1, spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
+            per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
+        r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)
+        b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
+        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances (sensor 0)
         c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False, shard=lshard))
         u_ms, _ = timed_l(upd)
-        losses = [prob.step(it) for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
-        t0 = time.perf_counter(); losses += [prob.step(it) for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
+        m_tw = np.ascontiguousarray(scl.sensors()[1].to_world.affine12(), dtype=np.float32)          # what moving a camera costs: host-side only
+        t0 = time.perf_counter()
+        for _ in range(200):
+            lib.mi355_scene_set_param(scl.handle(), mi.abi.PARAM_SENSOR_TO_WORLD, 1, m_tw.ctypes.data_as(mi.abi.f32p), 12)
+        edit_us = (time.perf_counter() - t0) / 200 * 1e6
+        losses = [prob.step(it)[0] for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
+        t0 = time.perf_counter(); losses += [prob.step(it)[0] for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
         info = scl.info()
         if dist is not None:                            # (host timers: the slowest rank's)
             tt = torch.tensor([r_ms, b_ms, a_ms, c_ms, u_ms, it_ms], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
-        lens = {"metric": "lens doublet (BASELINE configs[4]): ptracer 128^2, render @256 spp + render_backward @128 spp over all vertices and IORs",
+        lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
+                "sensors": per_sensor, "sensor_edit_us": round(edit_us, 2), "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
                 "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",
                 "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
                 "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
                 "render_backward_geometry_and_colour_ms": a_ms, "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
-                "light_paths_per_s_backward": round(128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
+                "light_paths_per_s_backward": round(n_src * 128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
         scl.release()
 
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------

@@ -292,13 +292,45 @@ MI_DEV bool tri_intersect(const DTri &tr, const Ray &ray, float &t, float &u, fl
     t = dot3(e2, qvec) * inv_det;
     return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= ray.maxt;
 }
+// Watertight ray / triangle test, used by the geometric tracer (k_trace) only.  Its callers aim rays EXACTLY at mesh vertices and along
+// mesh edges: a field's central ray goes to the entrance-pupil position, which is the pole vertex of the front lens mesh
+// (notebooks/scripts/lens_design/design_problem.py:152-153, :183-189), and the tracer check sends its rays in the symmetry plane y = 0 of
+// the icosphere (:442-453).  The reference intersects meshes through Embree / OptiX, which do not leak at shared edges; Moeller-Trumbore
+// (above, the formula of mesh.h:430-453 that the rendering kernels and the oracle's renderer use) does -- u and v are relative to each
+// triangle's own first vertex, so a ray on a shared edge can be marginally outside BOTH neighbours.  Pluecker edge functions (Embree's
+// PlueckerIntersector): f(P, Q) = dot(cross(P - Q, P + Q), d) with P, Q relative to the ray origin; the neighbour sees the edge as (Q, P)
+// and computes exactly -f (negation and commutation are exact, rounding is sign-symmetric), so a ray is inside at least one of the two.
+// The exact vertices are gathered from the mesh buffers (DTri holds rounded edge vectors); `slot` = traversal slot of the triangle.
+MI_DEV bool tri_intersect_watertight(const DScene &sc, uint32_t slot, const Ray &ray, float &t, float &u, float &v) {
+    const DShape &sh = sc.shapes[sc.tri_shape[slot]];
+    const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + sc.tri_face[slot]);
+    v3 v0 = ld3(sc.positions + 3 * (size_t) (sh.vtx_offset + fi[0])) - ray.o, v1 = ld3(sc.positions + 3 * (size_t) (sh.vtx_offset + fi[1])) - ray.o,
+       v2 = ld3(sc.positions + 3 * (size_t) (sh.vtx_offset + fi[2])) - ray.o;
+    v3 e0 = v2 - v0, e1 = v0 - v1, e2 = v1 - v2;
+    float U = dot3(cross3(e0, v2 + v0), ray.d), V = dot3(cross3(e1, v0 + v1), ray.d), W = dot3(cross3(e2, v1 + v2), ray.d);
+    float UVW = U + V + W, eps = MI_EPS * fabsf(UVW);
+    float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+    bool ok = (mn >= -eps || mx <= eps) && UVW != 0.f;
+    v3 ng = cross3(v1 - v0, v2 - v0);
+    float den = dot3(ng, ray.d);
+    t = dot3(v0, ng) / den;
+    float inv = 1.f / UVW;
+    u = fminf(fmaxf(U * inv, 0.f), 1.f); v = fminf(fmaxf(V * inv, 0.f), 1.f);
+    return ok && den != 0.f && t >= 0.f && t <= ray.maxt;
+}
+template <bool WT> MI_DEV bool tri_hit(const DScene &sc, uint32_t slot, const Ray &ray, float &t, float &u, float &v) {
+    if (WT) return tri_intersect_watertight(sc, slot, ray, t, u, v);
+    return tri_intersect(sc.tris[slot], ray, t, u, v);
+}
 // conservative slab test against a (wave-uniform) box; used only to SKIP work, never to decide a hit
 MI_DEV bool box_overlap(const float *lo, const float *hi, const Ray &ray, v3 inv_d) {
-    float t0x = (lo[0] - ray.o.x) * inv_d.x, t1x = (hi[0] - ray.o.x) * inv_d.x;
-    float t0y = (lo[1] - ray.o.y) * inv_d.y, t1y = (hi[1] - ray.o.y) * inv_d.y;
-    float t0z = (lo[2] - ray.o.z) * inv_d.z, t1z = (hi[2] - ray.o.z) * inv_d.z;
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), ray.maxt));
+    // entering / leaving planes by the sign of inv_d; a NaN plane distance (ray inside a face plane, zero direction component) sets no bound
+    const bool nx = __float_as_uint(inv_d.x) >> 31, ny = __float_as_uint(inv_d.y) >> 31, nz = __float_as_uint(inv_d.z) >> 31;
+    float t0x = ((nx ? hi[0] : lo[0]) - ray.o.x) * inv_d.x, t1x = ((nx ? lo[0] : hi[0]) - ray.o.x) * inv_d.x;
+    float t0y = ((ny ? hi[1] : lo[1]) - ray.o.y) * inv_d.y, t1y = ((ny ? lo[1] : hi[1]) - ray.o.y) * inv_d.y;
+    float t0z = ((nz ? hi[2] : lo[2]) - ray.o.z) * inv_d.z, t1z = ((nz ? lo[2] : hi[2]) - ray.o.z) * inv_d.z;
+    float tn = fmaxf(fmaxf(0.f, t0x), fmaxf(t0y, t0z));
+    float tf = fminf(fminf(ray.maxt, t1x), fminf(t1y, t1z));
     return tn <= tf * 1.00001f + 1e-6f;
 }
 
@@ -331,19 +363,29 @@ static __device__ unsigned long long g_bvh_stats[4];
 #endif
 struct Bvh4Hits { float tn[4]; uint32_t e[4]; };
 // slab test of the four children of `node`; a child that is missed (or empty) gets tn = +inf.  Conservative like box_overlap.
+// The entering plane of an axis is the box's low face when the ray runs up that axis and its high face otherwise, picked by the SIGN of
+// inv_d -- not by min / max of the two plane distances.  Two reasons: (i) a ray that lies exactly IN a face plane with a zero direction
+// component gives 0 * inf = NaN for that plane; v_max_f32 / v_min_f32 return the other operand (IEEE minNum / maxNum), so the NaN plane
+// simply sets no bound -- the ray is inside the closed slab for every t, which is the right answer -- whereas min(NaN, +inf) = +inf made
+// such a ray MISS the box.  The fork's own tracer check sends all its rays in the plane y = 0 (design_problem.py:442-453), a symmetry
+// plane of the icosphere lens meshes: edges, and therefore box faces, lie exactly in it.  (ii) it is two VALU instructions per child and
+// axis less.
 MI_DEV Bvh4Hits bvh4_node(const DScene &sc, uint32_t node, const Ray &ray, v3 inv_d, float tmax) {
     const float4 *n4 = reinterpret_cast<const float4 *>(sc.bvh + node);
     Bvh4Hits h;
     float tn[4] = { 0.f, 0.f, 0.f, 0.f }, tf[4] = { tmax, tmax, tmax, tmax };
-    {   const float4 lo = n4[0], hi = n4[3]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+    {   const bool neg = __float_as_uint(inv_d.x) >> 31; const float4 nr = n4[neg ? 3 : 0], fr = n4[neg ? 0 : 3];
+        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.x) * inv_d.x, b = (u[c] - ray.o.x) * inv_d.x; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
-    {   const float4 lo = n4[1], hi = n4[4]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.x) * inv_d.x); tf[c] = fminf(tf[c], (u[c] - ray.o.x) * inv_d.x); } }
+    {   const bool neg = __float_as_uint(inv_d.y) >> 31; const float4 nr = n4[neg ? 4 : 1], fr = n4[neg ? 1 : 4];
+        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.y) * inv_d.y, b = (u[c] - ray.o.y) * inv_d.y; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
-    {   const float4 lo = n4[2], hi = n4[5]; const float l[4] = { lo.x, lo.y, lo.z, lo.w }, u[4] = { hi.x, hi.y, hi.z, hi.w };
+        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.y) * inv_d.y); tf[c] = fminf(tf[c], (u[c] - ray.o.y) * inv_d.y); } }
+    {   const bool neg = __float_as_uint(inv_d.z) >> 31; const float4 nr = n4[neg ? 5 : 2], fr = n4[neg ? 2 : 5];
+        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float a = (l[c] - ray.o.z) * inv_d.z, b = (u[c] - ray.o.z) * inv_d.z; tn[c] = fmaxf(tn[c], fminf(a, b)); tf[c] = fminf(tf[c], fmaxf(a, b)); } }
+        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.z) * inv_d.z); tf[c] = fminf(tf[c], (u[c] - ray.o.z) * inv_d.z); } }
     const uint4 en = *reinterpret_cast<const uint4 *>(n4 + 6);
     h.e[0] = en.x; h.e[1] = en.y; h.e[2] = en.z; h.e[3] = en.w;
 #pragma unroll
@@ -373,6 +415,7 @@ MI_DEV void bvh4_sort(Bvh4Hits &h) {                                       // ne
 #define MI_BVH_QCULL 1                      // closest hit: keep a postponed leaf's entering distance and drop the leaf when a nearer hit was found meanwhile
 #endif
 #if MI_BVH_PHASED
+template <bool WT = false>
 MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
     int sp = 0, qh = 0, qt = 0;                                            // inner stack [0, sp) from the bottom; leaf FIFO [qh, qt) from the top
     uint32_t node = active ? 0u : MI_BVH_EMPTY, tri = 0u, left = 0u;
@@ -407,7 +450,7 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
                             BVH_STAT(2, count);
                             for (uint32_t k = 0; k < count; ++k) {
                                 float t, u, v;
-                                if (tri_intersect(sc.tris[first + k], ray, t, u, v) && t < hit.t) {
+                                if (tri_hit<WT>(sc, first + k, ray, t, u, v) && t < hit.t) {
                                     hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[first + k]; hit.shape = sc.tri_shape[first + k]; ray.maxt = t;
                                 }
                             }
@@ -432,7 +475,7 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
             if (left != 0u) {
                 float t, u, v;
                 BVH_STAT(2, 1);
-                if (tri_intersect(sc.tris[tri], ray, t, u, v) && t < hit.t) {
+                if (tri_hit<WT>(sc, tri, ray, t, u, v) && t < hit.t) {
                     hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[tri]; hit.shape = sc.tri_shape[tri]; ray.maxt = t;
                 }
                 tri++; left--;
@@ -491,6 +534,7 @@ MI_DEV bool bvh_any(const DScene &sc, const Ray &ray, v3 inv_d, bool active, uin
     return occluded;
 }
 #else
+template <bool WT = false>
 MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool active, uint32_t *stk) {
     int sp = 0; uint32_t node = 0u; bool have = active;
     if (active) BVH_STAT(0, 1);
@@ -509,7 +553,7 @@ MI_DEV void bvh_closest(const DScene &sc, Ray &ray, v3 inv_d, Hit &hit, bool act
                 BVH_STAT(2, count);
                 for (uint32_t k = 0; k < count; ++k) {
                     float t, u, v;
-                    if (tri_intersect(sc.tris[first + k], ray, t, u, v) && t < hit.t) {
+                    if (tri_hit<WT>(sc, first + k, ray, t, u, v) && t < hit.t) {
                         hit.t = t; hit.u = u; hit.v = v; hit.prim = sc.tri_face[first + k]; hit.shape = sc.tri_shape[first + k]; ray.maxt = t;
                     }
                 }
@@ -652,6 +696,24 @@ MI_DEV bool solve_quadratic(float a, float b, float c, float &x0, float &x1) {
     }
     return valid_linear || valid_quadratic;
 }
+// The same with IEEE division and square root, whatever MI_EXACT_MATH says: the aspherical lens interface accepts or rejects a ray by
+// |dz| < 10 eps after a Newton iteration that STARTS from this root -- a 1-ulp difference of the hardware v_rcp / v_sqrt flips that test for
+// a handful of rays, each of which adds or removes a whole path (round 2: asph_singlet gradient 3.6e-3 off; exact: 8.7e-4).  Lens-sensor
+// kernels only.
+MI_DEV bool solve_quadratic_ieee(float a, float b, float c, float &x0, float &x1) {
+    bool linear_case = a == 0.f, valid_linear = linear_case && b != 0.f;
+    x0 = x1 = -c / b;
+    float discrim = fmaf(b, b, -(4.f * a * c));
+    bool valid_quadratic = !linear_case && discrim >= 0.f;
+    if (valid_quadratic) {
+        float sqrt_discrim = sqrtf(discrim);
+        float temp = -0.5f * (b + copysignf(sqrt_discrim, b));
+        float x0p = temp / a, x1p = c / temp;
+        x0 = fminf(x0p, x1p); x1 = fmaxf(x0p, x1p);
+    }
+    return valid_linear || valid_quadratic;
+}
+MI_DEV v3 normalize3_ieee(v3 a) { return a * (1.0f / sqrtf(sqnorm3(a))); }
 // Sphere::ray_intersect_preliminary_impl, src/shapes/sphere.cpp:491-563 (closest) and ray_test_impl :565-601 (any)
 template <typename P>
 MI_DEV bool sphere_intersect(P sp, const Ray &ray, float tlim, float &t) {
@@ -673,7 +735,7 @@ MI_DEV bool sphere_intersect(P sp, const Ray &ray, float tlim, float &t) {
 #define MI_BOX_FLAG 0x40000000u
 #define MI_SPHERE_FLAG 0x20000000u
 // Scene::ray_intersect_preliminary (scene.cpp:192-199): closest hit over all shapes.
-template <int FULL>
+template <int FULL, bool WT = false>
 MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk) {
     Hit hit; hit.t = MI_INF; hit.u = hit.v = 0.f; hit.prim = 0; hit.shape = 0xffffffffu;
     float tlim = active ? excl_limit(ray.maxt) : 0.f;
@@ -748,7 +810,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
     }
     if (FULL == 1 && sc.n_bvh_shapes) {                                          // (a scene with BVH meshes runs the FULL kernels: features bit 3)
         v3 inv_d = V3(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
-        bvh_closest(sc, ray, inv_d, hit, active, stk);
+        bvh_closest<WT>(sc, ray, inv_d, hit, active, stk);
     }
     return hit;
 }
@@ -1284,13 +1346,13 @@ MI_DEV v3 asph_normal(const float *L, v3 p) {
     float inv = 1.f / L[2], rx = p.x * inv, ry = p.y * inv, r2_ = rx * rx + ry * ry;
     if (r2_ >= 4.f * MI_EPS) { float s = 1.f / sqrtf(r2_); rx *= s; ry *= s; } else { rx = 0.f; ry = 0.f; }
     float zg = asph_grad_(L, r2_);
-    return normalize3(V3(zg * rx, zg * ry, -1.f));
+    return normalize3_ieee(V3(zg * rx, zg * ry, -1.f));
 }
 MI_DEV bool asph_conic_hit(const float *L, v3 o, v3 d, float &t_out) {
     float R = L[2], c = L[7], K = L[6], z0 = L[3];
     v3 on = (o - V3(0.f, 0.f, z0)) * (1.f / R);
     float A = c * (1.f + K * (d.z * d.z)), B = 2.f * (c * (dot3(on, d) + K * on.z * d.z) - d.z), C = c * (dot3(on, on) + K * (on.z * on.z)) - 2.f * on.z;
-    float t0, t1; if (!solve_quadratic(A, B, C, t0, t1)) return false;
+    float t0, t1; if (!solve_quadratic_ieee(A, B, C, t0, t1)) return false;
     t0 *= R; t1 *= R;
     float z0t = c * (o.z + t0 * d.z - z0), z1t = c * (o.z + t1 * d.z - z0), lim = K > -1.f ? R * (1.f / (1.f + K)) : MI_INF;
     bool v0 = z0t > 0.f && z0t <= lim, v1 = z1t > 0.f && z1t <= lim;
@@ -1324,7 +1386,7 @@ MI_DEV bool lens_interact(const float *L, v3 &o, v3 &d) {
         v3 center = V3(0.f, 0.f, z + R);
         v3 pc = center - o;
         float center_proj = dot3(pc, d);
-        float perp = norm3(pc - d * center_proj);
+        float perp = sqrtf(sqnorm3(pc - d * center_proj));                  // (IEEE throughout the lens: see solve_quadratic_ieee)
         float disc = R * R - perp * perp;
         if (!(disc >= 0.f)) return false;
         float sq = sqrtf(disc), near_t = center_proj - sq, far_t = center_proj + sq;
@@ -1333,7 +1395,7 @@ MI_DEV bool lens_interact(const float *L, v3 &o, v3 &d) {
         t = (convex != (d.z < 0.f)) ? (near_t >= 0.f ? near_t : MI_INF) : far_t;
         if (!(t != MI_INF)) return false;
         p = fma3s(d, t, o);
-        n = normalize3(p - center); if (!convex) n = -n;
+        n = normalize3_ieee(p - center); if (!convex) n = -n;
     } else {
         n = V3(0.f, 0.f, -1.f);
         float n_dot_d = dot3(n, d);
@@ -1374,12 +1436,12 @@ MI_DEV float sample_lens_ray(const DScene &sc, float pos_x, float pos_y, float a
         pupil_p = V3(cos_t * ppx - sin_t * ppy, sin_t * ppx + cos_t * ppy, sc.lens[3]);
     }
     v3 aperture_p = sc.sample_exit_pupil ? pupil_p : V3(sc.lens[2] * dkx, sc.lens[2] * dky, sc.lens[3]);   // sample_rear_element, :1870-1878
-    v3 o = film_p, d = normalize3(aperture_p - film_p);
+    v3 o = film_p, d = normalize3_ieee(aperture_p - film_p);
     bool active = true;
     for (uint32_t i = 0; i < sc.lens_count; ++i) { v3 o2 = o, d2 = d; bool ok = lens_interact(sc.lens + MI_LENS_ROW * i, o2, d2); if (active && ok) { o = o2; d = d2; } active = active && ok; }
     const float *tw = sc.cam_to_world;
     ray.o = xf_point(tw, o); ray.d = xf_vector(tw, d);
-    float inv_z = rcp_(d.z), near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;
+    float inv_z = 1.f / d.z, near_t = sc.near_clip * inv_z, far_t = sc.far_clip * inv_z;
     ray.o = ray.o + ray.d * near_t; ray.maxt = far_t - near_t;
     float c2 = d.z * d.z;
     if (sc.sample_exit_pupil)                                               // :2282-2285
@@ -2073,7 +2135,7 @@ MI_DEV bool lens_sample_direction(const DScene &sc, v3 ref_p, float sx_, float s
     const float *Lf = sc.lens + MI_LENS_ROW * (sc.lens_count - 1u);
     float dkx, dky; disk_concentric(sx_, sy_, dkx, dky);
     v3 aperture_p = V3(dkx * Lf[2], dky * Lf[2], Lf[3]);
-    v3 dir = ref_p - aperture_p; float dist_ref = norm3(dir), inv_dist_ref = 1.f / dist_ref;
+    v3 dir = ref_p - aperture_p; float dist_ref = sqrtf(sqnorm3(dir)), inv_dist_ref = 1.f / dist_ref;
     dir = dir * inv_dist_ref;
     v3 o = ref_p, d = -dir;
     bool ok = true;

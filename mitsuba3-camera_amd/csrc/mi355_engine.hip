@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float *rays, u
     uint32_t depth = 0; v3 beta = V3(1.f, 1.f, 1.f), p_last = V3(0.f, 0.f, 0.f);
     bool active = act, si_valid = false;
     while (__any(active)) {                                                 // every live lane gains a surface or stops: at most num_lenses trips
-        Hit hit = scene_intersect<true>(sc, ray, active, stk);
+        Hit hit = scene_intersect<true, true>(sc, ray, active, stk);         // watertight triangle test: see tri_intersect_watertight
         if (active) {
             const bool valid = hit.t != MI_INF;
             bool active_next = valid && (depth + 1u < max_depth);           // :99
@@ -2262,7 +2262,8 @@ static int reinit_sensor(mi355_scene *s, uint32_t index, const mi355_sensor_desc
     std::vector<float> lens_copy;                                           // (the description may point into the slot it replaces)
     if (nd.type == MI355_SENSOR_REALISTICLENS && nd.lens_data && nd.lens_count && nd.lens_count <= 64) { lens_copy.assign(nd.lens_data, nd.lens_data + MI_LENS_ROW * (size_t) nd.lens_count); nd.lens_data = lens_copy.data(); }
     int rc = validate_sensor(nd); if (rc) return rc;                         // a refused update leaves the sensor as it was
-    HIP_TRY(hipSetDevice(s->device));
+    const bool device_work = nd.type == MI355_SENSOR_REALISTICLENS || (index < s->sensors.size() && (s->sensors[index].d_lens || s->sensors[index].d_pupil));
+    if (device_work) HIP_TRY(hipSetDevice(s->device));                      // (a perspective camera is host-side state only: no runtime call at all)
     if (index == s->sensors.size()) s->sensors.emplace_back();
     if ((rc = init_sensor_slot(s, s->sensors[index], nd))) return rc;
     if (s->cur_sensor == index) s->cur_sensor = 0xffffffffu;                // re-select on the next call

@@ -497,6 +497,7 @@ class SceneParameters:
         self._comp = {}        # key -> component of a shared engine parameter: 0 / 1 = int_ior / ext_ior of MI355_PARAM_BSDF_IOR, None = no engine slot (V_d)
         self._values = {}
         self._dirty = set()
+        self._pushed = {}      # key -> (tensor object, its in-place version) of the last upload
         self._grads = None
         self._tangents = None
         scene.handle()
@@ -661,6 +662,14 @@ class SceneParameters:
     def _push(self, key, tensor):
         """Upload one parameter to the device replica and keep the host description coherent."""
         kind, index, _ = self._entries[key]
+        # The same tensor object at the same in-place version was pushed last time: nothing to do.  (mi.render pushes its differentiable
+        # parameters at every call -- their tensors may have been edited in place -- and a design iteration renders once per sensor:
+        # without this the six lens meshes would be uploaded and the BVH refitted three times per iteration.)  The reference is kept so
+        # that the identity test cannot be fooled by a recycled object.
+        last = self._pushed.get(key)
+        if last is not None and last[0] is tensor and last[1] == tensor._version:
+            return
+        self._pushed[key] = (tensor, tensor._version)
         v = tensor.detach().to(torch_float32()).contiguous()
         if kind == abi.PARAM_BSDF_IOR:                 # two keys (or four, `dispersive`) share the engine's (int_ior, ext_ior) pair
             b = self.scene.bsdfs[index]; name = key.rsplit(".", 1)[1]; val = float(v.reshape(-1)[0].item())
@@ -678,6 +687,8 @@ class SceneParameters:
                                                           _stream_ptr(v.device)))
         if kind == abi.PARAM_VERTEX_POSITIONS:         # Mesh::parameters_changed: the engine refits and recomputes the normals; the host copy follows lazily
             sh = self.scene.shapes[index]
+            if v.data_ptr() == tensor.data_ptr():      # keep what was PUSHED: an in-place edit of the caller's tensor must not leak into the host mirror
+                v = v.clone()
             sh._positions_device = v; sh._normals_stale = sh._vn is not None      # (no download here: the host copies catch up when somebody reads them)
             return
         host = v.cpu().numpy()

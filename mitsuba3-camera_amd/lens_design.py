@@ -4,9 +4,14 @@
   notebooks/scripts/lens_design/lens.py       ConicSurface :55-97, EvenAsphericSurface :166-249, LensMaterial :252-339,
                                               LensElement :343-581 (add_to_scene :418-470, add_to_optimizer :473-498, update :509-568),
                                               LensSystem :752-808
-  notebooks/scripts/lens_design/design_problem.py   FieldSource :12-279 (directionalarea disk source + perspective sensor),
-                                              DesignProblem :283-584 (prepare :481-492, optimize :495-584)
-  notebooks/scripts/lens_design/losses.py     rms_loss :8-29
+  notebooks/scripts/lens_design/design_problem.py   FieldSource :12-279 (directionalarea disk source + perspective sensor per field angle,
+                                              createSourceArray :142-181, get_sensor_dict :192-247, center_camera_on_pixel :258-265,
+                                              upsample_sensor :135-140, update :86-132),
+                                              DesignProblem :283-584 (_build_scene :403-428 with the `prb_basic` geometric tracer,
+                                              __test_geo_tracer :430-472, prepare :481-492, optimize :495-584)
+  notebooks/scripts/lens_design/lens.py       LensSystem.compute_paraxial_quantities :810-880, compute_pupils :956-968, compute_BFL / FFL / EFL
+                                              :932-954, get_rear_surface_params :970-997, abbe_to_cauchy :1251-1255, ApertureElement :585-744
+  notebooks/scripts/lens_design/losses.py     rms_loss :8-29, rms_loss_and_center :31-41
 
 What the notebook does per iteration, and what runs where here:
   lens scalars (c, K, z0, a4..a16 per surface; ior / V_d per glass)           torch leaf tensors held by mi.Adam
@@ -18,7 +23,8 @@ What the notebook does per iteration, and what runs where here:
     -> optimizer.step()
 Dr.Jit arrays become torch tensors; units are millimetres, the film is the plane z = 0 and +z faces the world, as in the fork.
 The icosphere / boundary-loop helpers of `gpytoolbox` (absent here) are restated below; vertex numbering differs from that
-library's, nothing depends on it.  One field source (on axis) per scene: this build's Scene holds one sensor.
+library's, nothing depends on it.  `num_sources` field sources per scene, each with its own sensor; a render names its sensor
+(mi.render(..., sensor=i), design_problem.py:519-526) and the device replica is shared by all of them.
 """
 import math
 import numpy as np
@@ -216,6 +222,10 @@ class LensMaterial:
     def remove_all_optvars(self):
         self.active_optvars = []
 
+    def remove_optvar(self, param_name):
+        if param_name in self.active_optvars:
+            self.active_optvars.remove(param_name)
+
     def add_to_optimizer(self, optimizer, device):
         torch = _torch()
         if self.name == "air":
@@ -247,6 +257,17 @@ class LensElement:
         self.param_keys_to_opt_keys = None
         self.is_world_facing = is_world_facing
         self.active_optvars = list(self.surface.params.keys())
+        self._pushed_materials = {}
+
+    def remove_optvar(self, param_name):
+        if param_name in self.active_optvars:
+            self.active_optvars.remove(param_name)
+
+    def remove_optvars(self, names):
+        self.active_optvars = [v for v in self.active_optvars if v not in names]
+
+    def remove_all_optvars(self):
+        self.active_optvars = []
 
     def initialize_geometry(self):
         """lens.py:373-401 without the PLY round trip: the buffers go to the scene as a `mesh` with computed vertex normals, which is what
@@ -292,17 +313,25 @@ class LensElement:
         self.initial_lens_vertices = params['%s.vertex_positions' % self.lens_key].detach().reshape(-1, 3).clone()
         self.initial_baffle_vertices = params['%s.vertex_positions' % self.baffle_key].detach().reshape(-1, 3).clone()
 
-    def update(self, params, optimizer):
-        """lens.py:509-568: the materials' values into the interface BSDF, the optimised surface scalars into the mesh vertices."""
+    def update(self, params, optimizer, ext_params=None):
+        """lens.py:509-568: the materials' values into the interface BSDF, the optimised surface scalars into the mesh vertices.
+        `ext_params`: shape parameters set directly (the constrained rear surface, lens.py:540-543).  A material that is not optimised keeps
+        plain floats: assigning an unchanged float marks nothing dirty, so a constant glass costs no upload per iteration."""
         torch = _torch()
-        params['%s.bsdf.int_ior_d' % self.lens_key] = _as1(self.int_material.params['ior'], self.initial_lens_vertices)
-        params['%s.bsdf.int_V_d' % self.lens_key] = _as1(self.int_material.params['V_d'], self.initial_lens_vertices)
-        params['%s.bsdf.ext_ior_d' % self.lens_key] = _as1(self.ext_material.params['ior'], self.initial_lens_vertices)
-        params['%s.bsdf.ext_V_d' % self.lens_key] = _as1(self.ext_material.params['V_d'], self.initial_lens_vertices)
+        for comp, mat in (("int", self.int_material), ("ext", self.ext_material)):
+            for short, name in (("ior", "ior_d"), ("V_d", "V_d")):
+                key = '%s.bsdf.%s_%s' % (self.lens_key, comp, name); v = mat.params[short]
+                if torch.is_tensor(v):
+                    params[key] = _as1(v, self.initial_lens_vertices)
+                elif self._pushed_materials.get(key) != float(v):
+                    params[key] = _as1(v, self.initial_lens_vertices); self._pushed_materials[key] = float(v)
         if self.param_keys_to_opt_keys is None:
             return
         for var_key, opt_key in self.param_keys_to_opt_keys.items():
             self.surface.params[var_key] = optimizer[opt_key]
+        if ext_params is not None:
+            for k, v in ext_params.items():
+                self.surface.params[k] = v
         x0, y0 = self.initial_lens_vertices[:, 0], self.initial_lens_vertices[:, 1]
         new_pos = torch.stack([x0, y0, self.surface.compute_z(x0, y0)], dim=1)
         params['%s.vertex_positions' % self.lens_key] = new_pos.reshape(-1)
@@ -319,32 +348,197 @@ def _as1(v, like):
     return torch.tensor([float(v)], dtype=torch.float32, device=like.device)
 
 
+class ApertureElement:
+    """lens.py:585-744: an aperture stop -- no refracting surface, only the black baffle frame around the opening."""
+
+    def __init__(self, element_id, surface, N=5, is_world_facing=True):
+        self.subdiv_level = N; self.id = element_id; self.surface = surface
+        self.param_keys_to_opt_keys = None; self.is_world_facing = is_world_facing
+        self.active_optvars = list(self.surface.params.keys())
+
+    def initialize_geometry(self):
+        _, _, V_ap, F_ap, _ = create_surface_geometry(N=self.subdiv_level, r_element=self.surface.radial_extent, compute_z=self.surface.compute_z_np, c=0.0,
+                                                      flip_normals=not self.is_world_facing, baffle_radius=1.1 * self.surface.radial_extent)
+        self.V_ap, self.F_ap = V_ap, F_ap
+
+    def add_to_scene(self, scene_dict):
+        self.ap_key = "lens%d_AP" % self.id
+        if 'black-bsdf' not in scene_dict:
+            scene_dict['black-bsdf'] = {'type': 'diffuse', 'reflectance': 0.0}
+        if self.ap_key in scene_dict:
+            raise KeyError("Aperture `%s` already exists in scene!" % self.ap_key)
+        scene_dict[self.ap_key] = {'type': 'mesh', 'vertex_positions': self.V_ap.astype(np.float32), 'faces': self.F_ap.astype(np.uint32),
+                                   'compute_vertex_normals': True, 'bsdf': {'type': 'ref', 'id': 'black-bsdf'}}
+
+    def add_to_optimizer(self, optimizer, device):
+        torch = _torch()
+        self.param_keys_to_opt_keys = self.param_keys_to_opt_keys or {}
+        for var_name, value in self.surface.params.items():
+            if var_name not in self.active_optvars:
+                continue
+            key = 'ap%d_%s' % (self.id, var_name)
+            if key in optimizer:
+                raise KeyError("Variable %s already exists in optimizer!" % key)
+            optimizer[key] = torch.tensor([float(value)], dtype=torch.float32, device=device)
+            self.param_keys_to_opt_keys[var_name] = key
+
+    def save_init_state(self, params):
+        self.initial_ap_vertices = params['%s.vertex_positions' % self.ap_key].detach().reshape(-1, 3).clone()
+
+    def update(self, params, optimizer, ext_params=None):
+        torch = _torch()
+        if self.param_keys_to_opt_keys is None:
+            return
+        x0 = self.initial_ap_vertices
+        rim = self.surface.compute_z(torch.full((1,), self.surface.radial_extent, device=x0.device), torch.zeros(1, device=x0.device))
+        params['%s.vertex_positions' % self.ap_key] = torch.stack([x0[:, 0], x0[:, 1], rim.expand(x0.shape[0])], dim=1).reshape(-1)
+
+    def remove_optvar(self, param_name):
+        if param_name in self.active_optvars:
+            self.active_optvars.remove(param_name)
+
+    def remove_all_optvars(self):
+        self.active_optvars = []
+
+
+def _f(v):
+    """A lens scalar as a Python float (optimised scalars are 1-element tensors)."""
+    return float(v.detach().reshape(-1)[0]) if _torch().is_tensor(v) else float(v)
+
+
+def abbe_to_cauchy(nd, Vd, lbdas=(0.5893, 0.48613, 0.65627)):
+    """lens.py:1251-1255: Cauchy coefficients (A, B) of n(lambda) = A + B / lambda^2 from the index at the d line and the Abbe number."""
+    lbda_D, lbda_F, lbda_C = lbdas
+    B = (nd - 1) / (Vd * (lbda_F ** -2 - lbda_C ** -2))
+    A = nd - B * lbda_D ** -2
+    return A, B
+
+
 class LensSystem:
-    """lens.py:752-808: surfaces ordered from the film towards the world; materials[i] lies between surface i and i + 1, air outside."""
+    """lens.py:752-1255: surfaces ordered from the film towards the world; materials[i] lies between surface i and i + 1, air outside.
+    Carries the paraxial ray-transfer matrices of the system (compute_paraxial_quantities), which the design problem uses to place its
+    sources (entrance pupil) and to check the geometric tracer."""
     SUBDIV_LEVELS = 7
 
-    def __init__(self, surfaces, materials, subdiv_levels=None):
+    def __init__(self, surfaces, materials, aperture_index=None, subdiv_levels=None):
         if len(materials) != len(surfaces) - 1:
             raise AssertionError("Material and surface lists do not match: len(materials)=%d, len(surfaces)=%d" % (len(materials), len(surfaces)))
+        if aperture_index is None or aperture_index < 0:
+            self.has_aperture = False; aperture_index = len(surfaces) - 1
+        else:
+            self.has_aperture = True
         materials = [LensMaterial()] + list(materials)
         n_mat = len(materials)
         N = self.SUBDIV_LEVELS if subdiv_levels is None else subdiv_levels
-        self.elements = [LensElement(N=N, element_id=i, surface=surfaces[i], ext_material=materials[i], int_material=materials[(i + 1) % n_mat],
-                                     is_world_facing=False) for i in range(len(surfaces))]
+        self.elements = []
+        for i in range(len(surfaces)):
+            if self.has_aperture and i == aperture_index:
+                self.elements.append(ApertureElement(N=N, element_id=len(self.elements), surface=surfaces[i], is_world_facing=False))
+            else:
+                self.elements.append(LensElement(N=N, element_id=len(self.elements), surface=surfaces[i], ext_material=materials[i], int_material=materials[(i + 1) % n_mat],
+                                                 is_world_facing=False))
         self.materials = materials
-        self.rear_z = float(surfaces[0].params['z0']); self.front_z = float(surfaces[-1].params['z0'])
+        self.rear_z = _f(surfaces[0].params['z0']); self.front_z = _f(surfaces[-1].params['z0'])
         self.front_radial_extent = surfaces[-1].radial_extent
+        self.aperture_index = aperture_index
+        self.compute_paraxial_quantities()
+
+    # ---- paraxial optics (2 x 2 ray-transfer matrices acting on (y, u); float64 on the host) ------------------------------------------
+    def _element_matrices(self, idx):
+        """lens.py:821-840: refraction at surface idx (film-side medium -> world-side medium) after the transit from the previous one."""
+        n_mat = len(self.materials)
+        z_prev = 0.0 if idx == 0 else _f(self.elements[idx - 1].surface.params['z0'])
+        thickness = _f(self.elements[idx].surface.params['z0']) - z_prev
+        curvature = -self.elements[idx].surface.get_curvature()
+        ior_i = _f(self.materials[idx].params['ior']); ior_f = _f(self.materials[(idx + 1) % n_mat].params['ior'])
+        lens_matrix = np.array([[1.0, 0.0], [-(ior_f - ior_i) * curvature / ior_f, ior_i / ior_f]])
+        transit_matrix = np.array([[1.0, thickness], [0.0, 1.0]])
+        return lens_matrix, transit_matrix
+
+    def compute_paraxial_quantities(self):
+        """lens.py:810-880"""
+        M_film2front = np.eye(2); M_rear2front = np.eye(2); M_film2ap = np.eye(2); M_ap2front = np.eye(2)
+        for idx in range(len(self.elements)):
+            lens_matrix, transit_matrix = self._element_matrices(idx)
+            elem = lens_matrix @ transit_matrix
+            M_film2front = elem @ M_film2front
+            if idx < self.aperture_index:
+                M_film2ap = elem @ M_film2ap
+            elif idx == self.aperture_index:
+                M_film2ap = transit_matrix @ M_film2ap; M_ap2front = lens_matrix @ M_ap2front
+            else:
+                M_ap2front = elem @ M_ap2front
+            M_rear2front = (lens_matrix if idx == 0 else elem) @ M_rear2front
+        self.ray_matrix_film2front = M_film2front
+        self.ray_matrix_front2film = np.linalg.inv(M_film2front)
+        self.ray_matrix_rear2front = M_rear2front
+        self.pupil_rear_matrix = M_film2ap; self.pupil_front_matrix = M_ap2front
+        self.exit_pupil_position, self.entrance_pupil_position, self.exit_pupil_radius, self.entrance_pupil_radius = self.compute_pupils()
+
+    def get_EFL_paraxial_matrix(self):
+        """lens.py:884-912: the system without its rear surface (and without the transit in front of surface 1)."""
+        M = np.eye(2)
+        for idx in range(1, len(self.elements)):
+            lens_matrix, transit_matrix = self._element_matrices(idx)
+            M = (lens_matrix if idx == 1 else lens_matrix @ transit_matrix) @ M
+        return M
+
+    def trace_paraxial_film2front(self, ray):
+        """(y, u) from the film plane z = 0 to the last interface; `ray` = 2 x n array or a pair (lens.py:915-921)."""
+        return self.ray_matrix_film2front @ np.asarray(ray, dtype=np.float64)
+
+    def trace_paraxial_front2film(self, ray):
+        """(y, u) from the last interface (z = front_z) back onto the film plane; the ray is oriented film -> world (lens.py:923-929)."""
+        return self.ray_matrix_front2film @ np.asarray(ray, dtype=np.float64)
+
+    def compute_BFL(self):
+        return -self.ray_matrix_rear2front[1, 1] / self.ray_matrix_rear2front[1, 0]
+
+    def compute_FFL(self):
+        return -self.ray_matrix_rear2front[0, 0] / self.ray_matrix_rear2front[1, 0]
+
+    def compute_EFL(self):
+        return -1.0 / self.ray_matrix_rear2front[1, 0]
+
+    def compute_pupils(self):
+        """lens.py:956-968: paraxial exit / entrance pupil positions and radii."""
+        z_exit = self.pupil_rear_matrix[0, 1] / self.pupil_rear_matrix[0, 0]
+        z_entrance = _f(self.elements[-1].surface.params['z0']) - self.pupil_front_matrix[0, 1] / self.pupil_front_matrix[1, 1]
+        ap_radius = self.elements[self.aperture_index].surface.radial_extent
+        return z_exit, z_entrance, ap_radius / self.pupil_rear_matrix[0, 0], ap_radius / self.pupil_front_matrix[1, 1]
+
+    def get_rear_surface_params(self, f):
+        """lens.py:970-997: curvature (dimensionless) and axial position of the rear surface that give the system the focal length `f`
+        and put its paraxial focus on the film plane."""
+        Mk = self.get_EFL_paraxial_matrix()
+        C, D = Mk[1, 0], Mk[1, 1]
+        k = _f(self.materials[0].params['ior']) / _f(self.materials[1].params['ior'])
+        z2 = _f(self.elements[1].surface.params['z0'])
+        surf_z0 = f * k * (C * z2 + D) / (1.0 + f * k * C)
+        surf_c = -(1.0 / f + C) / ((C * (z2 - surf_z0) + D) * (1 - k))
+        return {'c': surf_c * self.elements[0].surface.radial_extent, 'z0': surf_z0}
 
     def size(self):
-        return len(self.elements)
+        return len(self.elements) - 1 if self.has_aperture else len(self.elements)
 
     def initialize_geometry(self):
         for e in self.elements:
             e.initialize_geometry()
 
-    def add_to_scene(self, scene_dict):
+    def add_to_scene(self, scene_dict, housing=True):
+        """lens.py:1065-1095: the elements, and four black walls around them (`camera_housing_i`: the unit square mesh under
+        scale(rmax, -rmax, zmax / 2) . look_at(origin = z + o, target = z, up = z))."""
+        rmax = 0.0
         for e in self.elements:
-            e.add_to_scene(scene_dict)
+            e.add_to_scene(scene_dict); rmax = max(rmax, e.surface.radial_extent)
+        if not housing:
+            return
+        T = ScalarTransform4f
+        zmax = self.front_z * 1.1; rmax = rmax * 1.1
+        z = np.array([0.0, 0.0, 1.0])
+        for i, origin in enumerate(([1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0])):
+            tw = T.scale([rmax, -rmax, zmax / 2]) @ T.look_at(origin=(z + np.array(origin, dtype=np.float64)).tolist(), target=z.tolist(), up=[0, 0, 1])
+            scene_dict['camera_housing_%d' % i] = dict(unit_square_mesh(), to_world=tw, bsdf={'type': 'ref', 'id': 'black-bsdf'})
 
     def add_to_optimizer(self, optimizer, device):
         for m in self.materials:
@@ -356,23 +550,80 @@ class LensSystem:
         for e in self.elements:
             e.save_init_state(params)
 
+    def disable_all_surfaces(self):
+        for e in self.elements:
+            e.remove_all_optvars()
+
     def disable_all_materials(self):
         for m in self.materials:
             m.remove_all_optvars()
 
+    def disable_surface_at_index(self, index): self.elements[index].remove_all_optvars()
+    def disable_material_at_index(self, index): self.materials[index].remove_all_optvars()
+
+    def disable_surface_vars(self, param_name):
+        for e in self.elements:
+            e.remove_optvar(param_name)
+
+    def disable_material_vars(self, param_name):
+        for m in self.materials:
+            m.remove_optvar(param_name)
+
+    def disable_var_in_surface(self, param_name, index): self.elements[index].remove_optvar(param_name)
+    def disable_var_in_material(self, param_name, index): self.materials[index].remove_optvar(param_name)
+
     def update(self, params, optimizer):
-        """Materials first, then the elements (lens.py:516-517 "materials update *must* be performed before LensElement update")."""
+        """Materials first, then the elements (lens.py:516-517 "materials update *must* be performed before LensElement update"), then the
+        paraxial matrices and the scene (lens.py:1009-1021)."""
         for m in self.materials:
             m.update(optimizer)
         for e in self.elements:
             e.update(params, optimizer)
+        self.compute_paraxial_quantities()
+        params.update()
+
+    def fixed_EFL_update(self, params, optimizer, efl):
+        """lens.py:1023-1042: as update(), with the rear surface's c and z0 dictated by the focal-length constraint."""
+        for m in self.materials:
+            m.update(optimizer)
+        if efl is not None:
+            for e in self.elements[1:]:
+                e.update(params, optimizer)
+            self.elements[0].update(params, optimizer, self.get_rear_surface_params(efl))
+        else:
+            for e in self.elements:
+                e.update(params, optimizer)
+        self.compute_paraxial_quantities()
+        params.update()
+
+    def describe(self):
+        """What LensSystem.print() shows (lens.py:1225-1248): Cauchy pairs of the materials world -> film, then curvature radii, thicknesses
+        and extents world -> film."""
+        mats = []
+        for m in reversed(self.materials):
+            mats.append((1.000277, 0.0) if m.name == "air" else tuple(float(x) for x in abbe_to_cauchy(_f(m.params['ior']), _f(m.params['V_d']))))
+        curv = [e.surface.get_curvature() for e in self.elements]
+        r_c = [1.0 / c if c != 0.0 else float("inf") for c in curv]
+        z0s = [0.0] + [_f(e.surface.get_z0()) for e in self.elements]
+        t = [z0s[i + 1] - z0s[i] for i in range(len(self.elements))]
+        return {"materials": mats, "r_c": r_c[::-1], "t": t[::-1], "r_e": [e.surface.radial_extent for e in self.elements][::-1]}
+
+
+def unit_square_mesh():
+    """`meshes/rectangle.obj` of the tutorial scenes (absent from the tree): the square [-1, 1]^2 in the plane z = 0 as two triangles,
+    normal +z.  A mesh, not the analytic `rectangle`: a hit point on it is the barycentric combination of vertices with z = 0, hence has
+    z == 0 exactly, which the geometric tracer's `dr.allclose(0, si.p.z)` (prb_basic.py:138) relies on."""
+    return {'type': 'mesh', 'vertex_positions': np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32),
+            'vertex_normals': np.array([[0, 0, 1]] * 4, dtype=np.float32), 'vertex_texcoords': np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32),
+            'faces': np.array([[0, 1, 2], [2, 3, 0]], dtype=np.uint32)}
 
 
 # ------------------------------------------------------------------------------------------------
 # losses.py / design_problem.py
 # ------------------------------------------------------------------------------------------------
-def rms_loss(image):
-    """losses.py:8-29: squared RMS radius (in pixels) of the spot in `image` (H x W x 3 torch tensor); centroid and normalisation detached."""
+def rms_loss_and_center(image):
+    """losses.py:31-41: squared RMS radius (in pixels) of the spot in `image` (H x W x 3 torch tensor) and its centroid (row, column); centroid
+    and normalisation detached."""
     torch = _torch()
     scaled = image / image.detach().mean()
     H, W = image.shape[0], image.shape[1]
@@ -380,71 +631,215 @@ def rms_loss(image):
     I = (scaled[:, :, 0] + scaled[:, :, 1] + scaled[:, :, 2]) / 3.0
     inv_I_sum = 1.0 / I.sum()
     ibar = ((ii * I).sum() * inv_I_sum).detach(); jbar = ((jj * I).sum() * inv_I_sum).detach()
-    return (I * ((ii - ibar) ** 2 + (jj - jbar) ** 2)).sum() * inv_I_sum
+    return (I * ((ii - ibar) ** 2 + (jj - jbar) ** 2)).sum() * inv_I_sum, ibar, jbar
+
+
+def rms_loss(image):
+    """losses.py:8-29"""
+    return rms_loss_and_center(image)[0]
+
+
+class Ray3f:
+    """The two fields of mi.Ray3f the geometric tracer reads (o, d as n x 3 arrays; maxt = Largest)."""
+
+    def __init__(self, o, d):
+        self.o = np.asarray(o, dtype=np.float64).reshape(-1, 3); self.d = np.asarray(d, dtype=np.float64).reshape(-1, 3)
 
 
 class FieldSource:
-    """design_problem.py:12-279 for the on-axis field: a `disk` with a `directionalarea` emitter in front of the lens, aimed at it, and a
-    `perspective` sensor just in front of the film looking back at it."""
+    """design_problem.py:12-279: one field angle = a `disk` with a `directionalarea` emitter in front of the lens, aimed at the entrance
+    pupil, and a `perspective` sensor just in front of the film, placed where the source's central ray lands."""
 
-    def __init__(self, lens_system, resolution, init_camera_z=0.9, fov=135.0, source_distance=None, radiance=0.05):
-        self.radius = lens_system.front_radial_extent
-        self.target = np.array([0.0, 0.0, lens_system.front_z])
-        dist = max(10.0, 1.1 * lens_system.front_z) if source_distance is None else source_distance
-        self.origin = self.target + dist * np.array([0.0, 0.0, 1.0])
+    def __init__(self, name, origin, target, radius, lens_system, resolution, init_camera_z, tracer, fov=135.0, radiance=0.05):
+        self.source_key = "source_" + name; self.sensor_key = "sensor_" + name
+        self.origin = np.asarray(origin, dtype=np.float64); self.target = np.asarray(target, dtype=np.float64)
+        self.radius = radius; self.radiance = radiance
         self.near_clip = min(0.005, lens_system.rear_z * 0.1)
-        self.resolution = resolution; self.fov = fov; self.radiance = radiance
-        z_camera = max(init_camera_z * lens_system.rear_z, 1.1 * self.near_clip)
-        self.camera_pos = np.array([0.0, 0.0, z_camera])
+        self.resolution = resolution
+        self.fov = fov                                   # 135 degrees, "for nikon" (:39-40; 45 is the commented-out default)
+        self.camera_pos = np.zeros(3)
+        self.fov_changed = False; self.pos_changed = False
+        self.lens_system = lens_system
+        self.sensor_dict = self.get_sensor_dict(tracer, init_camera_z)
+        self.losses = []
 
     def add_to_scene(self, scene_dict):
+        """:51-83"""
         T = ScalarTransform4f
-        scene_dict['source_00_0-deg'] = {
+        for key in (self.source_key, self.sensor_key):
+            if key in scene_dict:
+                raise KeyError("`%s` already exists in scene!" % key)
+        scene_dict[self.source_key] = {
             'type': 'disk', 'to_world': T.look_at(target=self.target.tolist(), origin=self.origin.tolist(), up=[0, 1, 0]) @ T.scale([self.radius, self.radius, 1]),
             'bsdf': {'type': 'ref', 'id': 'black-bsdf'}, 'emitter': {'type': 'directionalarea', 'radiance': self.radiance}}
-        scene_dict['sensor_00_0-deg'] = {
-            'type': 'perspective', 'near_clip': self.near_clip, 'far_clip': float(self.camera_pos[2]) + 1.0, 'fov': self.fov,
-            'to_world': T.look_at(target=[float(self.camera_pos[0]), float(self.camera_pos[1]), -1.0], origin=self.camera_pos.tolist(), up=[0, 1, 0]),
-            'sampler': {'type': 'independent', 'sample_count': 512},
-            'film': {'type': 'hdrfilm', 'width': self.resolution[0], 'height': self.resolution[1], 'pixel_format': 'rgb', 'rfilter': {'type': 'tent'}}}
+        scene_dict[self.sensor_key] = self.sensor_dict
+
+    def update(self, params):
+        """:86-132: move / zoom this field's camera through the scene parameters (to_world, x_fov).  Host-side values; the device replica
+        receives the two parameters at the next params.update()."""
+        T = ScalarTransform4f
+        if self.pos_changed:
+            params["%s.to_world" % self.sensor_key] = T.look_at(target=[float(self.camera_pos[0]), float(self.camera_pos[1]), -1.0], origin=[float(x) for x in self.camera_pos], up=[0, 1, 0])
+            self.pos_changed = False
+        if self.fov_changed:
+            params["%s.x_fov" % self.sensor_key] = self.fov
+            self.fov_changed = False
+
+    def upsample_sensor(self, zoom_factor=2.0):
+        """:135-140: zoom on the centre of the image field."""
+        self.fov = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(self.fov)) / zoom_factor))
+        self.fov_changed = True
+
+    @staticmethod
+    def createSourceArray(lens_system, resolution, tracer, num_sources=1, max_field_angle=0.0, init_camera_z=0.9, fov=135.0):
+        """:142-181: `num_sources` field angles from 0 to max_field_angle (degrees) in the xz plane, every source aimed at the entrance
+        pupil from a distance at which neighbouring disks do not overlap."""
+        source_radius = lens_system.front_radial_extent
+        entrance_pupil_position = np.array([0.0, 0.0, lens_system.entrance_pupil_position])
+        max_field_angle = np.deg2rad(np.abs(max_field_angle))
+        field_angles = np.linspace(0.0, max_field_angle, num_sources)
+        if num_sources > 1:
+            dtheta = max_field_angle / (num_sources - 1)
+            source_distance = 1.1 * source_radius / np.tan(0.5 * dtheta)
+        else:
+            source_distance = max(10.0, 1.1 * lens_system.front_z)
+        sources = []
+        for field_angle in field_angles:
+            direction = np.array([np.sin(field_angle), 0.0, np.cos(field_angle)])
+            origin = entrance_pupil_position + source_distance * direction
+            name = ("%04.1f-deg" % np.rad2deg(field_angle)).replace(".", "_")
+            sources.append(FieldSource(name=name, origin=origin, target=entrance_pupil_position, radius=source_radius, lens_system=lens_system,
+                                       resolution=resolution, tracer=tracer, init_camera_z=init_camera_z, fov=fov))
+        return sources
+
+    def get_central_ray(self):
+        """:183-189"""
+        d = self.target - self.origin
+        return Ray3f(self.origin, d / np.linalg.norm(d))
+
+    def get_sensor_dict(self, tracer, init_camera_z):
+        """:192-247: the camera sits in front of the film where the central ray of the source lands (geometric trace through the lens)."""
+        T = ScalarTransform4f
+        _, _, is_valid, film_pos = tracer(self.get_central_ray())
+        film_pos = np.asarray(film_pos.detach().cpu() if hasattr(film_pos, "detach") else film_pos, dtype=np.float64).ravel()
+        is_valid = np.asarray(is_valid.detach().cpu() if hasattr(is_valid, "detach") else is_valid).ravel()
+        if not np.all(is_valid):
+            raise AssertionError("Source's central ray was not transmitted through the lens system! is_valid=%s" % is_valid)
+        z_camera = max(init_camera_z * self.lens_system.rear_z, 1.1 * self.near_clip)
+        self.camera_pos = np.array([film_pos[0], film_pos[1], z_camera])
+        self.init_pixel_size = self.camera_pos[2] * math.tan(math.radians(0.5 * self.fov)) / (self.resolution[0] / 2)
+        return {'type': 'perspective', 'near_clip': self.near_clip, 'far_clip': z_camera + 1.0, 'fov': self.fov,
+                'to_world': T.look_at(target=[float(self.camera_pos[0]), float(self.camera_pos[1]), -1.0], origin=[float(x) for x in self.camera_pos], up=[0, 1, 0]),
+                'sampler': {'type': 'independent', 'sample_count': 512},
+                'film': {'type': 'hdrfilm', 'width': self.resolution[0], 'height': self.resolution[1], 'pixel_format': 'rgb', 'rfilter': {'type': 'tent'}}}
 
     def get_pixel_size(self):
+        """:249-256: physical size of a camera pixel on the film plane, in millimetres."""
         return float(self.camera_pos[2]) * math.tan(math.radians(0.5 * self.fov)) / (self.resolution[0] / 2)
 
-    def evaluate_rms_loss(self, image):
-        """design_problem.py:267-279: the spot's squared RMS radius in mm^2."""
-        return rms_loss(image) * self.get_pixel_size() ** 2
+    def center_camera_on_pixel(self, i, j):
+        """:258-265: when the spot's centroid column is more than a tenth of the image to the LEFT of the centre (the test is one-sided in
+        the reference), slide the camera in x so that the spot is centred."""
+        pixel_size = self.get_pixel_size()
+        delta_x = self.resolution[0] / 2 - 0.5 - float(j)
+        self.pos_changed = bool(delta_x / self.resolution[0] > 0.1)
+        if self.pos_changed:
+            self.camera_pos[0] -= delta_x * pixel_size
+
+    def evaluate_rms_loss(self, image, recenter=False):
+        """:267-279: the spot's squared RMS radius in mm^2 and the upsample flag (spot smaller than a tenth of the image)."""
+        if recenter:
+            pixel_loss, ibar, jbar = rms_loss_and_center(image)
+            self.center_camera_on_pixel(ibar, jbar)
+        else:
+            pixel_loss = rms_loss(image)
+        upsample_flag = bool(pixel_loss.detach() < (self.resolution[0] * 0.1) ** 2)
+        physical_loss = pixel_loss * self.get_pixel_size() ** 2
+        self.losses.append(float(physical_loss.detach()))
+        return physical_loss, upsample_flag
 
 
 class DesignProblem:
-    """design_problem.py:283-584 (prepare :481-492, optimize :495-584) for one on-axis source."""
+    """design_problem.py:283-584: `num_sources` field sources, one sensor each, rendered one after the other in every iteration."""
 
-    def __init__(self, lens_system, resolution, spp, learning_rate, iters, film_diagonal=35.0, init_camera_z=0.9, fov=135.0, source_distance=None):
+    def __init__(self, lens_system, resolution, spp, learning_rate, iters, film_diagonal=35.0, num_sources=1, max_field_angle=5.0, init_camera_z=0.9, fov=135.0):
         lens_system.initialize_geometry()
         self.lens_system = lens_system; self.resolution = resolution; self.spp = spp; self.lr = learning_rate; self.iters = iters
-        self.film_diagonal = film_diagonal; self.init_camera_z = init_camera_z; self.fov = fov; self.source_distance = source_distance
+        self.film_diagonal = film_diagonal; self.num_sources = num_sources; self.max_field_angle = max_field_angle; self.init_camera_z = init_camera_z; self.fov = fov
         self.scene = self.params = self.optimizer = None
+        self.geo_check = None
 
-    def scene_dict(self):
-        """_build_preliminary_scene (:364-401) + add_field_sources (:310-327)."""
+    def _get_integrator(self, integrator_type):
+        return {'type': integrator_type, 'max_depth': self.lens_system.size() + 2, 'hide_emitters': False}      # :355-362
+
+    def _build_preliminary_scene(self, integrator_type):
+        """:364-401: lenses and film plane only."""
         T = ScalarTransform4f
-        d = {'type': 'scene',
-             'integrator': {'type': 'ptracer', 'max_depth': self.lens_system.size() + 2, 'hide_emitters': False},
+        d = {'type': 'scene', 'integrator': self._get_integrator(integrator_type),
              'white-bsdf': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': (1, 1, 1)}},
              'black-bsdf': {'type': 'diffuse', 'reflectance': 0.0},
-             'film_plane': {'type': 'rectangle', 'to_world': T.look_at(target=[0, 0, 1], origin=[0, 0, 0], up=[0, 1, 0]).scale([self.film_diagonal, self.film_diagonal, 1]),
-                            'bsdf': {'type': 'ref', 'id': 'white-bsdf'}}}
+             'film_plane': dict(unit_square_mesh(), to_world=T.look_at(target=[0, 0, 1], origin=[0, 0, 0], up=[0, 1, 0]).scale([self.film_diagonal, self.film_diagonal, 1]),
+                                bsdf={'type': 'ref', 'id': 'white-bsdf'})}
         self.lens_system.add_to_scene(d)
-        self.field_source = FieldSource(self.lens_system, self.resolution, self.init_camera_z, self.fov, self.source_distance)
-        self.field_source.add_to_scene(d)
+        return d
+
+    def add_field_sources(self, scene_dict, geo_tracer):
+        """:310-327"""
+        self.field_sources = FieldSource.createSourceArray(lens_system=self.lens_system, num_sources=self.num_sources, max_field_angle=self.max_field_angle,
+                                                           resolution=self.resolution, tracer=geo_tracer, init_camera_z=self.init_camera_z, fov=self.fov)
+        for fs in self.field_sources:
+            fs.add_to_scene(scene_dict)
+
+    def test_geo_tracer(self, tracer, N=100):
+        """:430-472 (__test_geo_tracer): N near-axis rays through the lens MESHES against the paraxial matrices.  Returns (max |y_exact -
+        y_paraxial|, max |u_exact - u_paraxial|); the reference prints both and asks for atol 2e-5."""
+        ls = self.lens_system
+        z_init = ls.front_z * 1.1; r_max = ls.front_radial_extent * 0.001; theta_max = 0.001 * math.pi
+        idx = np.arange(N, dtype=np.uint64)
+        rs = r_max * (2.0 * np.array([radical_inverse_2(int(i)) for i in idx]) - 1.0)
+        thetas = theta_max * (2.0 * np.array([sobol_2(int(i)) for i in idx]) - 1.0)
+        d = -np.stack([np.tan(thetas), np.zeros(N), np.ones(N)], axis=1)          # "negate direction since ray is traveling backwards"
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = np.stack([rs, np.zeros(N), np.full(N, z_init)], axis=1)
+        _, d_exact, _, out_exact = tracer(Ray3f(o, d))
+        d_exact = np.asarray(d_exact.detach().cpu() if hasattr(d_exact, "detach") else d_exact, dtype=np.float64)
+        out_exact = np.asarray(out_exact.detach().cpu() if hasattr(out_exact, "detach") else out_exact, dtype=np.float64)
+        y = rs - (z_init - ls.front_z) * np.tan(thetas); u = np.tan(thetas)
+        out_paraxial = ls.trace_paraxial_front2film(np.stack([y, u]))
+        err_y = float(np.max(np.abs(out_exact[:, 0] - out_paraxial[0])))
+        err_u = float(np.max(np.abs(d_exact[:, 0] / d_exact[:, 2] - out_paraxial[1])))
+        return err_y, err_u
+
+    def _build_scene(self):
+        """:403-428: a first scene (lenses + film) carries the `prb_basic` geometric tracer that places the field cameras; the rendering
+        scene uses `ptracer`."""
+        from .scene import load_dict
+        geo_scene = load_dict(self._build_preliminary_scene("prb_basic"))
+        trace_depth = self.lens_system.size() + 1
+        integ = geo_scene.integrator()
+        geo_tracer = lambda ray: integ.trace(geo_scene, ray, trace_depth)
+        d = self._build_preliminary_scene("ptracer")
+        self.add_field_sources(d, geo_tracer)
+        scene = load_dict(d)
+        self.geo_check = self.test_geo_tracer(geo_tracer)
+        geo_scene.release()
+        return scene
+
+    def scene_dict(self):
+        """The rendering scene's dictionary (needs a device: the field cameras are placed by the geometric tracer)."""
+        from .scene import load_dict
+        geo_scene = load_dict(self._build_preliminary_scene("prb_basic"))
+        integ = geo_scene.integrator(); depth = self.lens_system.size() + 1
+        d = self._build_preliminary_scene("ptracer")
+        self.add_field_sources(d, lambda ray: integ.trace(geo_scene, ray, depth))
+        geo_scene.release()
         return d
 
     def prepare(self):
-        from .scene import load_dict
+        """:481-492"""
         from .integrators import traverse
         from .optimizers import Adam
-        import torch
-        self.scene = load_dict(self.scene_dict())
+        self.scene = self._build_scene()
         self.params = traverse(self.scene)
         dev = self.params[next(iter(self.params._entries))].device
         self.optimizer = Adam(lr=self.lr)
@@ -452,24 +847,80 @@ class DesignProblem:
         self.lens_system.add_to_optimizer(self.optimizer, dev)
         return self
 
-    def step(self, it):
-        """One iteration of optimize() (:508-565): update the scene from the optimizer, render differentiably, back-propagate the spot loss,
-        take the optimizer step.  Returns the loss (mm^2 x 10000, as the notebook scales it)."""
+    def step(self, it, recenter=True):
+        """One iteration of optimize() (:508-565): update the scene from the optimizer, update the field cameras, render every field
+        differentiably, back-propagate the summed spot loss (x 10000, as the notebook scales it), take the optimizer step.  Returns
+        (loss, upsample_flag)."""
         from .integrators import render
         self.lens_system.update(self.params, self.optimizer)
+        for fs in self.field_sources:
+            fs.update(self.params)
+        loss = None; upsample_flag = True
         # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
         # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
-        image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, shard=getattr(self, "shard", None), group=getattr(self, "group", None))
-        loss = 10000.0 * self.field_source.evaluate_rms_loss(image)
+        for sensor_idx in range(self.num_sources):
+            image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, sensor=sensor_idx, shard=getattr(self, "shard", None), group=getattr(self, "group", None))
+            sensor_loss, upsample = self.field_sources[sensor_idx].evaluate_rms_loss(image, recenter=recenter)
+            upsample_flag = upsample_flag and upsample
+            loss = 10000.0 * sensor_loss if loss is None else loss + 10000.0 * sensor_loss
         loss.backward()
         self.optimizer.step()
+        if upsample_flag:
+            for fs in self.field_sources:
+                fs.upsample_sensor()
         self.params.update()
-        return float(loss.detach())
+        return float(loss.detach()), upsample_flag
 
     def optimize(self, iters=None):
-        losses = []
+        losses = []; self.upsample_steps = 0
         for it in range(self.iters if iters is None else iters):
-            losses.append(self.step(it))
+            loss, up = self.step(it)
+            losses.append(loss); self.upsample_steps += int(up)
             if it in (int(0.7 * self.iters), int(0.9 * self.iters)):
                 self.optimizer.set_learning_rate(0.3 * self.optimizer.lr_default)
         return losses
+
+    def render(self, spp, sensor_idx=0, resolution=None, zoom_factor=None):
+        """:586-619: a look at the film through one field's camera, optionally zoomed and at another resolution; everything is restored."""
+        from .integrators import render
+        import torch
+        with torch.no_grad():
+            if zoom_factor is not None:
+                for fs in self.field_sources:
+                    fs.upsample_sensor(zoom_factor); fs.update(self.params)
+            key = "%s.film" % self.field_sources[sensor_idx].sensor_key
+            if resolution is not None:
+                saved = (self.params[key + ".size"], self.params[key + ".crop_size"], self.params[key + ".crop_offset"])
+                self.params[key + ".size"] = (resolution[0], resolution[1])
+            self.params.update()
+            image = render(self.scene, self.params, spp=spp, sensor=sensor_idx)
+            if zoom_factor is not None:
+                for fs in self.field_sources:
+                    fs.upsample_sensor(1.0 / zoom_factor); fs.update(self.params)
+            if resolution is not None:
+                self.params[key + ".size"] = saved[0]; self.params[key + ".crop_size"] = saved[1]; self.params[key + ".crop_offset"] = saved[2]
+            self.params.update()
+        return image
+
+
+def radical_inverse_2(index, scramble=0):
+    """mi.radical_inverse_2 (include/mitsuba/core/qmc.h:189-211, single precision): van der Corput in base 2 by bit reversal; the float is
+    built from the 23 high bits ((bits >> 9) | 0x3f800000) - 1."""
+    index &= 0xffffffff
+    index = ((index << 16) | (index >> 16)) & 0xffffffff
+    index = (((index & 0x00ff00ff) << 8) | ((index & 0xff00ff00) >> 8)) & 0xffffffff
+    index = (((index & 0x0f0f0f0f) << 4) | ((index & 0xf0f0f0f0) >> 4)) & 0xffffffff
+    index = (((index & 0x33333333) << 2) | ((index & 0xcccccccc) >> 2)) & 0xffffffff
+    index = (((index & 0x55555555) << 1) | ((index & 0xaaaaaaaa) >> 1)) & 0xffffffff
+    return float(((index ^ scramble) >> 9) / float(1 << 23))
+
+
+def sobol_2(index, scramble=0):
+    """mi.sobol_2 (qmc.h:217-237, single precision): the second Sobol' dimension, Float(bits) / Float(2^32)."""
+    index &= 0xffffffff; v = 1 << 31
+    while index != 0:
+        if index & 1:
+            scramble ^= v
+        index >>= 1
+        v ^= v >> 1
+    return float(np.float32(np.float32(scramble) / np.float32(2.0 ** 32)))

@@ -503,8 +503,32 @@ static inline int disk_intersect(const OShape *sh, const Ray *ray, float *t_out,
     return hit;
 }
 static inline v3 mesh_vertex(const OShape *sh, uint32_t i) { return V3(sh->pos[3*i], sh->pos[3*i+1], sh->pos[3*i+2]); }
+/* Watertight ray / triangle test for the geometric tracer (orc_trace).  The callers of prb_basic.trace aim rays EXACTLY at mesh vertices and
+   along mesh edges -- a field's central ray goes to the entrance-pupil position, which is the pole vertex of the front lens mesh
+   (design_problem.py:152-153, :183-189), and the tracer check sends its rays in the symmetry plane y = 0 of the icosphere (:442-453) --
+   and the reference intersects meshes through Embree / OptiX, which do not leak at shared edges.  Moeller-Trumbore below does (its u, v
+   are computed relative to each triangle's own first vertex: a ray on a shared edge can be marginally outside BOTH neighbours).  Pluecker
+   edge functions (Embree's PlueckerIntersector): for the edge (P, Q) f = dot(cross(P - Q, P + Q), d) with P, Q relative to the ray origin;
+   the neighbour sees the same edge as (Q, P) and gets exactly -f in floating point (negation and commutation are exact, rounding is
+   sign-symmetric), so a ray is inside at least one of the two.  u, v as mesh.h:430-453 defines them (weights of p1, p2). */
+static __thread int g_watertight = 0;
+static inline int pluecker_watertight(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
+    v3 v0 = sub3(p0, ray->o), v1 = sub3(p1, ray->o), v2_ = sub3(p2, ray->o);
+    v3 e0 = sub3(v2_, v0), e1 = sub3(v0, v1), e2 = sub3(v1, v2_);
+    float U = dot3(cross3(e0, add3(v2_, v0)), ray->d), V = dot3(cross3(e1, add3(v0, v1)), ray->d), W = dot3(cross3(e2, add3(v1, v2_)), ray->d);
+    float UVW = U + V + W, eps = 5.9604644775390625e-8f * fabsf(UVW);
+    float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+    int active = (mn >= -eps || mx <= eps) && UVW != 0.f;
+    v3 ng = cross3(sub3(v1, v0), sub3(v2_, v0));
+    float den = dot3(ng, ray->d), t = dot3(v0, ng) / den;
+    active = active && den != 0.f && t >= 0.f && t <= ray->maxt;
+    float inv = 1.f / UVW;
+    *t_out = t; uv_out->x = fminf(fmaxf(U * inv, 0.f), 1.f); uv_out->y = fminf(fmaxf(V * inv, 0.f), 1.f);
+    return active;
+}
 /* Mesh::moeller_trumbore: include/mitsuba/render/mesh.h:430-453 */
 static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
+    if (g_watertight) return pluecker_watertight(ray, p0, p1, p2, t_out, uv_out);
     v3 e1 = sub3(p1, p0), e2 = sub3(p2, p0);
     v3 pvec = cross3(ray->d, e2);
     float inv_det = rcpf_(dot3(e1, pvec));
@@ -2376,6 +2400,7 @@ ORC_API void orc_ray_intersect(OScene *sc, const float *rays, uint32_t n, float 
 ORC_API void orc_trace(OScene *sc, const float *rays, uint32_t n, uint32_t num_lenses, int32_t max_depth_in, float *out) {
     const uint32_t max_depth = (uint32_t) max_depth_in;
     const int saved_mode = g_importance_mode; g_importance_mode = 0;
+    g_watertight = 1;                                                       /* see pluecker_watertight */
     for (uint32_t i = 0; i < n; ++i) {
         Ray ray; ray.o = V3(rays[8*i], rays[8*i+1], rays[8*i+2]); ray.d = V3(rays[8*i+3], rays[8*i+4], rays[8*i+5]); ray.maxt = rays[8*i+6];
         Ray pen = ray; uint32_t depth = 0; v3 beta = V3(1.f, 1.f, 1.f), p_last = V3(0.f, 0.f, 0.f); int active = 1, si_valid = 0;
@@ -2403,7 +2428,7 @@ ORC_API void orc_trace(OScene *sc, const float *rays, uint32_t n, uint32_t num_l
         o[0] = pen.o.x; o[1] = pen.o.y; o[2] = pen.o.z; o[3] = pen.d.x; o[4] = pen.d.y; o[5] = pen.d.z;
         o[6] = p_last.x; o[7] = p_last.y; o[8] = p_last.z; o[9] = si_valid ? 1.f : 0.f; o[10] = (float) depth; o[11] = 0.f;
     }
-    g_importance_mode = saved_mode;
+    g_importance_mode = saved_mode; g_watertight = 0;
 }
 ORC_API void orc_primary_rays(OScene *sc, const float *sample_pos, uint32_t n, float *rays) {
     for (uint32_t i = 0; i < n; ++i) {

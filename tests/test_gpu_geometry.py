@@ -258,9 +258,9 @@ def test_lens_design_doublet(mi, orc, torch_cuda):
     scene, params = problem.scene, problem.params
     info = scene.info()
     assert info["bvh_meshes"] == 6 and info["triangles"] >= 3 * 8000
-    assert len(problem.optimizer.keys()) == 30
+    assert len(problem.optimizer.keys()) == 30 and len(scene.sensors()) == 1 and problem.num_sources == 1      # (the 3-field problem: tests/test_gpu_sensors.py)
     # ---- (i) after one update (normals follow the positions), against the oracle
-    system.update(params, problem.optimizer); params.update()
+    system.update(params, problem.optimizer)
     o = orc.OracleScene(scene, mi.abi)
     for e in system.elements:
         for key in (e.lens_key, e.baffle_key):
@@ -295,7 +295,7 @@ def test_lens_design_doublet(mi, orc, torch_cuda):
         assert abs(lhs - rhs) < 2e-3 * max(abs(lhs), abs(rhs), 1e-12), (name, lhs, rhs)
     # ---- (iii) the optimisation loop of design_problem.py:508-565
     handle = scene._handle
-    losses = [problem.step(it) for it in range(6)]
+    losses = [problem.step(it)[0] for it in range(6)]
     assert scene._handle is handle                                          # the device replica was updated in place, never rebuilt
     assert np.isfinite(losses).all() and min(losses[3:]) < losses[0], losses
     moved = [float((problem.optimizer[k].detach() - v0).abs().max()) for k, v0 in [("lens1_c", torch.tensor([-8.0 / 24], device="cuda")), ("lens2_c", torch.tensor([8.0 / 24], device="cuda"))]]

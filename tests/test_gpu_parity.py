@@ -426,23 +426,28 @@ def test_realisticlens_matches_oracle(mi, orc, torch_cuda, design):
     # some rays are vignetted / miss; exp2 (rear filter plate 27 mm wide, 1.35 mm from the film, no exit-pupil LUT) transmits
     # ~1e-4 of the uniformly sampled rays, as in the reference's default mode: its lanes agree but are all dark at this size
     assert (ref[:, :3].max() > 0 or design == "exp2a") and (ref[:, 3] == 0).any()
+    if design == "exp2a":
+        # ... so agreeing on darkness proves little: a million lanes (1024 spp) let a hundred-odd rays through the 22 surfaces and the two
+        # aspheres -- those lanes carry light, and they must agree too
+        n_big = 32 * 32 * 1024
+        ref_big = o.lane_radiance(o.params(integ, seed, 1024), 0, n_big)
+        got_big = integ.lane_radiance(scene, seed, 1024, 0, n_big).cpu().numpy()
+        lit = ref_big[:, :3].max(axis=1) > 0
+        assert lit.sum() >= 20, int(lit.sum())
+        both = np.isclose(got_big[:, :3], ref_big[:, :3], rtol=2e-4, atol=1e-5).all(axis=1) & (got_big[:, 3] == ref_big[:, 3])
+        assert both.mean() > 0.9999 and both[lit].mean() > 0.97, (float(both.mean()), float(both[lit].mean()), int(lit.sum()))
     img = integ.render(scene, seed=3, spp=16).cpu().numpy()
     img_ref, _ = o.render(o.params(integ, 3, 16))
     err = np.abs(img - img_ref)
-    if design == "asph_singlet":
-        # the asphere's Newton iteration accepts a hit when |dz| < 10 eps: v_rsq / v_rcp against libm can flip that test for a
-        # handful of rays (they are the "diverged lanes" above), each of which moves one pixel by 1/spp of a sample
-        assert np.percentile(err, 99.5) < 1e-3 * img_ref.max() and err.max() < 2e-2 * img_ref.max()
-    else:
-        assert err.max() <= 1e-3 * img_ref.max()
+    # (round 3: the whole lens walk -- film point to front element, the asphere's conic root, Newton iteration and acceptance |dz| < 10 eps --
+    #  runs in IEEE arithmetic on the device whatever the rest of the build uses, so the aspherical singlet is held to the same bar as
+    #  every other design; with v_rcp / v_rsq in the walk a handful of its rays flipped that acceptance, profiles/r02_grad_parity.txt)
+    assert err.max() <= 1e-3 * img_ref.max(), (design, err.max() / img_ref.max())
     params = mi.traverse(scene)
     gin = np.random.default_rng(2).normal(size=(32, 32, 3)).astype(np.float32)
     g = integ.render_backward(scene, params, torch.tensor(gin), seed=9, spp=16).cpu().numpy()
     g_ref = o.render_backward(o.params(integ, 9, 16), gin)
-    # asph_singlet: the same flipped Newton acceptances as in the image above -- a flipped ray adds or removes a whole path's gradient
-    # (measured 3.6e-3 of the largest component with v_rcp / v_rsq, 16 k paths; every other design sits at 1e-6 .. 3e-4; a -DMI_EXACT_MATH
-    # build brings this design to 8.7e-4 and `singlet` from 3.1e-4 to 5.3e-7: profiles/r02_grad_parity.txt)
-    assert grad_close(g, g_ref, 5e-3 if design == "asph_singlet" else 1e-3, design)
+    assert grad_close(g, g_ref, 1e-3, design)
     films = {}
     for mode in (mi.abi.MODE_STATIC, mi.abi.MODE_FUSED, mi.abi.MODE_WAVEFRONT):      # re-packing carries eta / prev_delta and the lens weight too
         pi = mi.PathIntegrator({"max_depth": 5}); pi.mode = mode
@@ -553,7 +558,7 @@ def test_exit_pupil_sampling_matches_oracle(mi, orc, torch_cuda, design):
     import ctypes
     scene = _lens_cbox(mi, design, sample_exit_pupil=True, shutter_open=0.0, shutter_close=1.0)
     got = np.empty((64, 4), dtype=np.float32)
-    mi.abi.check(mi.abi.lib().mi355_lens_exit_pupil_bounds(scene.handle(), got.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    mi.abi.check(mi.abi.lib().mi355_lens_exit_pupil_bounds(scene.handle(), 0, got.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
     integ = mi.PRBIntegrator({"max_depth": 4, "rr_depth": 3})
     spp, seed, n = 8, 5, 32 * 32 * 8
     lanes = integ.lane_radiance(scene, seed, spp, 0, n).cpu().numpy()
@@ -652,7 +657,7 @@ def test_render_forward_matches_oracle(mi, orc, torch_cuda, scene_name):
         p = integ._params(scene, 5, 32, shard=mi.shard_tiles(f.crop_width, f.crop_height, r, 2, rows=8)); p.integrator = mi.abi.INTEGRATOR_PRB
         mi.abi.check(mi.abi.lib().mi355_render_forward(scene.handle(), C.byref(p), C.c_void_p(params.tangent_buffer(acc.device).data_ptr()), C.c_void_p(acc.data_ptr()), None))
     img2 = torch.empty((f.crop_height, f.crop_width, 3), device="cuda")
-    mi.abi.check(mi.abi.lib().mi355_film_develop(scene.handle(), C.c_void_p(acc.data_ptr()), C.c_void_p(img2.data_ptr()), None))
+    mi.abi.check(mi.abi.lib().mi355_film_develop(scene.handle(), 0, C.c_void_p(acc.data_ptr()), C.c_void_p(img2.data_ptr()), None))
     torch.cuda.synchronize()
     assert np.allclose(img2.cpu().numpy(), gimg, rtol=1e-3, atol=1e-4 * scale)
     params.clear_tangents()

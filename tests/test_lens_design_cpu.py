@@ -1,0 +1,178 @@
+"""CPU tests of the host-side mirror of the fork's lens-design scripts (mitsuba3-camera_amd/lens_design.py) and of the oracle's twin of
+the geometric ray tracer `prb_basic.trace` -- what BASELINE config 5 (notebooks/doublet_full_optim.ipynb) is set up with.
+
+Pins (all reference-held):
+  * notebooks/doublet_full_optim.ipynb cell 5 ("Exact Vd: 6.861593997805768"), cell 6 (LensSystem.print(): Cauchy pairs, r_c, t) and cell 9
+    (optimizer variables lens0_c, lens0_z0 after the focal-length constraint) -- stored OUTPUTS of the reference, float32 Dr.Jit arithmetic;
+  * notebooks/scripts/lens_design/lens.py:1270-1282 (test_focal_lengths_singlet: BFL / FFL of two singlets) and :1284-1330 (Petzval and
+    Cooke triplets: EFL 49.999855 / 50.000541);
+  * include/mitsuba/core/qmc.h:189-237 (radical_inverse_2, sobol_2: the first points of the two sequences);
+  * notebooks/scripts/lens_design/design_problem.py:430-472 (__test_geo_tracer: exact trace of the lens MESHES against the paraxial matrices,
+    atol 2e-5; cell 7 of the notebook prints what the reference itself measured: u within 8.6e-6 -- "u is close: True" -- and y off by
+    3.8e-4 -- "y is close: False").
+"""
+import math
+
+import numpy as np
+import pytest
+
+
+def _doublet(ld, subdiv, constrained=True):
+    surfs = [{'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 140, 'z0': 48}, {'radial_extent': 8.0, 'K': 0.0, 'c': -1 / 24, 'z0': 49}, {'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 24, 'z0': 52}]
+    mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
+    system = ld.LensSystem([ld.EvenAsphericSurface(**s) for s in surfs], mats, aperture_index=-1, subdiv_levels=subdiv)
+    system.disable_all_materials()
+    if constrained:                              # cell 5: "apply focal length constraint"
+        s1 = system.get_rear_surface_params(50.0)
+        system.elements[0].surface.params['c'] = float(s1['c']); system.elements[0].surface.params['z0'] = float(s1['z0'])
+        system.compute_paraxial_quantities()
+    return system
+
+
+def test_doublet_matches_the_notebooks_stored_outputs(mi):
+    ld = mi.lens_design
+    system = _doublet(ld, 2)
+    # cell 9: problem.optimizer.variables (float32 in the reference)
+    assert abs(system.elements[0].surface.params['c'] - (-0.04761601984500885)) < 2e-8
+    assert abs(system.elements[0].surface.params['z0'] - 46.7470817565918) < 1e-5
+    assert abs(system.elements[1].surface.params['c'] - (-0.3333333432674408)) < 1e-7 and abs(system.elements[2].surface.params['c'] - 0.3333333432674408) < 1e-7
+    # cell 6: LensSystem.print()
+    d = system.describe()
+    assert np.allclose(d["materials"][0], (1.456079838959, 0.021086562958), rtol=0, atol=1e-11)
+    assert np.allclose(d["materials"][1], (1.568952539042, 0.026305160873), rtol=0, atol=1e-11)
+    assert d["materials"][2] == (1.000277, 0.0)
+    assert np.allclose(d["r_c"], (24.0, -24.0, -168.01068267), rtol=1e-7)
+    assert np.allclose(d["t"], (3.0, 2.25291824, 46.74708176), rtol=0, atol=1e-5)
+    assert d["r_e"] == [8.0, 8.0, 8.0]
+    # the constraint holds: focal length 50 mm, paraxial focus on the film plane
+    assert abs(system.compute_EFL() - 50.0) < 1e-9 and abs(system.compute_BFL() - system.elements[0].surface.params['z0']) < 1e-9
+    # cell 4 / 5: get_exact_Vd -> "Exact Vd: 6.861593997805768"
+    inv_c = system.elements[0].surface.get_curvature(); inv_b = -system.elements[1].surface.get_curvature(); inv_a = system.elements[2].surface.get_curvature()
+    n1, V1, n2 = system.materials[2].params['ior'], system.materials[2].params['V_d'], system.materials[1].params['ior']
+    P1 = (n1 - 1) * (inv_a + inv_b); P2 = -(n2 - 1) * (inv_b + inv_c)
+    assert abs(-(P2 / P1) * V1 - 6.861593997805768) < 2e-5
+    # no aperture stop: the entrance pupil sits on the front surface, the sources aim there (design_problem.py:152-153)
+    assert system.entrance_pupil_position == 52.0 and system.size() == 3
+
+
+def test_focal_lengths_of_the_references_own_lens_tests(mi):
+    """lens.py:1258-1330"""
+    ld = mi.lens_design
+
+    def singlet(c0, c1):
+        s = [ld.ConicSurface(radial_extent=0.8, c=c0, K=0.0, z0=2.5), ld.ConicSurface(radial_extent=0.8, c=c1, K=0.0, z0=2.8)]
+        l = ld.LensSystem(s, [ld.LensMaterial("nbk7", 1.5047, 64.17)], subdiv_levels=1)
+        return np.array([l.compute_BFL(), l.compute_FFL()])
+    assert np.allclose(singlet(-0.3, 0.3), [3.25439588, 3.25439588])
+    assert np.allclose(singlet(-0.277226358652119, 0.421164870262146), [2.76563327, 2.80743881])
+
+    # :1284-1330 PRINTS (does not assert) the EFL of two published prescriptions next to the catalogue values 50.000541 / 49.999855; those
+    # hold for n_air = 1 -- with the scripts' own air (1.000277) both come out 0.04 mm longer -- so the comparison is made in vacuum
+    def compound(surfs, mats):
+        surfaces = [ld.ConicSurface(K=0, radial_extent=s[0], c=(0.0 if math.isinf(s[1]) else 1.0 / s[1]), z0=s[2]) for s in surfs]
+        l = ld.LensSystem(surfaces, mats, subdiv_levels=1)
+        for m in l.materials:
+            if m.name == "air":
+                m.params['ior'] = 1.0
+        l.compute_paraxial_quantities()
+        return l
+    air = ld.LensMaterial("air")
+    sk16, f4 = ld.LensMaterial("sk16", 1.62041, 60.32), ld.LensMaterial("f4", 1.616592, 36.63)
+    cooke = compound([(5.0, -17.285, 42.95), (5.0, 141.25, 44.95), (5.0, 19.3, 50.95), (5.0, -20.25, 51.95), (5.0, -158.65, 57.95), (5.0, 21.25, 59.95)], [sk16, air, f4, air, sk16])
+    assert abs(cooke.compute_EFL() - 50.000541) < 5e-4
+    k7, f2 = ld.LensMaterial("k7", 1.51112, 60.41), ld.LensMaterial("f2", 1.62004, 36.37)
+    petzval = compound([(0.8, -188.1, 20.4), (0.8, -22.1, 22.4), (0.8, 28.42, 28.9), (0.8, math.inf, 64.67), (0.8, -37.87, 66.67), (0.8, 36.27, 72.67)], [f2, k7, air, f2, k7])
+    assert abs(petzval.compute_EFL() - 49.999855) < 5e-4
+
+
+def test_low_discrepancy_points_of_the_tracer_check(mi):
+    """qmc.h:189-237: van der Corput / the second Sobol' dimension (0, 1/2, 1/4, 3/4, 1/8 ... and, with the direction numbers 1/2, 3/4, 5/8 in natural index order, 0, 1/2, 3/4, 1/4, 5/8 ...)."""
+    ld = mi.lens_design
+    assert [ld.radical_inverse_2(i) for i in range(6)] == [0.0, 0.5, 0.25, 0.75, 0.125, 0.625]
+    assert [ld.sobol_2(i) for i in range(6)] == [0.0, 0.5, 0.75, 0.25, 0.625, 0.125]
+
+
+def test_field_sources_are_laid_out_as_in_the_reference(mi):
+    """FieldSource.createSourceArray (design_problem.py:142-181): angles 0 .. 5 degrees, aimed at the entrance pupil, far enough apart that
+    neighbouring disks do not overlap; names as the reference formats them."""
+    ld = mi.lens_design
+    system = _doublet(ld, 1)
+    tracer = lambda ray: (None, None, np.ones(1, dtype=bool), np.array([[0.1, 0.0, 0.0]]))
+    fs = ld.FieldSource.createSourceArray(system, (16, 16), tracer, num_sources=3, max_field_angle=5.0, init_camera_z=0.01)
+    assert [f.source_key for f in fs] == ["source_00_0-deg", "source_02_5-deg", "source_05_0-deg"]
+    assert [f.sensor_key for f in fs] == ["sensor_00_0-deg", "sensor_02_5-deg", "sensor_05_0-deg"]
+    dist = 1.1 * 8.0 / math.tan(0.5 * math.radians(2.5))
+    for f, ang in zip(fs, (0.0, 2.5, 5.0)):
+        assert np.allclose(f.target, [0, 0, 52.0]) and np.allclose(f.origin, np.array([0, 0, 52.0]) + dist * np.array([math.sin(math.radians(ang)), 0, math.cos(math.radians(ang))]))
+        assert f.radius == 8.0 and f.near_clip == 0.005 and f.fov == 135.0
+        z_cam = max(0.01 * system.rear_z, 1.1 * 0.005)
+        assert np.allclose(f.camera_pos, [0.1, 0.0, z_cam])
+        assert abs(f.get_pixel_size() - z_cam * math.tan(math.radians(67.5)) / 8) < 1e-12
+    centres = np.array([f.origin for f in fs])
+    assert np.linalg.norm(centres[1] - centres[0]) >= 2 * 8.0                      # the disks do not overlap
+    # center_camera_on_pixel (:258-265): the reference's one-sided test -- only a spot left of the centre by more than a tenth moves the camera
+    f = fs[1]; x0 = f.camera_pos[0]
+    f.center_camera_on_pixel(7.5, 12.0); assert not f.pos_changed and f.camera_pos[0] == x0
+    f.center_camera_on_pixel(7.5, 2.0); assert f.pos_changed and abs(f.camera_pos[0] - (x0 - 5.5 * f.get_pixel_size())) < 1e-12
+    # upsample_sensor (:135-140): a 2x zoom halves tan(fov / 2)
+    t0 = math.tan(math.radians(f.fov / 2)); f.upsample_sensor(); assert f.fov_changed and abs(math.tan(math.radians(f.fov / 2)) - t0 / 2) < 1e-12
+
+
+@pytest.mark.parametrize("subdiv", [5])
+def test_oracle_geometric_tracer_against_the_paraxial_matrices(mi, orc, subdiv):
+    """design_problem.py:430-472 on the oracle's twin of prb_basic.trace: 100 near-axis rays through the three lens MESHES land on the film
+    where the paraxial matrices say, and leave the rear surface with the paraxial slope.  The reference asks for atol 2e-5 on both and
+    reports (cell 7 of the notebook, subdivision 7) 8.6e-6 for the slope -- passed -- and 3.8e-4 for the position -- failed, a mesh-normal
+    effect: the slope error times the 47 mm to the film.  The same two magnitudes are asked for here."""
+    ld = mi.lens_design
+    system = _doublet(ld, subdiv)
+    problem = ld.DesignProblem(system, resolution=(16, 16), spp=4, learning_rate=1e-4, iters=1, num_sources=3, max_field_angle=5.0, init_camera_z=0.01)
+    geo = mi.load_dict(problem._build_preliminary_scene("prb_basic"))
+    assert geo.integrator().name == "prb_basic" and geo.integrator().max_depth == 5
+    o = orc.OracleScene(geo, mi.abi)
+
+    def tracer(ray):
+        rays = np.zeros((ray.o.shape[0], 8), dtype=np.float32); rays[:, :3] = ray.o; rays[:, 3:6] = ray.d; rays[:, 6] = np.float32(3.4028234663852886e38)
+        out = o.trace(rays, system.size() + 1, geo.integrator().max_depth)
+        z = np.abs(out[:, 8])
+        valid = (out[:, 9] != 0) & bool(np.all(z <= 1e-8 + 1e-5 * z))
+        return out[:, 0:3], out[:, 3:6], valid, out[:, 6:9]
+    err_y, err_u = problem.test_geo_tracer(tracer)
+    assert err_u < 2e-5, err_u
+    assert err_y < 1e-3, err_y
+    # the three central rays (one per field angle) reach the film: where get_sensor_dict puts the cameras (:192-247)
+    fs = ld.FieldSource.createSourceArray(system, (16, 16), tracer, num_sources=3, max_field_angle=5.0, init_camera_z=0.01)
+    xs = [f.camera_pos[0] for f in fs]
+    assert abs(xs[0]) < 1e-3 and abs(fs[0].camera_pos[1]) < 1e-3
+    # image height of a field angle theta for a lens of focal length 50 focused at infinity: -f tan(theta) (collimated source, inverted image)
+    for f, ang in zip(fs, (0.0, 2.5, 5.0)):
+        assert abs(f.camera_pos[0] - (-50.0 * math.tan(math.radians(ang)))) < 2e-2, (ang, f.camera_pos)
+    # a ray that misses the lens dies on the black baffle / housing: invalid for the design problem
+    out = o.trace(np.array([[30.0, 0.0, 60.0, 0.0, 0.0, -1.0, 3e38, 0.0]], dtype=np.float32), 4, 5)
+    assert out[0, 9] == 0.0 or out[0, 10] < 4
+
+
+def test_two_sensors_share_one_oracle_scene(mi, orc):
+    """Scene::sensors(): rendering sensor i of a two-sensor scene is rendering a one-sensor scene that holds just that sensor."""
+    from conftest import small_cbox
+    T = mi.ScalarTransform4f
+    d = small_cbox(mi, 16)
+    second = {'type': 'perspective', 'fov': 50.0, 'near_clip': 0.01, 'far_clip': 50.0, 'to_world': T.look_at(origin=[0.5, 0.3, 3.0], target=[0, 0, 0], up=[0, 1, 0]),
+              'sampler': {'type': 'independent', 'sample_count': 8}, 'film': {'type': 'hdrfilm', 'width': 24, 'height': 12, 'rfilter': {'type': 'tent'}, 'pixel_format': 'rgb'}}
+    both = dict(d); both["second"] = second
+    sc = mi.load_dict(both)
+    assert [s.id for s in sc.sensors()] == ["sensor", "second"] and sc.sensor is sc.sensors()[0]
+    assert sc.sensor_index(1) == 1 and sc.sensor_index(sc.sensors()[1]) == 1
+    with pytest.raises(mi.PluginError):
+        sc.sensor_index(2)
+    only = dict(d); del only["sensor"]; only["second"] = second
+    integ = mi.PathIntegrator({"max_depth": 3})
+    o2 = orc.OracleScene(sc, mi.abi); o1 = orc.OracleScene(mi.load_dict(only), mi.abi)
+    img2, _ = o2.render(o2.params(integ, 1, 8, sensor=1)); img1, _ = o1.render(o1.params(integ, 1, 8))
+    assert img2.shape == (12, 24, 3) and np.allclose(img1, img2, rtol=1e-5, atol=1e-8)      # (same samples; the oracle's OpenMP threads add their films in any order)
+    first, _ = o2.render(o2.params(integ, 1, 8, sensor=0))
+    assert first.shape == (16, 16, 3)
+    # a sensor parameter update (perspective.cpp:155-171) on the oracle twin: x_fov
+    sc.sensors()[1].x_fov = 35.0; o2.set_sensor(1)
+    zoomed, _ = o2.render(o2.params(integ, 1, 8, sensor=1))
+    assert zoomed.shape == (12, 24, 3) and not np.allclose(zoomed, img2, rtol=1e-3)
