@@ -321,6 +321,12 @@ int mi355_scene_set_sensor(mi355_scene *scene, uint32_t index, const mi355_senso
 /* Number of sensors of the replica. */
 int mi355_scene_sensor_count(const mi355_scene *scene);
 
+/* dr.enable_grad on / off for one geometry parameter (MI355_PARAM_VERTEX_POSITIONS: index = shape; MI355_PARAM_BSDF_IOR: index = bsdf).
+   Dr.Jit's backward pass only visits the parameters whose gradients are enabled (the lens-design loop differentiates the lens and baffle
+   meshes, not the film plane or the housing, design_problem.py:481-492 / lens.py:473-498); with a slot disabled the geometry adjoint skips
+   its scatter and leaves the slot untouched.  The layout does not change.  All slots are enabled at creation. */
+int mi355_scene_param_enable_grad(mi355_scene *scene, uint32_t kind, uint32_t index, int enable);
+
 /* Layout of the concatenated parameter-gradient buffer.  Returns the number of
    parameters; fills at most `capacity` entries. */
 int mi355_scene_param_layout(const mi355_scene *scene, mi355_param_info *out, uint32_t capacity,

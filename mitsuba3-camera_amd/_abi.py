@@ -107,6 +107,7 @@ SYMBOLS = [
     ("mi355_scene_destroy", C.c_int, [C.c_void_p]),
     ("mi355_scene_set_param", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint64]),
     ("mi355_scene_set_param_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("mi355_scene_param_enable_grad", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     ("mi355_scene_param_layout", C.c_int, [C.c_void_p, C.POINTER(ParamInfo), C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mi355_render_accumulate", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     ("mi355_film_develop", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

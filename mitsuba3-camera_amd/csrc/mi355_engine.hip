@@ -2319,6 +2319,25 @@ extern "C" int mi355_scene_set_param_device(mi355_scene *s, uint32_t kind, uint3
     HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
     return MI355_OK;
 }
+extern "C" int mi355_scene_param_enable_grad(mi355_scene *s, uint32_t kind, uint32_t index, int enable) {
+    if (!s) return fail(MI355_ERR_INVALID, "null scene");
+    uint64_t off = ~0ull;
+    for (const mi355_param_info &pi : s->layout) if (pi.kind == kind && pi.index == index) off = pi.offset;
+    if (off == ~0ull || (kind != MI355_PARAM_VERTEX_POSITIONS && kind != MI355_PARAM_BSDF_IOR)) return fail(MI355_ERR_INVALID, "no such geometry parameter (vertex_positions of a mesh, IOR pair of a dielectric)");
+    HIP_TRY(hipSetDevice(s->device));
+    if (kind == MI355_PARAM_VERTEX_POSITIONS) {
+        const uint32_t v = enable ? (off <= 0xfffffff0ull ? (uint32_t) off : 0xffffffffu) : 0xffffffffu;
+        if (s->shapes[index].grad_offset == v) return MI355_OK;
+        s->shapes[index].grad_offset = v;
+        HIP_TRY(hipMemcpy((char *) (s->d_shapes + index) + offsetof(DShape, grad_offset), &v, 4, hipMemcpyHostToDevice));
+    } else {
+        const int32_t v = enable ? (off <= 0x7ffffff0ull ? (int32_t) off : -1) : -1;
+        if (s->bsdfs[index].ior_grad_offset == v) return MI355_OK;
+        s->bsdfs[index].ior_grad_offset = v;
+        HIP_TRY(hipMemcpy((char *) (s->d_bsdfs + index) + offsetof(DBsdf, ior_grad_offset), &v, 4, hipMemcpyHostToDevice));
+    }
+    return MI355_OK;
+}
 extern "C" int mi355_scene_param_layout(const mi355_scene *s, mi355_param_info *out, uint32_t capacity, uint64_t *total_floats) {
     if (!s) return fail(MI355_ERR_INVALID, "null scene");
     for (uint32_t i = 0; i < s->layout.size() && i < capacity; ++i) if (out) out[i] = s->layout[i];

@@ -99,6 +99,24 @@ class HipBackend:
     def param_total(self, scene):
         return scene_param_total(scene)
 
+    def enable_grads(self, scene, params):
+        """dr.backward() only visits the parameters whose gradients are enabled: when some geometry / IOR parameter of `params` carries a
+        gradient request (a tensor with requires_grad), the geometry adjoint fills the slots of exactly those and skips the others -- the
+        film plane and the housing of a lens-design scene are meshes too, and every light path ends on the film plane's two triangles
+        (166 ms of same-address float atomics per pass on the doublet).  With no request at all every slot is filled (explicit
+        `geometry=True` on plain tensors)."""
+        geo = [k for k, e in params._entries.items() if e[0] in (abi.PARAM_VERTEX_POSITIONS, abi.PARAM_BSDF_IOR)]
+        wanted = {k for k in geo if getattr(params._values[k], "requires_grad", False)}
+        state = getattr(scene, "_grad_enabled", None)
+        if state is None:
+            state = scene._grad_enabled = {}
+        for k in geo:
+            kind, index, _ = params._entries[k]
+            en = (not wanted) or any(getattr(params._values[q], "requires_grad", False) for q in geo if params._entries[q][:2] == (kind, index))
+            if state.get((kind, index), True) != en:
+                abi.check(abi.lib().mi355_scene_param_enable_grad(scene.handle(), kind, index, 1 if en else 0))
+                state[(kind, index)] = en
+
     def synchronize(self, device):
         _torch().cuda.current_stream(device).synchronize()
 
@@ -403,6 +421,8 @@ class ParticleTracerIntegrator(Integrator):
             p.flags |= abi.FLAG_GEOMETRY_GRADS
             if not colour:
                 p.flags |= abi.FLAG_SKIP_COLOUR_GRADS
+            if params is not None and hasattr(be, "enable_grads"):
+                be.enable_grads(scene, params)
         grads = params.grad_buffer(dev) if params is not None else torch.zeros(max(be.param_total(scene), 1), dtype=torch.float32, device=dev)
         multi = shard is not None and shard[1] > 1
         local = torch.zeros_like(grads) if multi else grads

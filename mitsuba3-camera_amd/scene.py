@@ -587,6 +587,7 @@ class Scene:
         if self._handle is not None:
             abi.lib().mi355_scene_destroy(self._handle)
             self._handle = None
+            self._grad_enabled = {}
 
     def __del__(self):
         try:

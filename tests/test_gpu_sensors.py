@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 
 from conftest import small_cbox
-from test_gpu_geometry import _compare, _shape_index
+from test_gpu_geometry import _compare, _disabled_blocks, _shape_index
 from test_lens_design_cpu import _doublet
 
 pytestmark = pytest.mark.gpu
@@ -221,7 +221,7 @@ def test_three_field_design_problem(mi, orc, torch_cuda):
         g = integ.render_backward(scene, params, torch.tensor(gin), sensor=sensor, seed=0, spp=spp, geometry=True).cpu().numpy()
         p.flags |= mi.abi.FLAG_GEOMETRY_GRADS
         g_ref = o.ptracer_backward(p, gin)
-        assert _compare(mi, g, g_ref, lay, 1e-3, 0.98) >= 4, sensor
+        assert _compare(mi, g, g_ref, lay, 1e-3, 0.98, _disabled_blocks(mi, params)) >= 4, sensor
     # each camera looks at ITS spot: the three images differ, and each holds light
     assert all(im.max() > 0 for im in images) and not np.allclose(images[0], images[2])
     # ---- (iii) the optimisation loop
@@ -229,6 +229,10 @@ def test_three_field_design_problem(mi, orc, torch_cuda):
     assert scene._handle is handle
     assert np.isfinite(losses).all() and min(losses[3:]) < losses[0], losses
     assert all(len(fs.losses) == 6 for fs in problem.field_sources)
+    # dr.backward() visits only the parameters whose gradients are enabled: the lens and baffle meshes (their vertices follow the optimised
+    # scalars), not the film plane or the housing -- every light path ends on the film plane's two triangles
+    assert float(params.grad("lens1.vertex_positions").abs().max()) > 0 and float(params.grad("film_plane.vertex_positions").abs().max()) == 0.0
+    assert float(params.grad("camera_housing_0.vertex_positions").abs().max()) == 0.0
     # a camera that was re-centred moved through the parameter, not through a rebuild
     fs = problem.field_sources[2]
     fs.camera_pos[0] -= 3 * fs.get_pixel_size(); fs.pos_changed = True; fs.update(params)
