@@ -178,12 +178,22 @@ def main():
         args.no_prb = args.no_prb or "prb" not in want; args.no_veach = args.no_veach or "veach" not in want
         args.no_ptracer = args.no_ptracer or "ptracer" not in want; args.no_lens = args.no_lens or "lens" not in want; args.no_cpu = args.no_cpu or "cpu" not in want
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as a torch.distributed.run child.
+        # Decided BEFORE this process makes any GPU call (torch is not even imported yet): a process that has touched the GPU must never be
+        # replaced or forked.  The parent only waits; rank 0's JSON line goes to the inherited stdout; the child's exit code is ours.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")

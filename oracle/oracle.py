@@ -80,6 +80,9 @@ def lib(abi):
     l.orc_ptracer_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int]
     l.orc_radical_inverse.restype = C.c_float
     l.orc_radical_inverse.argtypes = [C.c_uint32, C.c_uint64]
+    l.orc_geo_mesh_hit_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.orc_geo_plane_hit_jacobian.argtypes = [C.c_void_p] * 5
+    l.orc_vertex_normals.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     l.orc_select_sensor.restype = C.c_int
     l.orc_select_sensor.argtypes = [C.c_void_p, C.c_uint32]
     l.orc_scene_set_sensor.restype = C.c_int
@@ -247,6 +250,31 @@ class OracleScene:
         c = np.zeros(3, dtype=np.uint64)
         self.l.orc_get_counters(self.h, _p(c), 1 if reset else 0)
         return {"n_isect": int(c[0]), "n_shade": int(c[1]), "n_shadow": int(c[2])}
+
+
+def geo_mesh_hit_jacobian(l, tri, normals, o, d, flip=False):
+    """Value (15: p, ng, ns, sh_s, sh_t) and Jacobian (15 x 24: ray origin 3, direction 3, positions 9, normals 9) of the oracle's multi-dual
+    mesh hit (mi_oracle_geo.inc: md_mesh_hit)."""
+    tri = np.ascontiguousarray(tri, dtype=np.float32).reshape(9); o = np.ascontiguousarray(o, dtype=np.float32); d = np.ascontiguousarray(d, dtype=np.float32)
+    nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(9)
+    out = np.zeros(15 + 15 * 24, dtype=np.float64)
+    l.orc_geo_mesh_hit_jacobian(_p(tri), _p(nrm) if nrm is not None else None, 1 if flip else 0, _p(o), _p(d), _p(out))
+    return out[:15], out[15:].reshape(15, 24)
+
+
+def geo_plane_hit_jacobian(l, q, n, o, d):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (q, n, o, d)]
+    out = np.zeros(3 + 18, dtype=np.float64)
+    l.orc_geo_plane_hit_jacobian(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out))
+    return out[:3], out[3:].reshape(3, 6)
+
+
+def vertex_normals(l, positions, faces):
+    """Mesh::recompute_vertex_normals (mesh.cpp:321-413) of the oracle on caller buffers."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3); f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+    out = np.zeros_like(pos)
+    l.orc_vertex_normals(_p(pos), pos.shape[0], _p(f), f.shape[0], _p(out))
+    return out
 
 
 def unpack_hits(hits):

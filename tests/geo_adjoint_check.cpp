@@ -171,7 +171,100 @@ static void test_fresnel() {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The closed-form AD assertions the REFERENCE's own tests hold for Mesh::compute_surface_interaction -- src/render/tests/test_mesh.py --
+// restated for mesh_hit_adjoint (reverse mode) and, through the transpose, for what its forward-mode tests say.  The mesh is
+// resources/data/common/meshes/rectangle.obj: the square [-1, 1]^2 in z = 0; the asserted gradient vectors themselves disclose its layout
+// (test16, :536-640): vertex 0 = (1, -1, 0), 1 = (-1, 1, 0), 2 = (-1, -1, 0), 3 = (1, 1, 0), and the triangle under the ray at
+// (0.99999, 0.99999) is {0, 3, 1} (counter-clockwise seen from +z: its normal is +z).  atol 1e-5 as in the reference.
+static void expect(const char *what, const std::vector<double> &got, const std::vector<double> &want, double atol = 1e-5) {
+    // dr.allclose(a, b, rtol = 1e-5, atol): |a - b| <= atol + rtol |b|
+    double worst = 0; bool ok = true;
+    for (size_t i = 0; i < want.size(); ++i) { const double e = fabs(got[i] - want[i]); worst = std::max(worst, e); ok = ok && e <= atol + 1e-5 * fabs(want[i]); }
+    printf("%-76s max |got - reference| = %.3e %s\n", what, worst, ok ? "ok" : "FAIL");
+    if (!ok) g_fail = 1;
+}
+static void test_reference_mesh_assertions() {
+    const V3d P[4] = { mk<F>(1, -1, 0), mk<F>(-1, 1, 0), mk<F>(-1, -1, 0), mk<F>(1, 1, 0) };
+    const int tri[3] = { 0, 3, 1 };
+    for (int with_normals = 0; with_normals < 2; ++with_normals) {         // si.n (geometric) and si.sh_frame.n (interpolated vertex normals of the flat mesh)
+        Tri<F> t; t.p0 = P[tri[0]]; t.p1 = P[tri[1]]; t.p2 = P[tri[2]];
+        t.has_nrm = with_normals != 0; t.flip = false; t.has_uv = false; t.n0 = t.n1 = t.n2 = mk<F>(0, 0, 1); t.du0x = t.du0y = t.du1x = t.du1y = 0;
+        auto run = [&](V3d o, V3d d, Shade<F> a, V3d &ao, V3d &ad, std::vector<double> &gv, TriAdj<F> *raw = nullptr) {
+            ao = ad = mk<F>(0, 0, 0); TriAdj<F> ta; mesh_hit_adjoint(t, o, d, a, ao, ad, ta);
+            gv.assign(12, 0.0);
+            const V3d tp[3] = { ta.p0, ta.p1, ta.p2 };
+            for (int k = 0; k < 3; ++k) { gv[3 * tri[k]] = tp[k].x; gv[3 * tri[k] + 1] = tp[k].y; gv[3 * tri[k] + 2] = tp[k].z; }
+            if (raw) *raw = ta;
+        };
+        auto zero = []() { Shade<F> a; a.p = a.ng = a.ns = a.sh_s = a.sh_t = mk<F>(0, 0, 0); return a; };
+        V3d ao, ad; std::vector<double> gv;
+        if (!with_normals) {
+            // test14 (:427-452): dr.backward(si.p.x) -> grad(ray.o) = (1, 0, 0)
+            { Shade<F> a = zero(); a.p.x = 1; run(mk<F>(-0.3, -0.4, -10), mk<F>(0, 0, 1), a, ao, ad, gv);
+              expect("test_mesh.py:444-446  backward(si.p.x) -> grad(ray.o) = (1, 0, 0)", { ao.x, ao.y, ao.z }, { 1, 0, 0 }); 
+              // test13 (:380-424), forward: d si.p / d ray.o.x = (1, 0, 0) and d si.p / d ray.d.x = (10, 0, 0)  (= the x-columns of the transposes)
+              Shade<F> ay = zero(); ay.p.y = 1; V3d aoy, ady; std::vector<double> g2; run(mk<F>(-0.3, -0.4, -10), mk<F>(0, 0, 1), ay, aoy, ady, g2);
+              Shade<F> az = zero(); az.p.z = 1; V3d aoz, adz; run(mk<F>(-0.3, -0.4, -10), mk<F>(0, 0, 1), az, aoz, adz, g2);
+              expect("test_mesh.py:402-406  forward(ray.o.x) -> grad(si.p) = (1, 0, 0)", { ao.x, aoy.x, aoz.x }, { 1, 0, 0 });
+              expect("test_mesh.py:420-424  forward(ray.d.x) -> grad(si.p) = (10, 0, 0)", { ad.x, ady.x, adz.x }, { 10, 0, 0 });
+              // si.t = (si.p - ray.o) . ray.d for the unit direction (0, 0, 1): backward(si.t) -> grad(ray.o) = (0, 0, -1) (:448-452) is d(p.z - o.z) / d o
+              expect("test_mesh.py:448-452  backward(si.t) -> grad(ray.o) = (0, 0, -1)", { aoz.x, aoz.y, aoz.z - 1.0 }, { 0, 0, -1 });
+              // test15 (:455-531), forward over a rigid translation of ALL vertices: d si.t / d z = 1, d si.p / d z = (0, 0, 1)
+              run(mk<F>(-0.2, -0.3, -10), mk<F>(0, 0, 1), az, aoz, adz, g2);
+              expect("test_mesh.py:488-499  forward(translate z) -> grad(si.t) = 1, grad(si.p).z = 1", { g2[2] + g2[5] + g2[8] + g2[11] }, { 1 });
+              run(mk<F>(-0.2, -0.3, -10), mk<F>(0, 0, 1), a, ao, ad, g2);          // a.p = (1, 0, 0): a translation in x or y leaves p.x alone, in z too
+              expect("test_mesh.py:488-499  forward(translate x / y / z) -> grad(si.p).x = 0", { g2[0] + g2[3] + g2[6] + g2[9], g2[1] + g2[4] + g2[7] + g2[10], g2[2] + g2[5] + g2[8] + g2[11] }, { 0, 0, 0 }); }
+            // test16 (:536-640), the ray that hits the corner (vertex 3)
+            { Shade<F> a = zero(); a.p.z = 1; run(mk<F>(0.99999, 0.99999, -10), mk<F>(0, 0, 1), a, ao, ad, gv);
+              expect("test_mesh.py:566-577  backward(si.t) / backward(si.p.z) -> vertex 3 moves along z", gv, { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 }); }
+        }
+        {   Shade<F> a = zero(); (with_normals ? a.ns : a.ng).x = 1; run(mk<F>(0.99999, 0.99999, -10), mk<F>(0, 0, 1), a, ao, ad, gv);
+            TriAdj<F> raw; std::vector<double> g3; V3d o2, d2; run(mk<F>(0.99999, 0.99999, -10), mk<F>(0, 0, 1), a, o2, d2, g3, &raw);
+            if (with_normals) {
+                // the interpolated normal depends on the positions through the vertex normals: recompute_vertex_normals (mesh.cpp:376-413); vertex 3
+                // belongs to this triangle only, vertices 0 and 1 also to {0, 1, 2} whose normal does not change the derivative of a flat mesh's n3
+                const V3d aN[3] = { raw.n0, raw.n1, raw.n2 }; V3d av[3]; face_normal_terms_adj(t.p0, t.p1, t.p2, aN, av);
+                // n_i = normalize(sum of angle-weighted face normals): for the flat mesh |sum| = total angle at the vertex; vertex 3 (index 1 here) has pi / 2
+                const double ang_tot[3] = { M_PI / 2, M_PI / 2, M_PI / 2 };   // vertex 0: pi/4 + pi/4, vertex 3: pi/2, vertex 1: pi/4 + pi/4
+                std::vector<double> gn(12, 0.0);
+                for (int c = 0; c < 3; ++c) {                              // adjoint of normalize at a unit vector n = (0, 0, 1): (aN - n (n . aN)) / |sum|
+                    V3d an = aN[c]; an.z = 0; V3d an_s = an * (1.0 / ang_tot[c]); V3d aNc[3] = { mk<F>(0, 0, 0), mk<F>(0, 0, 0), mk<F>(0, 0, 0) }; aNc[c] = an_s;
+                    V3d avc[3]; face_normal_terms_adj(t.p0, t.p1, t.p2, aNc, avc);
+                    for (int k = 0; k < 3; ++k) { gn[3 * tri[k]] += avc[k].x; gn[3 * tri[k] + 1] += avc[k].y; gn[3 * tri[k] + 2] += avc[k].z; }
+                }
+                (void) av;
+                for (int i = 0; i < 12; ++i) g3[i] += gn[i];
+                expect("test_mesh.py:616-622  backward(si.sh_frame.n.x) -> rotate the right edge about y", g3, { 0, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0, -0.5 }, 2e-5);
+            } else
+                expect("test_mesh.py:600-606  backward(si.n.x) -> rotate the right edge about y", gv, { 0, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0, -0.5 });
+        }
+        if (!with_normals) { Shade<F> a = zero(); a.ng.y = 1; run(mk<F>(0.99999, 0.99999, -10), mk<F>(0, 0, 1), a, ao, ad, gv);
+            expect("test_mesh.py:608-614  backward(si.n.y) -> rotate the top edge about x", gv, { 0, 0, 0.5, 0, 0, 0, 0, 0, 0, 0, 0, -0.5 }); }
+    }
+    // src/shapes/tests/test_rectangle.py:116-171 (test06 / test07): the analytic rectangle (the unit square in z = 0) as a fixed plane
+    {   const V3d q = mk<F>(0, 0, 0), n = mk<F>(0, 0, 1), o = mk<F>(-0.3, -0.3, -10), d = mk<F>(0, 0, 1);
+        V3d ao[3], ad[3];
+        for (int c = 0; c < 3; ++c) { V3d ap = mk<F>(c == 0, c == 1, c == 2); ao[c] = ad[c] = mk<F>(0, 0, 0); plane_hit_adjoint(q, n, o, d, ap, ao[c], ad[c]); }
+        expect("test_rectangle.py:157-160 backward(si.p.x) -> grad(ray.o) = (1, 0, 0)", { ao[0].x, ao[0].y, ao[0].z }, { 1, 0, 0 });
+        expect("test_rectangle.py:162-166 backward(si.t) -> grad(ray.o) = (0, 0, -1)", { ao[2].x, ao[2].y, ao[2].z - 1.0 }, { 0, 0, -1 });
+        expect("test_rectangle.py:124-128 forward(ray.o.x) -> grad(si.p) = (1, 0, 0)", { ao[0].x, ao[1].x, ao[2].x }, { 1, 0, 0 });
+        expect("test_rectangle.py:130-134 forward(ray.o.y) -> grad(si.p) = (0, 1, 0)", { ao[0].y, ao[1].y, ao[2].y }, { 0, 1, 0 });
+        expect("test_rectangle.py:148-152 forward(ray.d.x) -> grad(si.p) = (10, 0, 0)", { ad[0].x, ad[1].x, ad[2].x }, { 10, 0, 0 });
+    }
+    // test04 (:74-98): the angle weighting of recompute_vertex_normals on the 5-vertex, 2-face mesh
+    {   const double a_ = 1.0, b_ = 0.5;
+        const V3d v[5] = { mk<F>(0, 0, 0), mk<F>(-a_, 1, 0), mk<F>(a_, 1, 0), mk<F>(-b_, 0, 1), mk<F>(b_, 0, 1) };
+        V3d n0, n1; double a0[3], a1[3];
+        face_normal_terms(v[0], v[1], v[2], n0, a0); face_normal_terms(v[0], v[3], v[4], n1, a1);
+        V3d s = n0 * a0[0] + n1 * a1[0]; s = s * (1.0 / sqrt(dot(s, s)));
+        V3d ref = mk<F>(0, 0, -1) * (M_PI / 2.0) + mk<F>(0, 1, 0) * acos(3.0 / 5.0); ref = ref * (1.0 / sqrt(dot(ref, ref)));
+        expect("test_mesh.py:74-98    angle-weighted vertex normal of the shared vertex", { s.x, s.y, s.z, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z }, { ref.x, ref.y, ref.z, 0, 0, -1, 0, 1, 0 }, 5e-4);
+    }
+}
+
 int main() {
+    test_reference_mesh_assertions();
     test_fresnel();
     for (int nrm = 0; nrm < 2; ++nrm) for (int flip = 0; flip < 2; ++flip) for (int uv = 0; uv < 2; ++uv) test_mesh_hit(nrm, flip, uv);
     test_plane_sphere();

@@ -415,3 +415,36 @@ def test_geometry_adjoint_with_samples_per_pass(mi, torch_cuda):
     rel = float((grads[-1] - grads[16]).norm() / grads[-1].norm())
     assert rel < 0.5, rel                                                                          # ... of the same estimator
     scene.release()
+
+
+def test_device_vertex_normals_follow_the_references_weighting_scheme(mi, orc, kats, torch_cuda):
+    """src/render/tests/test_mesh.py:74-98 (test04_normal_weighting_scheme) on the DEVICE: after a `vertex_positions` update k_vertex_normals
+    recomputes the normals (Mesh::parameters_changed -> recompute_vertex_normals, mesh.cpp:138-139, :376-413); the shading normal of a hit
+    next to each of the five vertices is the reference's angle-weighted normal (rtol 5e-4 as there)."""
+    import ctypes as C, math
+    torch = torch_cuda
+    K = kats["mesh_normal_weighting"]
+    pos = np.array(K["vertex_positions"], dtype=np.float32); faces = np.array(K["faces"], dtype=np.uint32)
+    d = {'type': 'scene', 'integrator': {'type': 'path', 'max_depth': 2},
+         'm': {'type': 'mesh', 'vertex_positions': pos + np.float32(0.25), 'faces': faces, 'compute_vertex_normals': True, 'bsdf': {'type': 'diffuse'}},
+         'sensor': {'type': 'perspective', 'film': {'type': 'hdrfilm', 'width': 4, 'height': 4}}}
+    scene = mi.load_dict(d); params = mi.traverse(scene)
+    params['m.vertex_positions'] = torch.tensor(pos.reshape(-1), device="cuda"); params.update()      # (loaded displaced: the update is what is tested)
+    n0, n1 = np.array(K["n0"], dtype=np.float64), np.array(K["n1"], dtype=np.float64)
+    n2 = n0 * (math.pi / 2) + n1 * math.acos(3.0 / 5.0); n2 /= np.linalg.norm(n2)
+    want = np.stack([n2, n0, n0, n1, n1])
+    rays = np.zeros((5, 8), dtype=np.float32)
+    for v in range(5):
+        f = 0 if v in (0, 1, 2) else 1
+        centroid = pos[faces[f]].mean(axis=0); target = pos[v] + 2e-5 * (centroid - pos[v])
+        nf = n0 if f == 0 else n1
+        rays[v, :3] = target + nf; rays[v, 3:6] = -nf; rays[v, 6] = 10.0
+    out = torch.empty((5, 24), device="cuda"); d_rays = torch.tensor(rays, device="cuda")
+    mi.abi.check(mi.abi.lib().mi355_debug_surface_interaction(scene.handle(), C.c_void_p(d_rays.data_ptr()), 5, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize(); si = out.cpu().numpy()
+    assert (si[:, 15].view(np.uint32) == 0).all()                          # every ray hit the mesh
+    assert np.allclose(si[:, 8:11], want, rtol=K["rtol"], atol=1e-4), si[:, 8:11]
+    o = orc.OracleScene(scene, mi.abi); o.set_param(mi.abi.PARAM_VERTEX_POSITIONS, 0, pos.reshape(-1))
+    _, si_ref = o.ray_intersect(rays, with_si=True)
+    assert np.allclose(si[:, 8:11], si_ref[:, 8:11], atol=2e-6)
+    scene.release()

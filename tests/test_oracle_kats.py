@@ -694,3 +694,71 @@ def test_lens_render_oracle(orc, mi):
 def small_cbox_for(mi, res):
     d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
     return d
+
+
+# ---- the geometry derivative, pinned by the closed-form AD assertions the reference's own tests hold ------------------------------
+def _allclose(a, b, atol, rtol=1e-5):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= atol + rtol * np.abs(b)))          # dr.allclose
+
+
+def test_mesh_hit_derivative_matches_the_references_ad_assertions(orc, mi, kats):
+    """src/render/tests/test_mesh.py:380-640 (test13 - test16) on the oracle's multi-dual mesh hit (oracle/mi_oracle_geo.inc: md_mesh_hit),
+    the function every geometry-gradient parity test of the device is compared with.  Columns of the Jacobian are the reference's forward
+    assertions, rows its backward ones.  Input order: ray origin 0-2, direction 3-5, the triangle's positions 6-14, its normals 15-23."""
+    K = kats["mesh_ad"]; l = orc.lib(mi.abi); atol = K["atol"]
+    V = np.array(K["vertices"], dtype=np.float32); tri = K["triangle"]; P = V[tri]
+
+    def vertex_grad(row):                                                    # a row of the Jacobian over the 3 positions -> the 12-vector of the mesh
+        g = np.zeros(12)
+        for k, v in enumerate(tri):
+            g[3 * v:3 * v + 3] = row[6 + 3 * k:9 + 3 * k]
+        return g
+    # test13 (:380-424) forward in the ray; test14 (:427-452) backward to the ray
+    c = K["ray_forward"]; val, J = orc.geo_mesh_hit_jacobian(l, P, None, c["o"], c["d"])
+    assert _allclose(J[0:3, 0], c["dp_dox"], atol) and _allclose(J[0:3, 3], c["dp_ddx"], atol)
+    dt_do = J[2, 0:3] - np.array([0, 0, 1.0])                               # si.t = (si.p - ray.o) . d for d = (0, 0, 1)
+    assert _allclose(dt_do[2], c["dt_doz"], atol)
+    c = K["ray_backward"]; val, J = orc.geo_mesh_hit_jacobian(l, P, None, c["o"], c["d"])
+    assert _allclose(J[0, 0:3], c["grad_o_of_px"], atol) and _allclose(J[2, 0:3] - np.array([0, 0, 1.0]), c["grad_o_of_t"], atol)
+    # test15 (:455-531): a rigid translation of all vertices along z moves si.t by 1 and si.p by (0, 0, 1)
+    c = K["params_forward"]; val, J = orc.geo_mesh_hit_jacobian(l, P, None, c["o"], c["d"])
+    dz = J[0:3, 8] + J[0:3, 11] + J[0:3, 14]
+    assert _allclose(dz, c["translate_z"]["dp"], atol) and _allclose(dz[2], c["translate_z"]["dt"], atol)
+    # test16 (:536-640): the ray that hits the corner
+    c = K["params_backward"]; val, J = orc.geo_mesh_hit_jacobian(l, P, None, c["o"], c["d"])
+    assert _allclose(vertex_grad(J[2]), c["grad_of_pz"], atol) and _allclose(vertex_grad(J[2]), c["grad_of_t"], atol)
+    assert _allclose(vertex_grad(J[3]), c["grad_of_nx"], atol) and _allclose(vertex_grad(J[4]), c["grad_of_ny"], atol)
+    # ... and the interpolated normal of the flat mesh with vertex normals that FOLLOW the positions (recompute_vertex_normals): the chain
+    # d sh_n / d n_i . d n_i / d positions; vertex 3 belongs to this triangle only, and for a flat mesh the other triangle's share of
+    # n_0 and n_1 drops out of the corner ray's derivative (its weights are 1e-5)
+    N = np.tile(np.array([0, 0, 1], dtype=np.float32), (3, 1))
+    val, Jn = orc.geo_mesh_hit_jacobian(l, P, N, c["o"], c["d"])
+    b = [1.0 - val[0] * 0 - 0, 0, 0]                                        # (weights are read off the Jacobian below)
+    # d sh_n / d n_k = b_k (I - n n^T) for unit normals; n_k = normalize(sum_f angle_f n_f): at vertex 3 only this face, angle pi / 2
+    w3 = Jn[6, 15 + 3 * 1]                                                  # d sh_n.x / d n_{vertex 3}.x = b_1 (vertex 3 is the triangle's second corner)
+    assert abs(w3 - 1.0) < 2e-5
+    g_sh_nx = vertex_grad(Jn[6]) + w3 * vertex_grad(J[3])                   # direct part (none: sh_n ignores positions at fixed normals) + through n_3 = the face normal
+    g_sh_ny = vertex_grad(Jn[7]) + w3 * vertex_grad(J[4])
+    assert _allclose(g_sh_nx, c["grad_of_sh_nx"], 2e-5) and _allclose(g_sh_ny, c["grad_of_sh_ny"], 2e-5)
+
+
+def test_plane_hit_derivative_matches_the_references_ad_assertions(orc, mi, kats):
+    """src/shapes/tests/test_rectangle.py:116-171 (test06 / test07) on the oracle's fixed-plane hit (rectangle / disk)."""
+    K = kats["rectangle_ad"]; l = orc.lib(mi.abi)
+    val, J = orc.geo_plane_hit_jacobian(l, [0, 0, 0], [0, 0, 1], K["o"], K["d"])
+    assert _allclose(J[:, 0], K["dp_dox"], 1e-5) and _allclose(J[:, 1], K["dp_doy"], 1e-5) and _allclose(J[:, 3], K["dp_ddx"], 1e-5)
+    assert _allclose(J[0, 0:3], K["grad_o_of_px"], 1e-5) and _allclose(J[2, 0:3] - np.array([0, 0, 1.0]), K["grad_o_of_t"], 1e-5)
+    assert _allclose((J[2, 0:3] - np.array([0, 0, 1.0]))[2], K["dt_doz"], 1e-5)
+
+
+def test_vertex_normal_weighting_scheme(orc, mi, kats):
+    """src/render/tests/test_mesh.py:74-98 (test04): angle-weighted vertex normals on the reference's 5-vertex / 2-face mesh -- the oracle's
+    recompute_vertex_normals and the host mirror's compute_vertex_normals (the device's k_vertex_normals: tests/test_gpu_geometry.py)."""
+    K = kats["mesh_normal_weighting"]; l = orc.lib(mi.abi)
+    pos = np.array(K["vertex_positions"], dtype=np.float32); faces = np.array(K["faces"], dtype=np.uint32)
+    n0, n1 = np.array(K["n0"], dtype=np.float64), np.array(K["n1"], dtype=np.float64)
+    n2 = n0 * (math.pi / 2) + n1 * math.acos(3.0 / 5.0); n2 /= np.linalg.norm(n2)
+    want = np.stack([n2, n0, n0, n1, n1])
+    for got in (orc.vertex_normals(l, pos, faces), mi.scene.compute_vertex_normals(pos, faces)):
+        assert np.allclose(got, want, rtol=K["rtol"], atol=1e-6), got
