@@ -212,6 +212,10 @@ typedef struct mi355_scene_desc {
                                           tile-sorted splat (same film up to summation order; a debugging / comparison switch -- Gaussian
                                           filter 234.6 ms against 7.1 ms on the Cornell box 512^2 x 64 spp) */
 
+#define MI355_FLAG_NO_LANE_SORT   256u /* particle tracer on scenes with BVH meshes: keep the natural order of the light samples instead of listing them
+                                          cell by cell of their emitter's sample domain (DESIGN.md "coherent lanes"; same samples, same film and gradients up
+                                          to the order of the float atomics -- an A/B switch) */
+
 enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path state in registers; the path integrator re-packs the
                                           live paths of a workgroup (wave ballot + prefix sum, SoA state exchanged through LDS) from
                                           bounce 2 on whenever that empties a whole wave */

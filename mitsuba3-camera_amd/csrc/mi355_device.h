@@ -2352,6 +2352,38 @@ MI_DEV SI si_from_position(v3 p, v3 n, int32_t shape) {                     // S
     si.wi = V3(0.f, 0.f, 1.f); si.prim = 0; si.shape = shape;
     return si;
 }
+// Where a light sample STARTS, as a sort key (k_pt_keys): the emitter it picks and the cell of the emitter's sample domain -- 2D position
+// sample, or position x direction for emitters that scatter their rays -- its ray leaves from.  Replays the sampler calls that precede
+// prepare_ray in ptracer_sample below (sample_visible_emitters draws 1 + [2 + 2] + 2 + [1] numbers, [..] for connectable emitters only)
+// on a COPY of the stream.  The key only decides which hardware lane walks which sample, never a result: were it out of step with
+// ptracer_sample, the render would be the same and merely less coherent.
+MI_DEV uint32_t morton_spread2(uint32_t x) { x &= 0xffffu; x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u; return x; }
+MI_DEV uint32_t morton_spread4(uint32_t x) { x &= 0xffu; x = (x | (x << 12)) & 0x000f000fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u; return x; }
+template <int FULL>
+MI_DEV uint32_t ptracer_emission_cell(const DScene &sc, Pcg32 rng, int32_t max_depth, bool hide_emitters, uint32_t bits, bool four_d) {
+    const bool timed = sc.shutter_open_time > 0.f;
+    if (max_depth != 0 && !hide_emitters) {
+        if (timed) (void) next_1d(rng);
+        float es = next_1d(rng), w; const uint32_t e0 = pick_emitter(sc, es, w);
+        const bool connect = !FULL || sc.emitters[e0].type == MI355_EMITTER_AREA;
+        const int skip = (connect ? 4 : 0) + 2 + (connect ? 1 : 0);
+        for (int k = 0; k < skip; ++k) (void) next_1d(rng);
+    }
+    if (timed) (void) next_1d(rng);
+    float wav = next_1d(rng), w; const uint32_t ei = pick_emitter(sc, wav, w);
+    const float ax = next_1d(rng), ay = next_1d(rng), bx = next_1d(rng), by = next_1d(rng);
+    const float scale = (float) (1u << bits);
+    const uint32_t qa = min((uint32_t) (ax * scale), (1u << bits) - 1u), qb = min((uint32_t) (ay * scale), (1u << bits) - 1u);
+    uint32_t cell;
+    if (four_d) {
+        const uint32_t qc = min((uint32_t) (bx * scale), (1u << bits) - 1u), qd = min((uint32_t) (by * scale), (1u << bits) - 1u);
+        cell = morton_spread4(qa) | (morton_spread4(qb) << 1) | (morton_spread4(qc) << 2) | (morton_spread4(qd) << 3);
+        return (ei << (4u * bits)) | cell;
+    }
+    cell = morton_spread2(qa) | (morton_spread2(qb) << 1);
+    return (ei << (2u * bits)) | cell;
+}
+
 template <int FULL, bool GRAD = false>
 MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                            float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr, const SplatQueue *queue = nullptr,

@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void k_exit_pupil(const float *lens, uint32_t 
 template <int FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT_WAVES_FULL) : (GRAD ? MI_PT_WAVES_GRAD_BASIC : MI_PT_WAVES_BASIC)) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
-                                                                 uint32_t n_small, uint32_t copy_shift, uint32_t all_params) {
+                                                                 uint32_t n_small, uint32_t copy_shift, uint32_t all_params, const uint32_t *order) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     extern __shared__ float s_grad_dyn[];
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < a.n_local;
-    const uint32_t ii = on ? i : 0u;
+    const uint32_t ii = on ? (order ? order[i] : i) : 0u;                  // which light sample this hardware lane walks (pt_sort_lanes)
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     Counters3 cnt = {};
@@ -909,17 +909,49 @@ __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT
 #define MI_GEO_FWD_WAVES 3                 // (forward design mode 12.1 -> 11.0 ms)
 #endif
 template <int FULL>
-__global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue) {
+__global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue, const uint32_t *order) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < a.n_local;
-    const uint32_t ii = on ? i : 0u;
+    const uint32_t ii = on ? (order ? order[i] : i) : 0u;
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     for (uint32_t pass = 0; pass < a.passes; ++pass)
         ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk, &queue);
+}
+
+// ---- coherent lanes for the light tracer (pt_sort_lanes) ---------------------------------------------------------------------------
+// Light samples are independent streams, so the 64 lanes of a wave start 64 unrelated rays and walk 64 unrelated subtrees of the scene
+// BVH (lens doublet: 54 % of the VALU lanes busy, 10-19 GB fetched per launch, profiles/r02_pmc_lens_summary.txt).  The ASSIGNMENT of
+// samples to hardware lanes is free, though: k_pt_keys gives every sample the cell of the emitter's sample domain its ray leaves from,
+// a counting sort over those cells (k_pt_keys histogram, k_pt_scan, k_pt_scatter) lists the samples cell by cell, and the tracing
+// kernels take their sample from that list -- the same samples, the same film and gradients up to the order of the float atomics, but a
+// wave now walks one neighbourhood of the BVH.
+template <int FULL>
+__global__ __launch_bounds__(256) void k_pt_keys(DScene sc, RenderArgs a, uint32_t bits, uint32_t four_d, uint32_t *keys, uint32_t *hist) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_local) return;
+    const uint32_t lane = shard_pixel(a, i / a.s_count) * a.spp_total + a.s_begin + i % a.s_count;
+    Pcg32 rng; sampler_seed(rng, a.seed, lane);
+    const uint32_t key = ptracer_emission_cell<FULL>(sc, rng, (int32_t) a.max_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, bits, four_d != 0u);
+    keys[i] = key; atomicAdd(hist + key, 1u);
+}
+// exclusive prefix sum of `n` bin counts (n <= 64 Ki) in one workgroup; cursor = a second copy of the offsets for the scatter pass
+__global__ __launch_bounds__(1024) void k_pt_scan(const uint32_t *hist, uint32_t *cursor, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u, b = threadIdx.x * per, e = min(b + per, n);
+    uint32_t sum = 0; for (uint32_t k = b; k < e; ++k) sum += hist[k];
+    part[threadIdx.x] = sum; __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u; __syncthreads(); part[threadIdx.x] += v; __syncthreads(); }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = b; k < e; ++k) { const uint32_t c = hist[k]; cursor[k] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_pt_scatter(const uint32_t *keys, uint32_t *cursor, uint32_t *order, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    order[atomicAdd(cursor + keys[i], 1u)] = i;
 }
 
 // ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------
@@ -1131,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 #endif
 template <int FULL>
 __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
-                                                               GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds) {
+                                                               GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds, const uint32_t *order) {
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     extern __shared__ float s_ior_dyn[];
     for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) s_ior_dyn[k] = 0.f;
@@ -1141,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DSc
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;                    // slot on the tape
     const uint32_t i = lane_first + t;
     const bool on = t < n_chunk && i < a.n_local;
-    const uint32_t ii = on ? i : 0u;
+    const uint32_t ii = on ? (order ? order[i] : i) : 0u;
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
     const GeoBwdSink sink = { grad_rgb, d_grad, d_nrm_adj, n_ior_lds ? s_ior_dyn : nullptr };
@@ -1441,6 +1473,7 @@ struct mi355_scene {
     float4 *d_rec_a = nullptr, *d_srt_a = nullptr; float *d_rec_b = nullptr, *d_srt_b = nullptr; uint32_t rec_capacity = 0;
     float4 *d_rec_c = nullptr, *d_srt_c = nullptr; float *d_rec_d = nullptr, *d_srt_d = nullptr; uint32_t rec2_capacity = 0;   // derivative splats: second record half
     uint32_t *d_tile_u32 = nullptr; uint32_t tile_capacity = 0; uint32_t splat_cap_override = 0;
+    uint32_t *d_pt_keys = nullptr, *d_pt_order = nullptr, *d_pt_bins = nullptr; uint32_t pt_order_capacity = 0;   // pt_sort_lanes: keys, sorted sample list, 2 x 64 Ki bins
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow, [4] redone backward workgroups
     uint64_t n_gen = 0, n_splat = 0;
     hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
@@ -2101,7 +2134,7 @@ extern "C" int mi355_scene_destroy(mi355_scene *s) {
     void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
                      s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_redo, s->d_area_cdf,
                      s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_rec_c, s->d_srt_c, s->d_rec_d, s->d_srt_d, s->d_tile_u32,
-                     s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape };
+                     s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape, s->d_pt_keys, s->d_pt_order, s->d_pt_bins };
     for (void *b : bufs) if (b) (void) hipFree(b);
     for (SensorSlot &sl : s->sensors) { if (sl.d_lens) (void) hipFree(sl.d_lens); if (sl.d_pupil) (void) hipFree(sl.d_pupil); }
     if (s->ev_created) for (int i = 0; i < MAX_EVENTS; ++i) { (void) hipEventDestroy(s->ev[i][0]); (void) hipEventDestroy(s->ev[i][1]); }
@@ -2460,6 +2493,37 @@ static int splat_queue_flush(mi355_scene *s, const SplatQueue &q, hipStream_t st
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }
+// Lists the launch's light samples cell by cell of their emitter's sample domain (see k_pt_keys).  *order = nullptr: lanes keep their
+// natural order -- scenes without a BVH (every lane tests the same flat primitives anyway), MI355_FLAG_NO_LANE_SORT, tiny launches.
+#define PT_SORT_MAX_BINS 65536u
+static int pt_sort_lanes(mi355_scene *s, const mi355_render_params *p, const RenderArgs &a, hipStream_t st, const uint32_t **order) {
+    *order = nullptr;
+    if ((p->flags & MI355_FLAG_NO_LANE_SORT) || s->ds.n_bvh_shapes == 0u || a.n_local < 16384u || s->emitters.empty()) return MI355_OK;
+    bool four_d = false; for (const DEmitter &e : s->emitters) four_d = four_d || e.type != MI355_EMITTER_DIRECTIONALAREA;
+    const uint32_t n_em = (uint32_t) s->emitters.size(), dims = four_d ? 4u : 2u;
+    uint32_t bits = 1;                                                      // cells of ~128 samples, at most 64 Ki bins over all emitters
+    while (bits < (four_d ? 4u : 8u) && (uint64_t) n_em << (dims * (bits + 1u)) <= PT_SORT_MAX_BINS && ((uint64_t) n_em << (dims * (bits + 1u))) * 128u <= a.n_local) ++bits;
+    const uint64_t bins64 = (uint64_t) n_em << (dims * bits);
+    if (bins64 > PT_SORT_MAX_BINS) return MI355_OK;                         // (more emitters than the bins hold: keep the natural order)
+    const uint32_t bins = (uint32_t) bins64;
+    if (s->pt_order_capacity < a.n_local) {
+        for (void *b : { (void *) s->d_pt_keys, (void *) s->d_pt_order }) if (b) HIP_TRY(hipFree(b));
+        s->d_pt_keys = s->d_pt_order = nullptr; s->pt_order_capacity = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_pt_keys, (size_t) a.n_local * 4)); HIP_TRY(hipMalloc((void **) &s->d_pt_order, (size_t) a.n_local * 4));
+        s->pt_order_capacity = a.n_local;
+    }
+    if (!s->d_pt_bins) HIP_TRY(hipMalloc((void **) &s->d_pt_bins, 2 * (size_t) PT_SORT_MAX_BINS * 4));
+    uint32_t *hist = s->d_pt_bins, *cursor = s->d_pt_bins + PT_SORT_MAX_BINS;
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t) bins * 4, st));
+    const dim3 g((a.n_local + 255u) / 256u);
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_pt_keys<true>, g, dim3(256), 0, st, s->ds, a, bits, four_d ? 1u : 0u, s->d_pt_keys, hist);
+    else hipLaunchKernelGGL(k_pt_keys<false>, g, dim3(256), 0, st, s->ds, a, bits, four_d ? 1u : 0u, s->d_pt_keys, hist);
+    hipLaunchKernelGGL(k_pt_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) hist, cursor, bins);
+    hipLaunchKernelGGL(k_pt_scatter, g, dim3(256), 0, st, (const uint32_t *) s->d_pt_keys, cursor, s->d_pt_order, a.n_local);
+    HIP_TRY(hipGetLastError());
+    *order = s->d_pt_order;
+    return MI355_OK;
+}
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
     Phase ph(PHASE_RENDER);
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
@@ -2481,9 +2545,10 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         // Reconstruction filters with more than one tap: deferred, tile-sorted splat (see film_put_deferred).  The queue holds every
         // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
         SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, false, q))) return rc;
-        if (flat) hipLaunchKernelGGL((k_ptracer<2, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
-        else if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
-        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u);
+        const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
+        if (flat) hipLaunchKernelGGL((k_ptracer<2, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
+        else if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
+        else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
         HIP_TRY(hipGetLastError());
         if ((rc = splat_queue_flush(s, q, st, false, d_film_rgbw))) return rc;
         if ((rc = tm.end())) return rc;
@@ -2626,8 +2691,9 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
     }
     GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel, ntan };
     SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, true, q))) return rc;
-    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q);
-    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q);
+    const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
+    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
     HIP_TRY(hipGetLastError());
     return splat_queue_flush(s, q, st, true, d_film_rgbw);
 }
@@ -2663,9 +2729,10 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         while (cs > 0 && (n_small_pt << cs) > 2048u) --cs;
         const uint32_t all = (p->flags & MI355_FLAG_EMITTER_GRADS_ONLY) ? 0u : 1u;
         const size_t dyn = (size_t) (n_small_pt << cs) * sizeof(float);
+        const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
         if (!((p->flags & MI355_FLAG_GEOMETRY_GRADS) && (p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))) {      // (a lens-design step asks for geometry / IOR gradients only)
-            if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
-            else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all);
+            if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all, order);
+            else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all, order);
             HIP_TRY(hipGetLastError());
         }
         if (p->flags & MI355_FLAG_GEOMETRY_GRADS) {                         // vertex positions and IORs: forward walk onto the path tape, backward sweep
@@ -2688,8 +2755,8 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
                 //  9.15 ms on the lens doublet: fused, a workgroup reads its tape rows back while they are still in L2)
                 for (uint32_t first = 0; first < a.n_local; first += chunk) {
                     const uint32_t n = std::min<uint32_t>(chunk, a.n_local - first); const dim3 g((n + BLOCK - 1) / BLOCK);
-                    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo_bwd<true>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior);
-                    else hipLaunchKernelGGL(k_ptracer_geo_bwd<false>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior);
+                    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo_bwd<true>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
+                    else hipLaunchKernelGGL(k_ptracer_geo_bwd<false>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
                 }
                 HIP_TRY(hipGetLastError());
                 for (uint32_t i = 0; i < s->shapes.size(); ++i) {           // vertex-normal adjoints -> positions, for normals that follow the positions

@@ -169,7 +169,7 @@ class Integrator:
         p.seed = (int(seed) + se.base_seed) & 0xffffffff                # sampler.cpp:120: m_base_seed + seed
         p.spp = int(spp)
         p.max_depth = self.max_depth; p.rr_depth = self.rr_depth
-        p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0) | (abi.FLAG_REGEN if getattr(self, "regen", False) else 0) | (abi.FLAG_TWO_PASS if getattr(self, "two_pass", False) else 0) | (abi.FLAG_DIRECT_SPLAT if getattr(self, "direct_splat", False) else 0)
+        p.flags = (abi.FLAG_HIDE_EMITTERS if self.hide_emitters else 0) | (abi.FLAG_TIMING if self.timing else 0) | (abi.FLAG_REGEN if getattr(self, "regen", False) else 0) | (abi.FLAG_TWO_PASS if getattr(self, "two_pass", False) else 0) | (abi.FLAG_DIRECT_SPLAT if getattr(self, "direct_splat", False) else 0) | (abi.FLAG_NO_LANE_SORT if getattr(self, "no_lane_sort", False) else 0)
         p.mode = self.mode; p.integrator = self.integrator_id
         spass = int(getattr(self, "samples_per_pass", -1))
         if spass not in (-1, 0, 0xffffffff) and int(spp) > 0:           # integrator.cpp:565-573

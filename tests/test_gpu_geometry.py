@@ -289,7 +289,7 @@ def test_lens_design_doublet(mi, orc, torch_cuda):
     lay, _ = o.param_layout()
     off_blocks = _disabled_blocks(mi, params)
     assert (mi.abi.PARAM_VERTEX_POSITIONS, _shape_index(scene, "film_plane")) in off_blocks          # the film plane's own vertices are not optimised
-    assert _compare(mi, g, g_ref, lay, 1e-3, 0.98, off_blocks) >= 4        # (tent filter: see the module docstring)
+    assert _compare(mi, g, g_ref, lay, 1e-3, 0.98, off_blocks) >= 3        # (the three lens surfaces; tent filter: see the module docstring)
     # ---- (ii) reverse mode . d(vertex)/d(scalar) == forward mode, for curvature, conic constant, position and a polynomial term
     e0 = system.elements[1]
     for name in ("c", "K", "z0", "a4", "a6"):
@@ -448,3 +448,27 @@ def test_device_vertex_normals_follow_the_references_weighting_scheme(mi, orc, k
     _, si_ref = o.ray_intersect(rays, with_si=True)
     assert np.allclose(si[:, 8:11], si_ref[:, 8:11], atol=2e-6)
     scene.release()
+
+
+def test_lane_sort_changes_nothing_but_the_order(mi, torch_cuda):
+    """pt_sort_lanes: listing the light samples cell by cell of their emitter's sample domain only changes WHICH hardware lane walks which
+    sample -- film, colour gradients and geometry gradients equal the natural order's up to the order of the float atomics, for one pass
+    and for samples_per_pass, for a collimated source (2D cells) and an area light (4D cells)."""
+    torch = torch_cuda
+    res, spp, seed = 32, 64, 3
+    for name, d in (("collimated", _cap_lens_scene(mi, res)), ("area", _geo_lens_scene(mi, 1.0, "glass", res))):
+        scene = mi.load_dict(d)
+        assert scene.info()["bvh_meshes"] >= 1
+        gin = torch.tensor(np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32), device="cuda")
+        out = {}
+        for per in (-1, 16):
+            for sort in (True, False):
+                integ = mi.ParticleTracerIntegrator({"max_depth": 5, "rr_depth": 5, "samples_per_pass": per}); integ.no_lane_sort = not sort
+                params = mi.traverse(scene)
+                img = integ.render(scene, seed=seed, spp=spp).clone()
+                g = integ.render_backward(scene, params, gin, seed=seed + 1, spp=spp, geometry=True, colour=True).clone()
+                out[(per, sort)] = (img, g)
+            (ia, ga), (ib, gb) = out[(per, True)], out[(per, False)]
+            assert float(ia.max()) > 0 and float((ia - ib).abs().max()) < 1e-5 * float(ib.max()), (name, per)
+            assert float((ga - gb).abs().max()) < 2e-4 * float(gb.abs().max()), (name, per, float((ga - gb).abs().max()) / float(gb.abs().max()))
+        scene.release()

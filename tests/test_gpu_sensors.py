@@ -221,7 +221,7 @@ def test_three_field_design_problem(mi, orc, torch_cuda):
         g = integ.render_backward(scene, params, torch.tensor(gin), sensor=sensor, seed=0, spp=spp, geometry=True).cpu().numpy()
         p.flags |= mi.abi.FLAG_GEOMETRY_GRADS
         g_ref = o.ptracer_backward(p, gin)
-        assert _compare(mi, g, g_ref, lay, 1e-3, 0.98, _disabled_blocks(mi, params)) >= 4, sensor
+        assert _compare(mi, g, g_ref, lay, 1e-3, 0.98, _disabled_blocks(mi, params)) >= 3, sensor      # (the three lens surfaces; the black baffles receive nothing)
     # each camera looks at ITS spot: the three images differ, and each holds light
     assert all(im.max() > 0 for im in images) and not np.allclose(images[0], images[2])
     # ---- (iii) the optimisation loop
