@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--no-lens", action="store_true", help="skip the BASELINE configs[4] leg (lens doublet, ptracer + geometry adjoint)")
     ap.add_argument("--lens-subdiv", type=int, default=7, help="icosphere level of the lens surface meshes (the notebook uses 7)")
     ap.add_argument("--only", default="", help="comma-separated legs to run besides the headline one: prb,veach,ptracer,lens,cpu (default: all)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the A/B launches inside the legs (profiling runs: one variant per kernel name)")
     ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
     ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
@@ -488,10 +489,12 @@ def main():
             per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
         r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)
         b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
-        il.no_lane_sort = True                          # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
-        ru_ms, ru_k = timed_l(lambda: il.render(scl, sensor=0, seed=0, spp=256, shard=lshard))
-        bu_ms, bu_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=0, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
-        il.no_lane_sort = False
+        ru_ms = ru_k = bu_ms = bu_k = None
+        if not args.no_ab:
+            il.no_lane_sort = True                      # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
+            ru_ms, ru_k = timed_l(lambda: il.render(scl, sensor=0, seed=0, spp=256, shard=lshard))
+            bu_ms, bu_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=0, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
+            il.no_lane_sort = False
         a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances (sensor 0)
         c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False, shard=lshard))
         u_ms, _ = timed_l(upd)

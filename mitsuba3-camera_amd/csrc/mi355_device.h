@@ -90,6 +90,47 @@ struct DPrimFin {    // (b1, b2) = A (s, t) + c for each of the two triangles of
 struct DBvh4 { float lo[3][4]; float hi[3][4]; uint32_t entry[4]; uint32_t pad[4]; };
 #define MI_BVH_EMPTY 0xffffffffu
 #define MI_BVH_LEAF 0x80000000u
+// What the traversal READS: the same node in 56 bytes (stride 64).  The light tracer's kernels on large meshes are bound by the data-return
+// path of the vector memory pipeline (TD busy 88 % of the launch on the lens doublet, profiles/r03_pmc_lens_mem.txt), and 8 of every
+// 10 cycles of it went into the 128-byte nodes.  Child boxes are quantised to 8 bits per plane against the box of all children:
+// plane = org[axis] + q * 2^e[axis] with a power-of-two step, so decoding is exact (one fma), and conservatively -- low planes rounded
+// down, high planes up.  DBvh4 stays as the refit's working copy (full precision bottom-up), DBvhQ is re-encoded from it node by node.
+//   dwordx4 #0: org.x org.y org.z exps (three biased exponents, one per byte)
+//   dwordx4 #1: qlo.x qlo.y qlo.z qhi.x        (one byte per child)
+//   dwordx4 #2: qhi.y qhi.z entry0 entry1
+//   dwordx2 #3: entry2 entry3
+struct DBvhQ { float org[3]; uint32_t exps; uint32_t qlo[3]; uint32_t qhi[3]; uint32_t entry[4]; uint32_t pad[2]; };
+static_assert(sizeof(DBvhQ) == 64, "DBvhQ is one 64-byte line");
+static inline __host__ __device__ void bvhq_encode(const DBvh4 &n, DBvhQ &q) {
+    for (int a = 0; a < 3; ++a) {
+        float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+        for (int c = 0; c < 4; ++c) if (n.entry[c] != MI_BVH_EMPTY) { lo = n.lo[a][c] < lo ? n.lo[a][c] : lo; hi = n.hi[a][c] > hi ? n.hi[a][c] : hi; }
+        if (!(hi >= lo)) { lo = 0.f; hi = 0.f; }                            // no child (never traversed) or non-finite boxes (never hit)
+        // step 2^e with 254 steps covering the extent (one step of head room for the outward rounding below)
+        int e = -126;
+        const float ext = hi - lo;
+        if (ext > 0.f && ext < __builtin_huge_valf()) { int ex; (void) __builtin_frexpf(ext / 254.f, &ex); e = ex; }   // ext / 254 = m 2^ex, m in [0.5, 1): 2^ex >= ext / 254
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        const float step = __builtin_ldexpf(1.f, e), inv = __builtin_ldexpf(1.f, -e);
+        uint32_t wl = 0, wh = 0;
+        for (int c = 0; c < 4; ++c) {
+            uint32_t ql = 0, qh = 0;
+            if (n.entry[c] != MI_BVH_EMPTY) {
+                float fl = __builtin_floorf((n.lo[a][c] - lo) * inv), fh = __builtin_ceilf((n.hi[a][c] - lo) * inv);
+                fl = fl < 0.f ? 0.f : (fl > 255.f ? 255.f : fl); fh = fh < 0.f ? 0.f : (fh > 255.f ? 255.f : fh);
+                ql = (uint32_t) fl; qh = (uint32_t) fh;
+                while (ql > 0u && __builtin_fmaf((float) ql, step, lo) > n.lo[a][c]) --ql;          // the DECODED plane must not lie inside the child's box
+                while (qh < 255u && __builtin_fmaf((float) qh, step, lo) < n.hi[a][c]) ++qh;
+            }
+            wl |= ql << (8 * c); wh |= qh << (8 * c);
+        }
+        q.org[a] = lo; q.qlo[a] = wl; q.qhi[a] = wh;
+        if (a == 0) q.exps = 0u;
+        q.exps |= (uint32_t) (e + 127) << (8 * a);
+    }
+    for (int c = 0; c < 4; ++c) q.entry[c] = n.entry[c];
+    q.pad[0] = q.pad[1] = 0u;
+}
 struct DBsdf {                       // 96 B
     uint32_t type; float reflectance[3]; int32_t texture; int32_t grad_slot;
     float alpha_u, alpha_v; uint32_t distribution, sample_visible;      // roughconductor.cpp:163-212
@@ -114,7 +155,7 @@ struct DScene {
     const float    *normals;      // 3 per vertex (zeros when the mesh has none)
     const float    *texcoords;    // 2 per vertex
     const float    *area_cdf;     // meshes: Mesh::build_pmf table (mesh.cpp:430-470), one float per face
-    const DBvh4 *bvh;             // node 0 = root (n_bvh_shapes != 0)
+    const DBvhQ *bvh;             // node 0 = root (n_bvh_shapes != 0); the quantised copy of the 4-wide tree
     const uint32_t *tri_shape;    // traversal slot -> shape index
     const DPrim    *prims;        // rectangles + every mesh of <= MI_FLAT_MAX triangles
     const DPrimFin *fins;
@@ -371,23 +412,22 @@ struct Bvh4Hits { float tn[4]; uint32_t e[4]; };
 // plane of the icosphere lens meshes: edges, and therefore box faces, lie exactly in it.  (ii) it is two VALU instructions per child and
 // axis less.
 MI_DEV Bvh4Hits bvh4_node(const DScene &sc, uint32_t node, const Ray &ray, v3 inv_d, float tmax) {
-    const float4 *n4 = reinterpret_cast<const float4 *>(sc.bvh + node);
+    const uint4 *n4 = reinterpret_cast<const uint4 *>(sc.bvh + node);
+    const uint4 w0 = n4[0], w1 = n4[1], w2 = n4[2]; const uint2 w3 = *reinterpret_cast<const uint2 *>(n4 + 3);
     Bvh4Hits h;
     float tn[4] = { 0.f, 0.f, 0.f, 0.f }, tf[4] = { tmax, tmax, tmax, tmax };
-    {   const bool neg = __float_as_uint(inv_d.x) >> 31; const float4 nr = n4[neg ? 3 : 0], fr = n4[neg ? 0 : 3];
-        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.x) * inv_d.x); tf[c] = fminf(tf[c], (u[c] - ray.o.x) * inv_d.x); } }
-    {   const bool neg = __float_as_uint(inv_d.y) >> 31; const float4 nr = n4[neg ? 4 : 1], fr = n4[neg ? 1 : 4];
-        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.y) * inv_d.y); tf[c] = fminf(tf[c], (u[c] - ray.o.y) * inv_d.y); } }
-    {   const bool neg = __float_as_uint(inv_d.z) >> 31; const float4 nr = n4[neg ? 5 : 2], fr = n4[neg ? 2 : 5];
-        const float l[4] = { nr.x, nr.y, nr.z, nr.w }, u[4] = { fr.x, fr.y, fr.z, fr.w };
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { tn[c] = fmaxf(tn[c], (l[c] - ray.o.z) * inv_d.z); tf[c] = fminf(tf[c], (u[c] - ray.o.z) * inv_d.z); } }
-    const uint4 en = *reinterpret_cast<const uint4 *>(n4 + 6);
-    h.e[0] = en.x; h.e[1] = en.y; h.e[2] = en.z; h.e[3] = en.w;
+#define MI_BVHQ_AXIS(ORG, EXPSHIFT, QLO, QHI, O, INV) { \
+        const bool neg = __float_as_uint(INV) >> 31; const uint32_t nr = neg ? (QHI) : (QLO), fr = neg ? (QLO) : (QHI); \
+        const float step = __uint_as_float(((w0.w >> (EXPSHIFT)) & 255u) << 23), org = __uint_as_float(ORG); \
+        tn[0] = fmaxf(tn[0], (fmaf((float) (nr & 255u), step, org) - (O)) * (INV)); tf[0] = fminf(tf[0], (fmaf((float) (fr & 255u), step, org) - (O)) * (INV)); \
+        tn[1] = fmaxf(tn[1], (fmaf((float) ((nr >> 8) & 255u), step, org) - (O)) * (INV)); tf[1] = fminf(tf[1], (fmaf((float) ((fr >> 8) & 255u), step, org) - (O)) * (INV)); \
+        tn[2] = fmaxf(tn[2], (fmaf((float) ((nr >> 16) & 255u), step, org) - (O)) * (INV)); tf[2] = fminf(tf[2], (fmaf((float) ((fr >> 16) & 255u), step, org) - (O)) * (INV)); \
+        tn[3] = fmaxf(tn[3], (fmaf((float) (nr >> 24), step, org) - (O)) * (INV)); tf[3] = fminf(tf[3], (fmaf((float) (fr >> 24), step, org) - (O)) * (INV)); }
+    MI_BVHQ_AXIS(w0.x, 0, w1.x, w1.w, ray.o.x, inv_d.x)
+    MI_BVHQ_AXIS(w0.y, 8, w1.y, w2.x, ray.o.y, inv_d.y)
+    MI_BVHQ_AXIS(w0.z, 16, w1.z, w2.y, ray.o.z, inv_d.z)
+#undef MI_BVHQ_AXIS
+    h.e[0] = w2.z; h.e[1] = w2.w; h.e[2] = w3.x; h.e[3] = w3.y;
 #pragma unroll
     for (int c = 0; c < 4; ++c) h.tn[c] = (h.e[c] != MI_BVH_EMPTY && tn[c] <= tf[c] * 1.00001f + 1e-6f) ? tn[c] : MI_INF;
     return h;

@@ -126,6 +126,14 @@ MI_DEV uint32_t shard_pixel(const RenderArgs &a, uint32_t q) {
 
 enum { OUT_FILM = 0, OUT_LANES = 1 };
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8), and every XCD has its own 4 MB L2.  When
+// consecutive workgroups work on NEIGHBOURING data (the sorted light samples of pt_sort_lanes), giving XCD k the k-th contiguous eighth
+// of the work instead of every eighth workgroup lets each L2 hold one eighth of the scene BVH instead of all of it.  The grid must be a
+// multiple of 8 workgroups (xcd_grid); logical blocks beyond the work are idle.
+#define MI_XCDS 8u
+MI_DEV uint32_t xcd_block(uint32_t b, uint32_t n_blocks) { return (b % MI_XCDS) * (n_blocks / MI_XCDS) + b / MI_XCDS; }
+static inline uint32_t xcd_grid(uint32_t n_blocks) { return (n_blocks + MI_XCDS - 1u) / MI_XCDS * MI_XCDS; }
+
 // lane bookkeeping shared by all sampling kernels: integrator.cpp:293-310
 struct LaneInfo { bool act; uint32_t lane; int32_t px, py; uint32_t pixel; };
 MI_DEV LaneInfo lane_info(const DScene &sc, const RenderArgs &a, uint32_t i) {
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = (order ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * BLOCK + threadIdx.x;     // sorted samples: one contiguous eighth per XCD
     const bool on = i < a.n_local;
     const uint32_t ii = on ? (order ? order[i] : i) : 0u;                  // which light sample this hardware lane walks (pt_sort_lanes)
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
@@ -913,7 +921,7 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene 
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = (order ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * BLOCK + threadIdx.x;
     const bool on = i < a.n_local;
     const uint32_t ii = on ? (order ? order[i] : i) : 0u;
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
@@ -1171,8 +1179,9 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DSc
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;                    // slot on the tape
-    const uint32_t i = lane_first + t;
-    const bool on = t < n_chunk && i < a.n_local;
+    const uint32_t tl = (order ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * BLOCK + threadIdx.x;    // sorted samples: one contiguous eighth of the chunk per XCD
+    const uint32_t i = lane_first + tl;
+    const bool on = tl < n_chunk && i < a.n_local;
     const uint32_t ii = on ? (order ? order[i] : i) : 0u;
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_mesh_tris(const float *positions, const
     tris[k] = t;
 }
 // ... and the child boxes refitted bottom-up, one launch per tree level (deepest first); topology and leaf contents are kept.
-__global__ __launch_bounds__(256) void k_bvh_refit_level(DBvh4 *nodes, const uint32_t *level_nodes, uint32_t n, const DTri *tris) {
+__global__ __launch_bounds__(256) void k_bvh_refit_level(DBvh4 *nodes, DBvhQ *qnodes, const uint32_t *level_nodes, uint32_t n, const DTri *tris) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t node = level_nodes[i];
@@ -1255,8 +1264,10 @@ __global__ __launch_bounds__(256) void k_bvh_refit_level(DBvh4 *nodes, const uin
             const DBvh4 ch = nodes[e];                                      // (a deeper level: refitted by an earlier launch)
             for (int k = 0; k < 4; ++k) if (ch.entry[k] != MI_BVH_EMPTY) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], ch.lo[a][k]); hi[a] = fmaxf(hi[a], ch.hi[a][k]); }
         }
-        for (int a = 0; a < 3; ++a) { nodes[node].lo[a][c] = lo[a]; nodes[node].hi[a][c] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { nd.lo[a][c] = lo[a]; nd.hi[a][c] = hi[a]; }
     }
+    nodes[node] = nd;
+    DBvhQ q; bvhq_encode(nd, q); qnodes[node] = q;                         // what the traversal reads
 }
 
 // HDRFilm::develop, hdrfilm.cpp:304-409
@@ -1465,7 +1476,7 @@ struct mi355_scene {
     // device buffers
     DShape *d_shapes = nullptr; DTri *d_tris = nullptr; uint32_t *d_faces = nullptr, *d_tri_face = nullptr, *d_bvh_shapes = nullptr;
     DPrim *d_prims = nullptr; DPrimFin *d_fins = nullptr; DBox *d_boxes = nullptr; DSphere *d_spheres = nullptr; float *d_area_cdf = nullptr; float *d_positions = nullptr, *d_normals = nullptr,
-          *d_texcoords = nullptr; DBvh4 *d_bvh = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
+          *d_texcoords = nullptr; DBvh4 *d_bvh = nullptr; DBvhQ *d_bvhq = nullptr; DBsdf *d_bsdfs = nullptr; DEmitter *d_emitters = nullptr;
     DTexture *d_textures = nullptr; float *d_texdata = nullptr; uint32_t *d_small_map = nullptr;
     float4 *d_gw = nullptr; size_t gw_pixels = 0;   // grad_in / W scratch (crop_h x crop_w of the largest film served)
     uint32_t *d_redo = nullptr; uint32_t redo_capacity = 0;   // per-workgroup "redo with the two-pass kernel" flags
@@ -2079,6 +2090,9 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     if ((rc = upload(&s->d_normals, s->normals))) return rc;
     if ((rc = upload(&s->d_texcoords, s->texcoords))) return rc;
     if ((rc = upload(&s->d_bvh, s->bvh))) return rc;
+    {   std::vector<DBvhQ> bq(s->bvh.size());                               // the quantised copy the kernels traverse
+        for (size_t k = 0; k < s->bvh.size(); ++k) bvhq_encode(s->bvh[k], bq[k]);
+        if ((rc = upload(&s->d_bvhq, bq))) return rc; }
     if ((rc = upload(&s->d_prims, prims_for_device(s->prims)))) return rc;
     if ((rc = upload(&s->d_fins, s->fins))) return rc;
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
@@ -2103,7 +2117,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     HIP_TRY(hipMalloc((void **) &s->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     ds.shapes = s->d_shapes; ds.tris = s->d_tris; ds.tri_face = s->d_tri_face; ds.tri_shape = s->d_tri_shape; ds.faces = s->d_faces; ds.positions = s->d_positions; ds.normals = s->d_normals;
-    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvh; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes; ds.boxes = s->d_boxes; ds.n_boxes = (uint32_t) s->boxes.size();
+    ds.texcoords = s->d_texcoords; ds.bvh = s->d_bvhq; ds.prims = s->d_prims; ds.fins = s->d_fins; ds.bvh_shapes = s->d_bvh_shapes; ds.boxes = s->d_boxes; ds.n_boxes = (uint32_t) s->boxes.size();
     ds.spheres = s->d_spheres; ds.n_spheres = (uint32_t) s->spheres.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
@@ -2131,7 +2145,7 @@ extern "C" int mi355_scene_create(const mi355_scene_desc *desc, int device, mi35
 extern "C" int mi355_scene_destroy(mi355_scene *s) {
     if (!s) return MI355_OK;
     (void) hipSetDevice(s->device);
-    void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bsdfs, s->d_emitters,
+    void *bufs[] = { s->d_shapes, s->d_tris, s->d_faces, s->d_positions, s->d_normals, s->d_texcoords, s->d_bvh, s->d_bvhq, s->d_bsdfs, s->d_emitters,
                      s->d_textures, s->d_texdata, s->d_small_map, s->d_counters, s->d_tri_face, s->d_prims, s->d_fins, s->d_bvh_shapes, s->d_boxes, s->d_gw, s->d_spheres, s->d_redo, s->d_area_cdf,
                      s->d_rec_a, s->d_srt_a, s->d_rec_b, s->d_srt_b, s->d_rec_c, s->d_srt_c, s->d_rec_d, s->d_srt_d, s->d_tile_u32,
                      s->d_vadj_off, s->d_vadj, s->d_nrm_len, s->d_nrm_adj, s->d_bvh_levels, s->d_tape, s->d_ntan, s->d_tri_shape, s->d_pt_keys, s->d_pt_order, s->d_pt_bins };
@@ -2220,7 +2234,7 @@ static int ensure_geometry(mi355_scene *s, hipStream_t st) {
                            (const uint32_t *) s->d_tri_shape, (const DShape *) s->d_shapes, nt, s->d_tris);
         for (size_t l = s->bvh_level_off.size() - 1; l-- > 0;) {
             const uint32_t b = s->bvh_level_off[l], n = s->bvh_level_off[l + 1] - b;
-            if (n) hipLaunchKernelGGL(k_bvh_refit_level, dim3((n + 255u) / 256u), dim3(256), 0, st, s->d_bvh, (const uint32_t *) (s->d_bvh_levels + b), n, (const DTri *) s->d_tris);
+            if (n) hipLaunchKernelGGL(k_bvh_refit_level, dim3((n + 255u) / 256u), dim3(256), 0, st, s->d_bvh, s->d_bvhq, (const uint32_t *) (s->d_bvh_levels + b), n, (const DTri *) s->d_tris);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -2546,6 +2560,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         // connection of the launch when max_depth bounds their number; beyond its capacity a record falls back to direct atomics.
         SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, false, q))) return rc;
         const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
+        if (order) grid.x = xcd_grid(grid.x);
         if (flat) hipLaunchKernelGGL((k_ptracer<2, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
         else if (full) hipLaunchKernelGGL((k_ptracer<true, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
         else hipLaunchKernelGGL((k_ptracer<false, false>), grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, (const float *) nullptr, (float *) nullptr, (const uint32_t *) nullptr, s->d_counters, q, 0u, 0u, 0u, order);
@@ -2692,8 +2707,9 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
     GeoTangent gt = { t->shape, t->shape != MI355_NONE ? t->d_vertex_tangent : nullptr, t->bsdf, d_rel, ntan };
     SplatQueue q; if ((rc = splat_queue_setup(s, p, a, st, true, q))) return rc;
     const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
-    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
-    else hipLaunchKernelGGL(k_ptracer_geo<false>, grid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
+    const dim3 ggrid(order ? xcd_grid(grid.x) : grid.x);
+    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo<true>, ggrid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
+    else hipLaunchKernelGGL(k_ptracer_geo<false>, ggrid, block, 0, st, s->ds, a, sample_scale, d_film_rgbw, gt, q, order);
     HIP_TRY(hipGetLastError());
     return splat_queue_flush(s, q, st, true, d_film_rgbw);
 }
@@ -2723,13 +2739,14 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
     if ((rc = tm.begin())) return rc;
     if (pt) {                                                               // Integrator::render_backward (integrator.cpp:65-84) over ptracer.cpp, radiances only
         const float sample_scale = (float) (s->ds.crop_w * s->ds.crop_h) / (float) ((uint64_t) p->spp * s->ds.film_w * s->ds.film_h);
-        const dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
+        dim3 pgrid((a.n_local + BLOCK - 1) / BLOCK), pblock(BLOCK);
         const uint32_t n_small_pt = (uint32_t) s->small_map.size();
         uint32_t cs = 5;                                                    // 32 bank-spread copies while they fit in 8 KB
         while (cs > 0 && (n_small_pt << cs) > 2048u) --cs;
         const uint32_t all = (p->flags & MI355_FLAG_EMITTER_GRADS_ONLY) ? 0u : 1u;
         const size_t dyn = (size_t) (n_small_pt << cs) * sizeof(float);
         const uint32_t *order; if ((rc = pt_sort_lanes(s, p, a, st, &order))) return rc;
+        if (order) pgrid.x = xcd_grid(pgrid.x);
         if (!((p->flags & MI355_FLAG_GEOMETRY_GRADS) && (p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))) {      // (a lens-design step asks for geometry / IOR gradients only)
             if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer<true, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all, order);
             else hipLaunchKernelGGL((k_ptracer<false, true>), pgrid, pblock, dyn, st, s->ds, a, sample_scale, (float *) nullptr, d_grad_in, d_grad_params, (const uint32_t *) s->d_small_map, s->d_counters, SplatQueue{}, n_small_pt, cs, all, order);
@@ -2741,7 +2758,8 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
             const uint32_t n_verts = p->max_depth > 1 ? (uint32_t) p->max_depth - 1u : 0u;
             if (n_verts) {
                 const uint32_t chunk = std::min<uint32_t>(a.n_local, 1u << 22);    // lanes per launch: bounds the tape at 18 dwords x vertices x 4 Mi lanes
-                const size_t need = (size_t) MI_TAPE_FIELDS * n_verts * chunk;
+                const uint32_t stride = xcd_grid((chunk + BLOCK - 1) / BLOCK) * BLOCK;     // one tape slot per HARDWARE lane of a launch (the grid is rounded up to 8 workgroups)
+                const size_t need = (size_t) MI_TAPE_FIELDS * n_verts * stride;
                 if (s->tape_floats < need) {
                     if (s->d_tape) HIP_TRY(hipFree(s->d_tape));
                     s->d_tape = nullptr; s->tape_floats = 0;
@@ -2750,11 +2768,11 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
                 const size_t nv_total = s->positions.size() / 3;
                 HIP_TRY(hipMemsetAsync(s->d_nrm_adj, 0, std::max<size_t>(nv_total, 1) * 3 * sizeof(float), st));
                 const uint32_t n_ior = s->bsdfs.size() <= 2048 ? 2u * (uint32_t) s->bsdfs.size() : 0u;
-                GeoTape tape = { s->d_tape, chunk };
+                GeoTape tape = { s->d_tape, stride };
                 // (walk and sweep as two kernels -- the walk at 3 waves per SIMD, the sweep without a traversal stack -- measured SLOWER, 10.7 against
                 //  9.15 ms on the lens doublet: fused, a workgroup reads its tape rows back while they are still in L2)
                 for (uint32_t first = 0; first < a.n_local; first += chunk) {
-                    const uint32_t n = std::min<uint32_t>(chunk, a.n_local - first); const dim3 g((n + BLOCK - 1) / BLOCK);
+                    const uint32_t n = std::min<uint32_t>(chunk, a.n_local - first); const dim3 g(order ? xcd_grid((n + BLOCK - 1) / BLOCK) : (n + BLOCK - 1) / BLOCK);
                     if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo_bwd<true>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
                     else hipLaunchKernelGGL(k_ptracer_geo_bwd<false>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
                 }

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --only ${LEGS:-prb} $*"
+ARGS="--steps 3 --warmup 1 --no-ab --only ${LEGS:-prb} $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 echo "stats exit $?"
 i=0
@@ -20,3 +20,7 @@ for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INS
   timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $R/bench.py $ARGS > $OUT/pass$i.log 2>&1
   echo "pass$i exit $?"
 done
+# summarise on the box and drop the raw per-dispatch CSVs (hundreds of MB: gpurun_out/ is merged back only below 64 MiB)
+python3 $R/tools/pmc_summary.py $OUT $OUT/summary.txt > /dev/null 2>&1
+echo "summary exit $?"
+rm -rf $OUT/pass[0-9]* $OUT/stats

@@ -3,6 +3,16 @@
 with the same numbers per kernel (bench.py reads the instruction counts and the HBM traffic of its roofline block from that file)."""
 import collections, csv, glob, json, os, sys
 
+def csrc_sha256():
+    """sha256 over the kernel sources this pass was taken from (bench.py compares it with the sources it runs: `pmc_stale`)."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "mitsuba3-camera_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main(d, out):
     lines = []
     stats = glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv"))
@@ -13,14 +23,14 @@ def main(d, out):
                 lines.append("%-60s calls=%s avg_ms=%.4f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
-    out_json = {"source": os.path.basename(os.path.normpath(d)), "kernels": {}}
+    out_json = {"source": os.path.basename(os.path.normpath(d)), "csrc_sha256": csrc_sha256(), "kernels": {}}
     if stats:
         for r in csv.DictReader(open(stats[0])):
             out_json["kernels"].setdefault(r["Name"].split("(")[0][-40:], {})["avg_ns"] = float(r["AverageNs"])
     for f in sorted(glob.glob(os.path.join(d, "pass*", "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][-40:]
-            if not ("k_render" in k or "k_prb" in k or "k_splat" in k or "k_ptracer" in k):
+            if not ("k_render" in k or "k_prb" in k or "k_splat" in k or "k_ptracer" in k or "k_pt_" in k):
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
