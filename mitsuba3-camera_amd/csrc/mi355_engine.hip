@@ -1185,10 +1185,18 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DSc
     const uint32_t ii = on ? (order ? order[i] : i) : 0u;
     const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
     Pcg32 rng; sampler_seed(rng, a.seed, lane);
-    const GeoBwdSink sink = { grad_rgb, d_grad, d_nrm_adj, n_ior_lds ? s_ior_dyn : nullptr };
-    for (uint32_t pass = 0; pass < a.passes; ++pass)
-        ptracer_sample_geo_bwd<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, stk, tape,
-                                     min(t, tape.stride - 1u), sink);
+    // the vertex-adjoint table of the sweep lives in the BVH stacks of the walk (FULL == 1: 4 x 8 KB): barriers keep the two apart
+    static_assert(FULL != 1 || STACK_FLOATS(1) >= 8 * (int) MI_VTAB, "the vertex-adjoint table must fit the traversal stacks");
+    const GeoBwdSink sink = { grad_rgb, d_grad, d_nrm_adj, n_ior_lds ? s_ior_dyn : nullptr, FULL == 1 ? reinterpret_cast<uint32_t *>(smem) : nullptr };
+    const uint32_t slot = min(t, tape.stride - 1u);
+    for (uint32_t pass = 0; pass < a.passes; ++pass) {
+        const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, stk, tape, slot);
+#ifndef MI_GEO_NO_SWEEP
+        if (FULL == 1) { __syncthreads(); vertex_adj_clear(sink.tab); __syncthreads(); }
+        ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, sink);
+        if (FULL == 1) { __syncthreads(); vertex_adj_flush(sink); __syncthreads(); }
+#endif
+    }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) {
         const float v = s_ior_dyn[k];

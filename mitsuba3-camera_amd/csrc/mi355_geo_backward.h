@@ -32,7 +32,62 @@ struct GeoBwdSink {
     float *d_grad;               // the concatenated parameter-gradient buffer
     float *d_nrm_adj;            // 3 floats per vertex of every mesh (DScene::normals layout): adjoint of the vertex normals
     float *s_ior;                // LDS: 2 floats per bsdf (adjoint of int_ior, ext_ior), or nullptr -> global atomics
+    uint32_t *tab;               // LDS: the workgroup's vertex-adjoint table (vertex_adj_add), or nullptr -> global atomics
 };
+
+// ---- vertex adjoints, summed per workgroup before they leave the CU ----------------------------------------------------------------
+// Every mesh-vertex hit scatters 18 floats (position and normal adjoints of the triangle's three corners).  As device-scope float atomics
+// those execute on the memory side of the fabric (8 XCDs, 8 L2s: an L2 cannot own the line), one ~47-byte HBM transaction each: on the lens
+// doublet 83 M of them per launch, 3.9 GB written for a 12 MB gradient, and 3.5 of the kernel's 6.8 ms (profiles/r03_lens_ab.txt: the same
+// build without the scatter takes 3.3 ms) -- and the sorted light samples make it worse, not better: the lanes of a wave hit the same few
+// triangles, i.e. the same addresses.  That is also the way out: a workgroup's 256 paths touch a few dozen distinct vertices, so they are
+// summed in an LDS hash table first (key = global vertex index; position adjoint 3 floats, normal adjoint 3 floats, SoA so that the six
+// adds of a lane fall into six different 4 KB planes) and one global atomic per (vertex, component) leaves at the end.  The table lives in
+// the traversal stack's LDS, which the backward sweep does not use; walk and sweep are separated by barriers (k_ptracer_geo_bwd).  A
+// vertex that finds no slot within MI_VTAB_PROBES steps goes out directly, as before.
+#define MI_VTAB_LOG2 10
+#define MI_VTAB (1u << MI_VTAB_LOG2)        // 1024 entries x 8 words = 32 KB = the four waves' BVH stacks (MI_BVH_STACK = 32)
+#define MI_VTAB_PROBES 8
+#define MI_VTAB_EMPTY 0xffffffffu
+MI_DEV void vertex_adj_add(const GeoBwdSink &sink, uint32_t vid, uint32_t gaddr, ga::V<float> ap, bool with_n, ga::V<float> an) {
+    if (sink.tab) {
+        uint32_t *keys = sink.tab, *addrs = sink.tab + MI_VTAB; float *vals = reinterpret_cast<float *>(sink.tab + 2u * MI_VTAB);
+        uint32_t h = (vid * 2654435761u) >> (32 - MI_VTAB_LOG2);
+        for (int probe = 0; probe < MI_VTAB_PROBES; ++probe, h = (h + 1u) & (MI_VTAB - 1u)) {
+            const uint32_t prev = atomicCAS(&keys[h], MI_VTAB_EMPTY, vid);
+            if (prev == MI_VTAB_EMPTY || prev == vid) {
+                if (prev == MI_VTAB_EMPTY) addrs[h] = gaddr;                 // (read only after the barrier in front of the flush)
+                atomicAdd(&vals[h], ap.x); atomicAdd(&vals[MI_VTAB + h], ap.y); atomicAdd(&vals[2u * MI_VTAB + h], ap.z);
+                if (with_n) { atomicAdd(&vals[3u * MI_VTAB + h], an.x); atomicAdd(&vals[4u * MI_VTAB + h], an.y); atomicAdd(&vals[5u * MI_VTAB + h], an.z); }
+                return;
+            }
+        }
+    }
+    float *g = sink.d_grad + gaddr;
+    atomicAdd(g, ap.x); atomicAdd(g + 1, ap.y); atomicAdd(g + 2, ap.z);
+    if (with_n) { float *gn = sink.d_nrm_adj + 3 * (size_t) vid; atomicAdd(gn, an.x); atomicAdd(gn + 1, an.y); atomicAdd(gn + 2, an.z); }
+}
+MI_DEV void vertex_adj_clear(uint32_t *tab) {                               // all 256 threads
+    for (uint32_t k = threadIdx.x; k < MI_VTAB; k += blockDim.x) {
+        tab[k] = MI_VTAB_EMPTY;
+#pragma unroll
+        for (uint32_t c = 0; c < 6u; ++c) tab[(2u + c) * MI_VTAB + k] = 0u;
+    }
+}
+MI_DEV void vertex_adj_flush(const GeoBwdSink &sink) {                      // all 256 threads, after a barrier
+    const uint32_t *keys = sink.tab, *addrs = sink.tab + MI_VTAB; const float *vals = reinterpret_cast<const float *>(sink.tab + 2u * MI_VTAB);
+    for (uint32_t k = threadIdx.x; k < MI_VTAB; k += blockDim.x) {
+        const uint32_t vid = keys[k];
+        if (vid == MI_VTAB_EMPTY) continue;
+        float *g = sink.d_grad + addrs[k], *gn = sink.d_nrm_adj + 3 * (size_t) vid;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            const float a = vals[c * MI_VTAB + k], b = vals[(3u + c) * MI_VTAB + k];
+            if (a != 0.f) atomicAdd(g + c, a);
+            if (b != 0.f) atomicAdd(gn + c, b);
+        }
+    }
+}
 
 typedef ga::V<float> gv3;
 MI_DEV gv3 G3(v3 a) { return ga::mk<float>(a.x, a.y, a.z); }
@@ -252,18 +307,16 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
             }
             ga::TriAdj<float> ta;
             ga::mesh_hit_adjoint(t, G3(r.o), G3(r.d), a, ao, ad, ta);
+#ifndef MI_GEO_NO_SCATTER                                                   // (attribution builds: tools/lens_ab.sh)
             if (sh.grad_offset != 0xffffffffu) {
-                float *g = sink.d_grad + sh.grad_offset;
-                atomicAdd(g + 3 * l0, ta.p0.x); atomicAdd(g + 3 * l0 + 1, ta.p0.y); atomicAdd(g + 3 * l0 + 2, ta.p0.z);
-                atomicAdd(g + 3 * l1, ta.p1.x); atomicAdd(g + 3 * l1 + 1, ta.p1.y); atomicAdd(g + 3 * l1 + 2, ta.p1.z);
-                atomicAdd(g + 3 * l2, ta.p2.x); atomicAdd(g + 3 * l2 + 1, ta.p2.y); atomicAdd(g + 3 * l2 + 2, ta.p2.z);
-                if (t.has_nrm && (sh.flags & DSHAPE_NRM_DEP)) {
-                    float *gn = sink.d_nrm_adj;
-                    atomicAdd(gn + 3 * (size_t) i0, ta.n0.x); atomicAdd(gn + 3 * (size_t) i0 + 1, ta.n0.y); atomicAdd(gn + 3 * (size_t) i0 + 2, ta.n0.z);
-                    atomicAdd(gn + 3 * (size_t) i1, ta.n1.x); atomicAdd(gn + 3 * (size_t) i1 + 1, ta.n1.y); atomicAdd(gn + 3 * (size_t) i1 + 2, ta.n1.z);
-                    atomicAdd(gn + 3 * (size_t) i2, ta.n2.x); atomicAdd(gn + 3 * (size_t) i2 + 1, ta.n2.y); atomicAdd(gn + 3 * (size_t) i2 + 2, ta.n2.z);
-                }
+                const bool wn = t.has_nrm && (sh.flags & DSHAPE_NRM_DEP);
+                vertex_adj_add(sink, i0, sh.grad_offset + 3u * l0, ta.p0, wn, ta.n0);
+                vertex_adj_add(sink, i1, sh.grad_offset + 3u * l1, ta.p1, wn, ta.n1);
+                vertex_adj_add(sink, i2, sh.grad_offset + 3u * l2, ta.p2, wn, ta.n2);
             }
+#else
+            if (ta.p0.x + ta.p1.y + ta.p2.z + ta.n0.x + ta.n1.y + ta.n2.z == 1.2345e33f) atomicAdd(sink.d_grad, 1.f);     // keep the adjoint arithmetic alive
+#endif
         } else if (FULL && sh.type == MI355_SHAPE_SPHERE) {
             ga::sphere_hit_adjoint(G3(ld3(sh.frame_s)), sh.frame_t[0], (sh.flags & DSHAPE_FLIP) != 0u, G3(r.o), G3(r.d), h.t, a.p, a.ns + a.ng, ao, ad);
         } else {                                                            // rectangle / disk: a fixed plane (frame taken as constant)
@@ -283,7 +336,9 @@ template <int FULL>
 MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                                    float sample_scale, uint32_t *stk, const GeoTape &tp, uint32_t lane, const GeoBwdSink &sink) {
     const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, max_depth, rr_depth, hide_emitters, lane_on, stk, tp, lane);
+#ifndef MI_GEO_NO_SWEEP
     ptracer_geo_sweep<FULL>(sc, sample_scale, tp, lane, nv, sink);
+#endif
 }
 
 // ---- vertex normals: Mesh::recompute_vertex_normals (mesh.cpp:376-413, JIT branch), as a per-vertex GATHER over the incident
