@@ -426,7 +426,9 @@ int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 /* How the replica's geometry was organised (cf. the accel statistics Scene logs, scene.cpp:108-118):
    out[0] flat parallelogram records, out[1] oriented-box records, out[2] meshes traversed through a BVH,
    out[3] BVH nodes, out[4] triangles, out[5] differentiable floats, out[6] analytic spheres,
-   out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres, 4: realisticlens sensor; any bit -> general kernels). */
+   out[7] feature bits (1: glossy / specular BSDFs, 2: analytic spheres / disks / directional emitters, 4: realisticlens sensor (of the sensor
+   selected last), 8: meshes traversed through the BVH, 16: more shape / bsdf / emitter records than the all-diffuse kernels stage in LDS;
+   any bit -> general kernels). */
 int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
 
 /* ---- device memory the engine allocates on its own (per scene handle, lazily, kept until mi355_scene_destroy) ---------------------

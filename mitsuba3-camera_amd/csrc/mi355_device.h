@@ -189,6 +189,48 @@ struct DScene {
     uint32_t sample_exit_pupil; float film_diagonal; const float *pupil;   // exit-pupil bounds, 64 x (min.x, min.y, max.x, max.y)
 };
 
+// Record tables in LDS (the north star's "BSDF params staged in LDS").  The BASIC kernel variants (FULL == 0: all-diffuse scenes of flat
+// primitives -- the headline configurations) stage the shape / bsdf / emitter / primitive-finish records once per workgroup (lt_fill,
+// 4.6 KB) and index them per lane with ds_read instead of per-lane global gathers: forward kernel 8.92 -> 8.71 ms on the Cornell box
+// (profiles/r03_occupancy_ab.txt).  A scene whose tables exceed the staging area runs the general kernels (features bit 4).
+// -DMI_LDS_TABLES=0 restores the global gathers everywhere (A/B).
+#ifndef MI_LDS_TABLES
+#define MI_LDS_TABLES 1
+#endif
+#define MI_LT_SHAPES 16
+#define MI_LT_BSDFS 8
+#define MI_LT_EMITTERS 4
+#define MI_LT_FINS 16
+#if MI_LDS_TABLES
+__shared__ __attribute__((aligned(16))) DShape g_lt_shapes[MI_LT_SHAPES];
+__shared__ __attribute__((aligned(16))) DBsdf g_lt_bsdfs[MI_LT_BSDFS];
+__shared__ __attribute__((aligned(16))) DEmitter g_lt_emitters[MI_LT_EMITTERS];
+__shared__ __attribute__((aligned(16))) DPrimFin g_lt_fins[MI_LT_FINS];
+#define MI_SC_SHAPE(sc, i) (*((FULL) == 0 ? &g_lt_shapes[i] : &(sc).shapes[i]))
+#define MI_SC_BSDF(sc, i) (*((FULL) == 0 ? &g_lt_bsdfs[i] : &(sc).bsdfs[i]))
+#define MI_SC_EMITTER(sc, i) (*((FULL) == 0 ? &g_lt_emitters[i] : &(sc).emitters[i]))
+#define MI_SC_FIN(sc, i) (*((FULL) == 0 ? &g_lt_fins[i] : &(sc).fins[i]))
+// all threads of the workgroup, at the top of every kernel that has a FULL == 0 instantiation; ends with a barrier.  The primitive-finish
+// table is copied whole: the host allocates at least MI_LT_FINS entries.
+static __device__ __forceinline__ void lt_fill(const DScene &sc) {
+    const uint32_t *src[4] = { (const uint32_t *) sc.shapes, (const uint32_t *) sc.bsdfs, (const uint32_t *) sc.emitters, (const uint32_t *) sc.fins };
+    uint32_t *dst[4] = { (uint32_t *) g_lt_shapes, (uint32_t *) g_lt_bsdfs, (uint32_t *) g_lt_emitters, (uint32_t *) g_lt_fins };
+    const uint32_t words[4] = { min(sc.n_shapes, (uint32_t) MI_LT_SHAPES) * (uint32_t) (sizeof(DShape) / 4), min(sc.n_bsdfs, (uint32_t) MI_LT_BSDFS) * (uint32_t) (sizeof(DBsdf) / 4),
+                                min(sc.n_emitters, (uint32_t) MI_LT_EMITTERS) * (uint32_t) (sizeof(DEmitter) / 4), (uint32_t) MI_LT_FINS * (uint32_t) (sizeof(DPrimFin) / 4) };
+    for (int t = 0; t < 4; ++t) for (uint32_t k = threadIdx.x; k < words[t]; k += blockDim.x) dst[t][k] = src[t][k];
+    __syncthreads();
+}
+#define MI_LT_FILL(FULL, sc) do { if ((FULL) == 0) lt_fill(sc); } while (0)
+#define MI_LT_BYTES ((uint32_t) (MI_LT_SHAPES * sizeof(DShape) + MI_LT_BSDFS * sizeof(DBsdf) + MI_LT_EMITTERS * sizeof(DEmitter) + MI_LT_FINS * sizeof(DPrimFin)))
+#else
+#define MI_SC_SHAPE(sc, i) ((sc).shapes[i])
+#define MI_SC_BSDF(sc, i) ((sc).bsdfs[i])
+#define MI_SC_EMITTER(sc, i) ((sc).emitters[i])
+#define MI_SC_FIN(sc, i) ((sc).fins[i])
+#define MI_LT_FILL(FULL, sc) do { } while (0)
+#define MI_LT_BYTES 0u
+#endif
+
 // -------------------------------------------------------------------------------------------
 // small vector math with Dr.Jit's operation order
 // -------------------------------------------------------------------------------------------
@@ -838,7 +880,7 @@ MI_DEV Hit scene_intersect(const DScene &sc, Ray ray, bool active, uint32_t *stk
             if (FULL && fin == MI_DISK_FIN) fin = 0xffffffffu;         // a disk keeps its local (x, y) like a rectangle
         }
         if (fin != 0xffffffffu) {
-            const DPrimFin &f = sc.fins[fin];
+            const DPrimFin &f = MI_SC_FIN(sc, fin);
             float b1 = fmaf(f.a[0], s, fmaf(f.a[1], u, f.a[2])), b2 = fmaf(f.a[3], s, fmaf(f.a[4], u, f.a[5]));
             hit.prim = f.tri_a;
             if (f.tri_b != f.tri_a && fminf(fminf(b1, b2), 1.f - b1 - b2) < 0.f) {
@@ -906,7 +948,7 @@ MI_DEV bool scene_ray_test(const DScene &sc, const Ray &ray, bool active, uint32
 template <int FULL>
 MI_DEV SI compute_si(const DScene &sc, const Ray &ray, const Hit &hit) {
     SI si; si.t = hit.t; si.shape = (int32_t) hit.shape; si.prim = hit.prim;
-    const DShape &sh = sc.shapes[hit.shape];                               // per-lane gather (divergent index)
+    const DShape &sh = MI_SC_SHAPE(sc, hit.shape);                         // per-lane gather (divergent index)
     v3 dp_du, dp_dv;
     if (sh.type == MI355_SHAPE_RECTANGLE) {
         si.p = ray_at(ray, hit.t);
@@ -1263,8 +1305,8 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
         index = min((uint32_t) scaled, sc.n_emitters - 1u);
         emitter_weight = cf; sx = scaled - (float) index;
     }
-    const DEmitter &em = sc.emitters[index];
-    const DShape &sh = sc.shapes[em.shape];
+    const DEmitter &em = MI_SC_EMITTER(sc, index);
+    const DShape &sh = MI_SC_SHAPE(sc, em.shape);
     ds.emitter = (int32_t) index;
     if (FULL && em.type != MI355_EMITTER_AREA) return false;               // DirectionalArea::sample_direction fails by design, directionalarea.cpp:126-130
     if (sh.type == MI355_SHAPE_RECTANGLE || sh.type == MI355_SHAPE_MESH || (FULL && sh.type == MI355_SHAPE_DISK)) {   // Shape::sample_direction, shape.cpp:358-375
@@ -1319,7 +1361,7 @@ MI_DEV bool sample_emitter_direction(const DScene &sc, const SI &si, float sx, f
 // Scene::pdf_emitter_direction (scene.cpp:355-366) -> area.cpp:170-197 -> shape.cpp:377-388
 template <int FULL>
 MI_DEV float pdf_emitter_direction(const DScene &sc, int32_t emitter, v3 ref_p, v3 d, v3 n, float dist) {
-    const DShape &sh = sc.shapes[sc.emitters[emitter].shape];
+    const DShape &sh = MI_SC_SHAPE(sc, MI_SC_EMITTER(sc, emitter).shape);
     float dp = dot3(d, n);
     if (!(dp < 0.f)) return 0.f;
     float adp = fabsf(dp), pdf;
@@ -1567,21 +1609,21 @@ MI_DEV bool path_step(const DScene &sc, PathState &st, uint32_t it, uint32_t max
     hit_any = si_valid;
     if (si_valid) {
         SI si = compute_si<FULL>(sc, st.ray, hit);
-        const DShape &sh = sc.shapes[hit.shape];
+        const DShape &sh = MI_SC_SHAPE(sc, hit.shape);
         int32_t emitter = sh.emitter;
         if (emitter >= 0) {                                                // path.cpp:158-174
             v3 rel = si.p - st.prev_p; float dist = norm3(rel); v3 d = rel * rcp_(dist);   // records.h:173-180
             bool prev_delta = FULL ? st.prev_delta : (it == 0);
             float em_pdf = prev_delta ? 0.f : pdf_emitter_direction<FULL>(sc, emitter, st.prev_p, d, si.sh_n, dist);
             float mis_bsdf = mis_weight(st.prev_bsdf_pdf, em_pdf);
-            v3 le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? ld3(sc.emitters[emitter].radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
+            v3 le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? ld3(MI_SC_EMITTER(sc, emitter).radiance) : V3(0.f, 0.f, 0.f);  // area.cpp:83-90
             st.result = fma3(st.throughput, le * mis_bsdf, st.result);
         }
         PROF(cnt, 1);
         // At the last vertex (it + 1 == max_depth, uniform over the wave) nothing below can change the result:
         // active_next is false for every lane, so no NEE contribution, no continuation (path.cpp:177-187).
         if (it + 1 < max_depth) {
-            const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
+            const DBsdf &bsdf = MI_SC_BSDF(sc, sh.bsdf);
             v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
             // ---- emitter sampling (path.cpp:186-208)
             float ex = next_1d(st.rng), ey = next_1d(st.rng);

@@ -218,6 +218,7 @@ MI_DEV void flush_counters(uint32_t *s_cnt, const Counters3 &cnt, unsigned long 
 template <int INTEGRATOR, int OUT, int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : MI_MIN_WAVES) void k_render(DScene sc, RenderArgs a, float *film, float *lanes_out,
                                                   unsigned long long *g_counters) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
@@ -341,6 +342,7 @@ MI_DEV void ring_flush(const DScene &sc, float *stage, const float *ring, uint32
 #endif
 template <int FULL>
 __global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? MI_REGEN_WAVES_FLAT : MI_MIN_WAVES)) void k_render_regen(DScene sc, RenderArgs a, float *__restrict__ film, unsigned long long *__restrict__ g_counters) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[WAVES * RG_WAVE_WORDS(FULL)];
     __shared__ float s_ring[WAVES * 5 * RING];
     __shared__ uint32_t s_cnt[4];
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(BLOCK, FULL == 1 ? 2 : (FULL ? MI_REGEN_WAVES_FLAT 
 #endif
 template <int INTEGRATOR, int FULL>
 __global__ __launch_bounds__(BLOCK, FULL == 2 ? MI_COMPACT_WAVES_FLAT : (FULL ? 4 : MI_MIN_WAVES)) void k_render_compact(DScene sc, RenderArgs a, float *film, unsigned long long *g_counters) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];         // BVH stack | compaction state | splat staging
     __shared__ float fin[4 * BLOCK];                                           // final (r, g, b, valid) per ORIGINAL slot
     __shared__ uint32_t s_cnt[4];
@@ -561,6 +564,7 @@ __global__ void k_prepare_grad(const float *grad_in, const float *weight, float4
 template <int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : 5) void k_render_forward(DScene sc, RenderArgs a, const float *tangent, const uint32_t *small_map,
                                                                                       float *film, unsigned long long *g_counters) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[REGION_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
@@ -592,6 +596,7 @@ template <int FULL>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_BWD) void k_prb_backward(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters, const uint32_t *redo) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     if (redo && !redo[blockIdx.x]) return;                                  // second launch: only the workgroups the one-pass kernel gave up on
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     __shared__ float s_grad[MAX_SMALL_GRAD];
@@ -663,6 +668,7 @@ template <int FULL, bool BVH>
 __global__ __launch_bounds__(BLOCK, FULL ? 3 : MI_MIN_WAVES_1P) void k_prb_backward_1p(DScene sc, RenderArgs a, const float4 *gw,
                                                         float *g_grad, const uint32_t *small_map, uint32_t n_small,
                                                         unsigned long long *g_counters, uint32_t *redo, uint32_t q_granules, uint32_t copy_shift) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     extern __shared__ __attribute__((aligned(16))) float4 dyn_lds[];        // [(n_small << copy_shift) rounded up to 4 floats][q_granules x 16 B]
     __shared__ __attribute__((aligned(16))) float smem[BVH ? WAVES * STACK_WORDS : 64];
     __shared__ float s_ltot[3 * BLOCK];
@@ -875,6 +881,7 @@ template <int FULL, bool GRAD>
 __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT_WAVES_FULL) : (GRAD ? MI_PT_WAVES_GRAD_BASIC : MI_PT_WAVES_BASIC)) void k_ptracer(DScene sc, RenderArgs a, float sample_scale, float *film, const float *grad_rgb, float *d_grad,
                                                                  const uint32_t *small_map, unsigned long long *g_counters, SplatQueue queue,
                                                                  uint32_t n_small, uint32_t copy_shift, uint32_t all_params, const uint32_t *order) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     __shared__ uint32_t s_cnt[4];
     extern __shared__ float s_grad_dyn[];
@@ -918,6 +925,7 @@ __global__ __launch_bounds__(BLOCK, FULL ? (GRAD ? MI_PT_WAVES_GRAD_FULL : MI_PT
 #endif
 template <int FULL>
 __global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene sc, RenderArgs a, float sample_scale, float *gfilm, GeoTangent gt, SplatQueue queue, const uint32_t *order) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
@@ -1172,6 +1180,7 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 template <int FULL>
 __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
                                                                GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds, const uint32_t *order) {
+    MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     extern __shared__ float s_ior_dyn[];
     for (uint32_t k = threadIdx.x; k < n_ior_lds; k += BLOCK) s_ior_dyn[k] = 0.f;
@@ -2102,7 +2111,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         for (size_t k = 0; k < s->bvh.size(); ++k) bvhq_encode(s->bvh[k], bq[k]);
         if ((rc = upload(&s->d_bvhq, bq))) return rc; }
     if ((rc = upload(&s->d_prims, prims_for_device(s->prims)))) return rc;
-    if ((rc = upload(&s->d_fins, s->fins))) return rc;
+    {   std::vector<DPrimFin> padded(s->fins); padded.resize(std::max<size_t>(padded.size(), MI_LT_FINS));     // lt_fill copies MI_LT_FINS entries whatever the count
+        if ((rc = upload(&s->d_fins, padded))) return rc; }
     if ((rc = upload(&s->d_boxes, s->boxes))) return rc;
     if ((rc = upload(&s->d_spheres, s->spheres))) return rc;
     if ((rc = upload(&s->d_area_cdf, s->area_cdf))) return rc;
@@ -2116,7 +2126,7 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
         HIP_TRY(hipMalloc((void **) &s->d_nrm_len, nv_total * sizeof(float))); HIP_TRY(hipMalloc((void **) &s->d_nrm_adj, nv_total * 3 * sizeof(float)));
         HIP_TRY(hipMemset(s->d_nrm_len, 0, nv_total * sizeof(float)));
     }
-    s->cap_prims = std::max<size_t>(s->prims.size(), 1); s->cap_fins = std::max<size_t>(s->fins.size(), 1); s->cap_boxes = std::max<size_t>(s->boxes.size(), 1);
+    s->cap_prims = std::max<size_t>(s->prims.size(), 1); s->cap_fins = std::max<size_t>(s->fins.size(), MI_LT_FINS); s->cap_boxes = std::max<size_t>(s->boxes.size(), 1);
     if ((rc = upload(&s->d_bsdfs, s->bsdfs))) return rc;
     if ((rc = upload(&s->d_emitters, s->emitters))) return rc;
     if ((rc = upload(&s->d_textures, s->textures))) return rc;
@@ -2129,6 +2139,8 @@ static int build_device_scene(mi355_scene *s, const mi355_scene_desc *d) {
     ds.spheres = s->d_spheres; ds.n_spheres = (uint32_t) s->spheres.size();
     ds.n_prims = (uint32_t) s->prims.size(); ds.n_bvh_shapes = (uint32_t) s->bvh_shapes.size(); ds.bsdfs = s->d_bsdfs; ds.emitters = s->d_emitters; ds.textures = s->d_textures;
     ds.texdata = s->d_texdata;
+    // record tables larger than the LDS staging area of the BASIC kernels (mi355_device.h, MI_LT_*): the general kernels read them from memory
+    if (MI_LDS_TABLES && (s->shapes.size() > MI_LT_SHAPES || s->bsdfs.size() > MI_LT_BSDFS || s->emitters.size() > MI_LT_EMITTERS || s->fins.size() > MI_LT_FINS)) ds.features |= 16u;
     // the sensors: each keeps its own share of the kernel argument; sensor 0 is selected
     s->base_features = ds.features;
     s->sensors.resize(d->n_sensors);
@@ -2200,6 +2212,7 @@ static int rebuild_flat_tables(mi355_scene *s) {
     if ((rc = reupload(&s->d_boxes, &s->cap_boxes, s->boxes))) return rc;
     s->ds.prims = s->d_prims; s->ds.fins = s->d_fins; s->ds.boxes = s->d_boxes;
     s->ds.n_prims = (uint32_t) s->prims.size(); s->ds.n_boxes = (uint32_t) s->boxes.size();
+    if (MI_LDS_TABLES && s->fins.size() > MI_LT_FINS && !(s->base_features & 16u)) { s->base_features |= 16u; s->ds.features |= 16u; }   // (a moved mesh may pair its triangles differently)
     return MI355_OK;
 }
 // Runs (once) before any call that traces rays: vertex normals, triangles, BVH boxes, flat tables, emitter tables of every mesh whose
@@ -2819,7 +2832,7 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         const bool bvh = s->ds.n_bvh_shapes != 0u;
         if (n_small > MAX_SMALL_GRAD) return fail(MI355_ERR_UNSUPPORTED, "too many constant parameters for the LDS accumulators");
         // dynamic LDS = small-parameter accumulators + record queue, sized so that 4 workgroups share a CU's 160 KB
-        const uint32_t static_lds = (bvh ? WAVES * STACK_WORDS * 4u : 256u) + 3u * BLOCK * 4u + 64u;
+        const uint32_t static_lds = (bvh ? WAVES * STACK_WORDS * 4u : 256u) + 3u * BLOCK * 4u + 64u + (full ? 0u : MI_LT_BYTES);   // BASIC: + the record tables staged in LDS
         uint32_t copy_shift = 5;                                            // 32 copies (one per LDS bank) while they fit in 8 KB
         while (copy_shift > 0 && (n_small << copy_shift) > 2048u) --copy_shift;
         const uint32_t small_bytes = (((n_small << copy_shift) + 3u) / 4u) * 16u + (((n_small << copy_shift) + 1u) / 2u) * 16u;   // fp32 accumulators + their 64-bit twins

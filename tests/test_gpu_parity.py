@@ -315,7 +315,7 @@ def veach64(mi):
 
 
 def test_veach_scene_intersect(mi, orc, torch_cuda, veach64):
-    assert veach64.info()["spheres"] == 5 and veach64.info()["features"] == 3
+    assert veach64.info()["spheres"] == 5 and veach64.info()["features"] & 15 == 3      # (bit 4: more records than the all-diffuse kernels stage in LDS -- irrelevant here)
     o = orc.OracleScene(veach64, mi.abi)
     rays = _rays_for(veach64, o, 8192, seed=5)
     rays[4096:, 0:3] *= 3.0                                    # random origins spread over the whole scene
