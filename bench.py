@@ -38,21 +38,51 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 PEAK_CLOCK_GHZ = 2.4        # MI355X peak engine clock (MI355X_MICROARCH.md)
 VALU_CYCLES_PEAK = 2.0      # cycles one SIMD needs per wave64 VALU instruction (guide); profiles/r02_valu_issue.json measures 2.2-2.5
 VALU_PEAK_GINST = N_SIMD * PEAK_CLOCK_GHZ / VALU_CYCLES_PEAK      # 1228.8 G wave64-instructions / s
-PMC_FILE = os.path.join("profiles", "r02_pmc_summary.json")      # tools/pmc.sh + tools/pmc_summary.py, committed
+# committed PMC passes (tools/pmc.sh + tools/pmc_summary.py), one per leg; each records the sha256 of the kernel sources it was taken from
+PMC_FILE = os.path.join("profiles", "r03_pmc_summary.json")                 # headline (C2) + prb (C3)
+PMC_FILES = {"veach": os.path.join("profiles", "r03_pmc_veach_summary.json"), "ptracer": os.path.join("profiles", "r03_pmc_ptracer_summary.json"),
+             "lens": os.path.join("profiles", "r03_pmc_lens_summary.json")}
 TILE_ROWS = 16
 
 
-def pmc_kernel(substr):
-    """Counters of one kernel from the committed PMC pass (None when the file or the kernel is missing)."""
-    try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
-            ks = json.load(f)["kernels"]
-        for name, rec in ks.items():
-            if substr in name and "counters" in rec:
-                return rec
-    except Exception:
-        pass
+def csrc_sha256():
+    """sha256 over the kernel sources of THIS checkout (same recipe as tools/pmc_summary.py): a PMC pass taken from other sources is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mitsuba3-camera_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+_PMC_CACHE = {}
+
+
+def pmc_load(pmc_file):
+    if pmc_file not in _PMC_CACHE:
+        try:
+            with open(os.path.join(ROOT, pmc_file)) as f:
+                _PMC_CACHE[pmc_file] = json.load(f)
+        except Exception:
+            _PMC_CACHE[pmc_file] = None
+    return _PMC_CACHE[pmc_file]
+
+
+def pmc_kernel(substr, pmc_file=None):
+    """Counters of one kernel from a committed PMC pass (None when the file or the kernel is missing)."""
+    d = pmc_load(pmc_file or PMC_FILE)
+    if d is None:
+        return None
+    for name, rec in d["kernels"].items():
+        if substr in name and "counters" in rec:
+            return rec
     return None
+
+
+def pmc_stale(pmc_file=None):
+    """True when the committed pass was taken from other kernel sources than the ones this run executes (or carries no hash)."""
+    d = pmc_load(pmc_file or PMC_FILE)
+    return d is None or d.get("csrc_sha256") != csrc_sha256()
 
 
 def microbench_cycles(waves=5):
@@ -104,21 +134,30 @@ def issue_model(c):
             "note": "latency-free schedule of this instruction mix per tools/valu_issue_bench.hip (profiles/r02_valu_issue.json): vector issue + transcendentals, scalar instructions hidden behind them up to the scalar unit's own rate"}
 
 
-def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes):
+def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes, pmc_file=None):
     """roofline block of a fused path kernel: bound = wave64 VALU issue.  Instruction count and HBM traffic per launch are read from
-    the committed PMC pass (scaled by lanes when this launch covers a different number of lanes than the profiled one), the time is the
-    HIP-event time measured in this run."""
-    rec = pmc_kernel(pmc_name)
+    the committed PMC pass of the leg (scaled by lanes when this launch covers a different number of lanes than the profiled one), the
+    time is the HIP-event time measured in this run.  A pass taken from other kernel sources than this checkout's is reported as
+    `pmc_stale` and no fraction is stated."""
+    pmc_file = pmc_file or PMC_FILE
+    rec = pmc_kernel(pmc_name, pmc_file)
     sec = kernel_ms * 1e-3
+    sustained = microbench("v_fma_f32", 8)                                   # wall-clock cycles (at the nominal clock) per wave64 VALU instruction the part sustains
     out = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Ginst/s (wave64 VALU)", "frac": None, "traffic": None,
-           "kernel": kernel, "kernel_ms": round(kernel_ms, 4)}
+           "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+           "peak_at_sustained_clock": round(VALU_PEAK_GINST * VALU_CYCLES_PEAK / sustained, 1) if sustained else None}
+    if rec is not None and pmc_stale(pmc_file):
+        out["pmc_stale"] = True
+        out["note"] = "%s was taken from other kernel sources than this checkout (sha256 of csrc/ differs): instruction counts not trusted, frac not stated; re-run tools/pmc.sh" % pmc_file
+        rec = None
     if rec is not None and sec > 0:
         c = rec["counters"]; scale = lanes_per_launch / float(rec["grid"])
         insts = c["SQ_INSTS_VALU"] * scale
         out.update({"achieved": round(insts / sec / 1e9, 1), "frac": round(insts / sec / 1e9 / VALU_PEAK_GINST, 4),
+                    "frac_of_peak_at_sustained_clock": round(insts / sec / 1e9 / (VALU_PEAK_GINST * VALU_CYCLES_PEAK / sustained), 4) if sustained else None,
                     "insts_per_launch": int(insts), "cycles_per_inst_measured": round(sec * PEAK_CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
                     "cycles_per_inst_peak": VALU_CYCLES_PEAK, "cycles_per_inst_microbench": microbench_cycles(),
-                    "pmc": {"file": PMC_FILE, "kernel": pmc_name, "lanes_profiled": int(rec["grid"]), "scaled_by_lanes": round(scale, 6),
+                    "pmc": {"file": pmc_file, "kernel": pmc_name, "lanes_profiled": int(rec["grid"]), "scaled_by_lanes": round(scale, 6),
                             "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "GRBM_GUI_ACTIVE": c.get("GRBM_GUI_ACTIVE"),
                             "cycles_per_inst_pmc": (round(c["GRBM_GUI_ACTIVE"] / 8 * N_SIMD / c["SQ_INSTS_VALU"], 3) if c.get("GRBM_GUI_ACTIVE") else None),
                             "waves": c.get("SQ_WAVES"), "insts_per_wave": {k[9:].lower(): round(c[k] / c["SQ_WAVES"], 1) for k in
@@ -135,8 +174,8 @@ def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes)
             out["traffic"] = int(traffic)
             out["hbm"] = {"traffic_measured": int(traffic), "read_bytes": [int(v * scale) for v in rec["hbm_read_bytes"]], "write_bytes": int(rec["hbm_write_bytes"] * scale),
                           "achieved_GBs": round(traffic / sec / 1e9, 1), "peak_GBs": HBM_PEAK_GBS, "frac_of_peak": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)}
-    else:
-        out["note"] = "no PMC record for this kernel in %s: instruction count unknown, frac not stated" % PMC_FILE
+    elif "note" not in out:
+        out["note"] = "no PMC record for this kernel in %s: instruction count unknown, frac not stated" % pmc_file
     out["contract"] = {"algorithmic_bytes_per_launch": int(contract_bytes), "GBs": round(contract_bytes / sec / 1e9, 1) if sec > 0 else None,
                        "note": "SURVEY.md 8(d) bytes of the unfused SoA wavefront formulation / kernel time; the fused kernel keeps that state in registers, so this is bookkeeping, not a bound"}
     return out
@@ -411,6 +450,9 @@ def main():
               "events_per_lane": {k: round(k4[k] / max(k4["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")},
               "variant": "regen" if i4.regen else "repack", "tuned_kernel_ms": {k: round(v, 2) for k, v in tuned4.items()},
               "finite": bool(torch.isfinite(film4).all().item())}
+        l4 = max(k4["kernel_launches"], 1)
+        c4["roofline"] = valu_roofline("k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>", "k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>",
+                                       k4["kernel_ms"] / l4, k4["n_gen"] / l4, algorithmic_bytes(k4, 1024 * 1024 * n4 / max(world, 1)) / l4, PMC_FILES["veach"])
         sc4.release()
 
     # ---- optional: particle tracer (forward part) -----------------------------------------------------
@@ -433,6 +475,12 @@ def main():
             pt[rf] = {"value": round(npix * args.prb_spp * n_pt / dtp / 1e6, 2), "unit": "Msamples/s (light paths)", "ms_per_step": round(dtp / n_pt * 1e3, 3),
                       "kernel_ms": round(kp["kernel_ms"] / max(kp["kernel_launches"], 1), 3),
                       "connections_per_lane": round(kp["n_shadow"] / max(kp["n_gen"], 1), 3), "finite": bool(torch.isfinite(imgp).all().item())}
+            if not rf.endswith("-direct"):
+                lp = max(kp["kernel_launches"], 1)
+                # 28 B ray + 20 B hit per intersection, 20 B per connection record written, sorted and read (x3); kernel_ms covers
+                # k_ptracer AND the four deferred-splat passes (the library brackets the whole call), the VALU count is k_ptracer's
+                pt[rf]["roofline"] = valu_roofline("k_ptracer<0, false> (+ k_splat_*)", "k_ptracer<0, false>", kp["kernel_ms"] / lp, kp["n_gen"] / lp,
+                                                   (48 * kp["n_isect"] + 60 * kp["n_shadow"]) / lp, PMC_FILES["ptracer"])
             if rf == "gaussian" and world == 1:      # the derivative passes of the light tracer on the same scene (timings only)
                 def timed(fn, n=3):
                     fn(); torch.cuda.synchronize(dev); t0 = time.perf_counter()
@@ -475,6 +523,7 @@ def main():
                 fn()
             torch.cuda.synchronize(dev); ms = (time.perf_counter() - t0) / n * 1e3
             c = il.counters(scl, reset=True)
+            timed_l.last = c
             return round(ms, 3), round(c["kernel_ms"] / max(c["kernel_launches"], 1), 3)
 
         def upd():
@@ -482,10 +531,20 @@ def main():
                 for key in (e.lens_key, e.baffle_key):
                     pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
             pl.update(); il.render(scl, seed=0, spp=1, shard=lshard)
-        per_sensor = []
+        per_sensor = []; lens_roof = {}
         for sidx in range(n_src):                       # every field's camera: the iteration renders and differentiates all three
             rs_ms, rs_k = timed_l(lambda: il.render(scl, sensor=sidx, seed=0, spp=256, shard=lshard))
+            cr = timed_l.last
             bs_ms, bs_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=sidx, seed=1, spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
+            if sidx == 0:
+                # kernel_ms brackets the whole call: lane sort (k_pt_keys / _scan / _scatter) + the tracing kernel (+ the deferred splat); the VALU
+                # count and the HBM bytes are the tracing kernel's.  Algorithmic bytes: render = 28 B ray + 20 B hit per
+                # intersection + 3 x 20 B per connection record; adjoint = 144 B of path tape (write + read) + 36 B of scattered triangle adjoint per vertex
+                lr_ = max(cr["kernel_launches"], 1); lanes_r = cr["n_gen"] / lr_
+                lens_roof["render"] = valu_roofline("k_ptracer<1, false> (+ k_pt_*, k_splat_*)", "k_ptracer<1, false>", rs_k, lanes_r, (48 * cr["n_isect"] + 60 * cr["n_shadow"]) / lr_, PMC_FILES["lens"])
+                lanes_b = 128 * 128 * 128 / max(world, 1)
+                lens_roof["geometry_adjoint"] = valu_roofline("k_ptracer_geo_bwd<1> (+ k_pt_*, k_vertex_normals_bwd)", "k_ptracer_geo_bwd<1>", bs_k, lanes_b,
+                                                              180.0 * cr["n_shade"] / max(cr["n_gen"], 1) * lanes_b, PMC_FILES["lens"])
             per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
         r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)
         b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
@@ -510,7 +569,7 @@ def main():
             tt = torch.tensor([r_ms, b_ms, a_ms, c_ms, u_ms, it_ms], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
         lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
-                "sensors": per_sensor, "sensor_edit_us": round(edit_us, 2),
+                "sensors": per_sensor, "roofline": lens_roof, "sensor_edit_us": round(edit_us, 2),
                 "unsorted_lanes_sensor0": {"render_256spp_ms": ru_ms, "render_kernels_ms": ru_k, "render_backward_geometry_ms": bu_ms, "render_backward_kernels_ms": bu_k}, "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
                 "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",
                 "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),

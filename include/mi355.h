@@ -420,6 +420,20 @@ int mi355_ptracer_forward_design(mi355_scene *scene, const mi355_render_params *
    The reference's `valid` = si.is_valid() & dr.allclose(0, si.p.z) -- one verdict for the whole wavefront -- is formed by the caller from [8], [9]. */
 int mi355_trace_rays(mi355_scene *scene, const float *d_rays, uint32_t n, uint32_t num_lenses, int32_t max_depth, float *d_out, void *stream);
 
+/* The lens-design loop's surface update (notebooks/scripts/lens_design/lens.py: EvenAsphericSurface.compute_z_dr :166-249, ConicSurface :55-97,
+   LensElement.update :509-568 -- Dr.Jit arithmetic in the reference, part of the AD graph of every design iteration): the sag of a conic / even
+   asphere in the scripts' dimensionless form, for every vertex of a surface mesh, and its transpose.
+     d_params          10 floats: c, K, z0, a4, a6, a8, a10, a12, a14, a16 (c and the a_i already multiplied by the powers of radial_extent the scripts use)
+     d_base_positions  n x 3: the mesh as it was created; x and y are kept
+     d_eval_xy         n x 2 points the sag is evaluated at, or NULL: the vertices' own (x, y).  (A baffle follows the surface's rim: every vertex
+                       evaluates at (radial_extent, 0), lens.py:553-565.)
+     mi355_lens_sag          d_positions (n x 3) = (x, y, z(eval point))
+     mi355_lens_sag_backward d_grad_params (10 floats, ACCUMULATED) += sum_i d_grad_positions[i].z * dz_i / d_params
+   Pure functions of their arguments on the current HIP device; no scene handle. */
+int mi355_lens_sag(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params, float *d_positions, void *stream);
+int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params,
+                            const float *d_grad_positions, float *d_grad_params, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 

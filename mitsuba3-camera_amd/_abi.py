@@ -114,6 +114,8 @@ SYMBOLS = [
     ("mi355_film_develop", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_scene_set_sensor", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SensorDesc)]),
     ("mi355_scene_sensor_count", C.c_int, [C.c_void_p]),
+    ("mi355_lens_sag", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355_lens_sag_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_trace_rays", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("mi355_render", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_prb_splat_weights", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),

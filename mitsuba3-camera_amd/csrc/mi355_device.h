@@ -1970,11 +1970,15 @@ MI_DEV bool prb_primal_step(const DScene &sc, PathState &st, uint32_t it, uint32
 // the fp32 sum it replaces.  The two are added when the workgroup publishes.
 struct GradSink1 { float *s_grad; uint32_t copy_shift; float4 *q; uint32_t *qn; uint32_t qcap; uint32_t *overflow; bool have_tex_grad;
                    unsigned long long *s_fix; float fix_scale, fix_limit; };
-// x (already scaled, |x| < 2^50) -> 64-bit two's complement without a 64-bit conversion: hi = floor(x / 2^32) fits an int, the rest is in [0, 2^32)
+// x (already scaled, |x| < 2^50) -> 64-bit two's complement without a 64-bit conversion.  The MAGNITUDE is split -- hi = floor(|x| / 2^32)
+// fits an int, lo = |x| - hi 2^32 is in [0, 2^32) and exact (|x| has 24 significant bits, lo keeps its low ones) -- and the sign is applied in
+// integer arithmetic: splitting x itself gave a negative |x| < 2^32 the low word 2^32 + x, which a float only holds to 256 quanta.
 MI_DEV unsigned long long fix_from_float(float x) {
-    const float hi = floorf(x * 2.3283064365386963e-10f);                   // 2^-32
-    const float lo = fmaf(hi, -4294967296.f, x);                            // exact: x has 24 significant bits
-    return ((unsigned long long) (uint32_t) (int32_t) hi << 32) | (unsigned long long) (uint32_t) lo;   // (uint32_t) lo saturates at 2^32 - 1: one quantum
+    const float ax = fabsf(x);
+    const float hi = floorf(ax * 2.3283064365386963e-10f);                  // 2^-32
+    const float lo = fmaf(hi, -4294967296.f, ax);
+    const unsigned long long mag = ((unsigned long long) (uint32_t) hi << 32) | (unsigned long long) (uint32_t) lo;
+    return x < 0.f ? 0ull - mag : mag;
 }
 MI_DEV float fix_to_float(unsigned long long v, float inv_scale) { return (float) (long long) v * inv_scale; }
 MI_DEV void small_grad_add(const GradSink1 &sink, int32_t slot, v3 g) {

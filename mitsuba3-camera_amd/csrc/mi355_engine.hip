@@ -1287,6 +1287,57 @@ __global__ __launch_bounds__(256) void k_bvh_refit_level(DBvh4 *nodes, DBvhQ *qn
     DBvhQ q; bvhq_encode(nd, q); qnodes[node] = q;                         // what the traversal reads
 }
 
+// ---- the lens-design loop's surface update on the device ---------------------------------------------------------------------------
+// EvenAsphericSurface.compute_z_dr of the fork's scripts (notebooks/scripts/lens_design/lens.py:166-249; a ConicSurface, :55-97, is the
+// same with zero polynomial terms) in its dimensionless form: with r2 = (x^2 + y^2) / R^2,
+//     z = z0 - R r2 ( r2 (a4 + a6 r2 + ... + a16 r2^6) + c / (1 + sqrt(max(1 - (1 + K) c^2 r2, 0))) )
+// evaluated for every vertex of a surface mesh (LensElement.update, lens.py:509-568: new position = (x0, y0, z(x0, y0))) -- and its
+// transpose: d loss / d (c, K, z0, a4 .. a16) from d loss / d positions.  In the reference both are Dr.Jit arithmetic traced into the
+// render's AD graph; here they were ~300 tiny torch launches per design iteration (profiles/r03_iter_profile.txt).
+// p = (c, K, z0, a4, a6, a8, a10, a12, a14, a16), 10 floats of device memory.
+struct SagPoint { float z, d[10]; };
+MI_DEV SagPoint sag_eval(const float *p, float R, float x, float y, bool want_grad) {
+    const float c = p[0], K = p[1], z0 = p[2], r2 = (x * x + y * y) * (1.f / (R * R));
+    float poly = p[9];
+#pragma unroll
+    for (int k = 8; k >= 3; --k) poly = fmaf(poly, r2, p[k]);
+    const float safe = fmaxf(1.f - (1.f + K) * c * c * r2, 0.f), sq = sqrtf(safe), den = 1.f / (1.f + sq);
+    const float zz = fmaf(poly, r2, c * den);
+    SagPoint o; o.z = fmaf(zz, -R * r2, z0);
+    if (want_grad) {
+        const float g = -R * r2, ds = safe > 0.f ? 1.f / sq : 0.f;          // d sqrt / d safe * 2 (0 where the clamp is active)
+        o.d[0] = g * (den + c * c * (1.f + K) * r2 * ds * den * den);       // d/dc [c / (1 + s)],  ds/dc = -(1 + K) c r2 / s
+        o.d[1] = g * (0.5f * c * c * c * r2 * ds * den * den);              // ds/dK = -c^2 r2 / (2 s)
+        o.d[2] = 1.f;
+        float pw = g * r2;                                                  // d/da_(4 + 2j) = -R r2 * r2^(j + 1)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { o.d[3 + j] = pw; pw *= r2; }
+    }
+    return o;
+}
+// out[i] = (base[i].x, base[i].y, z(eval[i])): a lens mesh evaluates at its own (x, y); a baffle at the rim point (R, 0) for every vertex
+__global__ __launch_bounds__(256) void k_lens_sag(const float *eval_xy, const float *base, uint32_t n, float R, const float *p, float *out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float x = eval_xy ? eval_xy[2 * (size_t) i] : base[3 * (size_t) i], y = eval_xy ? eval_xy[2 * (size_t) i + 1] : base[3 * (size_t) i + 1];
+    out[3 * (size_t) i] = base[3 * (size_t) i]; out[3 * (size_t) i + 1] = base[3 * (size_t) i + 1]; out[3 * (size_t) i + 2] = sag_eval(p, R, x, y, false).z;
+}
+__global__ __launch_bounds__(256) void k_lens_sag_bwd(const float *eval_xy, const float *base, uint32_t n, float R, const float *p, const float *grad_pos, float *grad_p) {
+    __shared__ float s_acc[10];
+    if (threadIdx.x < 10) s_acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    float gz = 0.f; SagPoint sp; for (int k = 0; k < 10; ++k) sp.d[k] = 0.f;
+    if (i < n) {
+        const float x = eval_xy ? eval_xy[2 * (size_t) i] : base[3 * (size_t) i], y = eval_xy ? eval_xy[2 * (size_t) i + 1] : base[3 * (size_t) i + 1];
+        sp = sag_eval(p, R, x, y, true); gz = grad_pos[3 * (size_t) i + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { const float v = wave_sum(sp.d[k] * gz); if ((threadIdx.x & 63u) == 0u && v != 0.f) atomicAdd(&s_acc[k], v); }
+    __syncthreads();
+    if (threadIdx.x < 10 && s_acc[threadIdx.x] != 0.f) atomicAdd(grad_p + threadIdx.x, s_acc[threadIdx.x]);
+}
+
 // HDRFilm::develop, hdrfilm.cpp:304-409
 __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2939,6 +2990,23 @@ extern "C" int mi355_debug_texture_eval(mi355_scene *s, uint32_t texture, const 
     HIP_TRY(hipSetDevice(s->device));
     if (!n) return MI355_OK;
     hipLaunchKernelGGL(k_debug_texture, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t) stream, s->ds, texture, d_uv, n, d_rgb);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_lens_sag(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params, float *d_positions, void *stream) {
+    if (!d_base_positions || !d_params || !d_positions) return fail(MI355_ERR_INVALID, "null argument");
+    if (!(radial_extent > 0.f)) return fail(MI355_ERR_INVALID, "radial_extent must be positive");
+    if (!n) return MI355_OK;
+    hipLaunchKernelGGL(k_lens_sag, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t) stream, d_eval_xy, d_base_positions, n, radial_extent, d_params, d_positions);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params,
+                                       const float *d_grad_positions, float *d_grad_params, void *stream) {
+    if (!d_base_positions || !d_params || !d_grad_positions || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
+    if (!(radial_extent > 0.f)) return fail(MI355_ERR_INVALID, "radial_extent must be positive");
+    if (!n) return MI355_OK;
+    hipLaunchKernelGGL(k_lens_sag_bwd, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t) stream, d_eval_xy, d_base_positions, n, radial_extent, d_params, d_grad_positions, d_grad_params);
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

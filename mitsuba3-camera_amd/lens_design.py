@@ -332,13 +332,63 @@ class LensElement:
         if ext_params is not None:
             for k, v in ext_params.items():
                 self.surface.params[k] = v
-        x0, y0 = self.initial_lens_vertices[:, 0], self.initial_lens_vertices[:, 1]
-        new_pos = torch.stack([x0, y0, self.surface.compute_z(x0, y0)], dim=1)
-        params['%s.vertex_positions' % self.lens_key] = new_pos.reshape(-1)
-        # the baffle follows the surface's rim in z (lens.py:553-565)
-        rim = self.surface.compute_z(torch.full((1,), self.surface.radial_extent, device=x0.device), torch.zeros(1, device=x0.device))
-        bx, by = self.initial_baffle_vertices[:, 0], self.initial_baffle_vertices[:, 1]
-        params['%s.vertex_positions' % self.baffle_key] = torch.stack([bx, by, rim.expand(bx.shape[0])], dim=1).reshape(-1)
+        params['%s.vertex_positions' % self.lens_key] = surface_positions(self.surface, self.initial_lens_vertices).reshape(-1)
+        # the baffle follows the surface's rim in z (lens.py:553-565): every baffle vertex takes z(radial_extent, 0)
+        if getattr(self, "_rim_xy", None) is None or self._rim_xy.shape[0] != self.initial_baffle_vertices.shape[0] or self._rim_xy.device != self.initial_baffle_vertices.device:
+            self._rim_xy = torch.tensor([self.surface.radial_extent, 0.0], dtype=torch.float32, device=self.initial_baffle_vertices.device).repeat(self.initial_baffle_vertices.shape[0], 1)
+        params['%s.vertex_positions' % self.baffle_key] = surface_positions(self.surface, self.initial_baffle_vertices, self._rim_xy).reshape(-1)
+
+
+_SAG_KEYS = ('c', 'K', 'z0', 'a4', 'a6', 'a8', 'a10', 'a12', 'a14', 'a16')
+
+
+def surface_positions(surface, base_positions, eval_xy=None):
+    """New vertex positions of a surface mesh, (x0, y0, z(x, y)) (LensElement.update, lens.py:509-568).  On the GPU one launch of
+    mi355_lens_sag (and one of mi355_lens_sag_backward when the loss is back-propagated) instead of the ~25 elementwise torch launches of
+    surface.compute_z and as many again in its autograd graph; on the CPU, or for a surface type the kernel does not know, plain torch.
+    `eval_xy` (n x 2): evaluate the sag there instead of at the vertices' own (x, y) -- a baffle follows the surface's rim."""
+    torch = _torch()
+    if base_positions.is_cuda and set(surface.params.keys()) <= set(_SAG_KEYS):
+        like = base_positions
+        p10 = torch.cat([_as1(surface.params.get(k, 0.0), like) for k in _SAG_KEYS])
+        return _sag_op().apply(p10, base_positions, eval_xy, float(surface.radial_extent))
+    x, y = (base_positions[:, 0], base_positions[:, 1]) if eval_xy is None else (eval_xy[:, 0], eval_xy[:, 1])
+    z = surface.compute_z(x, y)
+    return torch.stack([base_positions[:, 0], base_positions[:, 1], z.expand(base_positions.shape[0])], dim=1)
+
+
+_SAG_OP = None
+
+
+def _sag_op():
+    global _SAG_OP
+    if _SAG_OP is not None:
+        return _SAG_OP
+    import ctypes as C
+    torch = _torch()
+
+    class _SagOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, p10, base, eval_xy, R):
+            base = base.detach().contiguous(); p = p10.detach().contiguous().float()
+            exy = None if eval_xy is None else eval_xy.detach().contiguous()
+            out = torch.empty_like(base)
+            st = C.c_void_p(torch.cuda.current_stream(base.device).cuda_stream)
+            abi.check(abi.lib().mi355_lens_sag(C.c_void_p(exy.data_ptr()) if exy is not None else None, C.c_void_p(base.data_ptr()), base.shape[0], R,
+                                                C.c_void_p(p.data_ptr()), C.c_void_p(out.data_ptr()), st))
+            ctx.saved = (p, base, exy, R)
+            return out
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            p, base, exy, R = ctx.saved
+            g = grad_out.contiguous().float(); gp = torch.zeros(10, dtype=torch.float32, device=base.device)
+            st = C.c_void_p(torch.cuda.current_stream(base.device).cuda_stream)
+            abi.check(abi.lib().mi355_lens_sag_backward(C.c_void_p(exy.data_ptr()) if exy is not None else None, C.c_void_p(base.data_ptr()), base.shape[0], R,
+                                                         C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(gp.data_ptr()), st))
+            return gp, None, None, None
+    _SAG_OP = _SagOp
+    return _SAG_OP
 
 
 def _as1(v, like):
@@ -390,8 +440,8 @@ class ApertureElement:
         if self.param_keys_to_opt_keys is None:
             return
         x0 = self.initial_ap_vertices
-        rim = self.surface.compute_z(torch.full((1,), self.surface.radial_extent, device=x0.device), torch.zeros(1, device=x0.device))
-        params['%s.vertex_positions' % self.ap_key] = torch.stack([x0[:, 0], x0[:, 1], rim.expand(x0.shape[0])], dim=1).reshape(-1)
+        rim_xy = torch.tensor([self.surface.radial_extent, 0.0], dtype=torch.float32, device=x0.device).repeat(x0.shape[0], 1)
+        params['%s.vertex_positions' % self.ap_key] = surface_positions(self.surface, x0, rim_xy).reshape(-1)
 
     def remove_optvar(self, param_name):
         if param_name in self.active_optvars:

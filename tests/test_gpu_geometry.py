@@ -472,3 +472,36 @@ def test_lane_sort_changes_nothing_but_the_order(mi, torch_cuda):
             assert float(ia.max()) > 0 and float((ia - ib).abs().max()) < 1e-5 * float(ib.max()), (name, per)
             assert float((ga - gb).abs().max()) < 2e-4 * float(gb.abs().max()), (name, per, float((ga - gb).abs().max()) / float(gb.abs().max()))
         scene.release()
+
+
+def test_lens_sag_kernels_match_the_torch_expression(mi, torch_cuda):
+    """mi355_lens_sag / mi355_lens_sag_backward -- EvenAsphericSurface.compute_z_dr of the fork's scripts (lens.py:166-249) and its transpose
+    as two kernels -- against the same expression in torch (surface.compute_z) and torch's autograd: positions to 2e-6 of the element
+    radius, parameter gradients to 2e-5 of their largest magnitude, for a lens mesh (own x, y) and a baffle (rim point)."""
+    torch = torch_cuda
+    ld = mi.lens_design
+    surf = ld.EvenAsphericSurface(radial_extent=8.0, c=-1 / 24, K=-0.3, z0=49.0, a4=2e-5, a6=-3e-7, a8=1e-9, a16=1e-18)
+    V, F, Va, Fa, _ = ld.create_surface_geometry(4, 8.0, surf.compute_z_np, c=surf.get_curvature(), baffle_radius=8.8, flip_normals=True)
+    base = torch.tensor(V, dtype=torch.float32, device="cuda"); base_b = torch.tensor(Va, dtype=torch.float32, device="cuda")
+    rim_xy = torch.tensor([8.0, 0.0], device="cuda").repeat(base_b.shape[0], 1)
+    w = torch.tensor(np.random.default_rng(0).normal(size=V.shape).astype(np.float32), device="cuda"); wb = torch.tensor(np.random.default_rng(1).normal(size=Va.shape).astype(np.float32), device="cuda")
+    keys = list(surf.params.keys())
+    results = {}
+    for use_kernel in (True, False):
+        leaves = {k: torch.tensor([float(surf.params[k])], dtype=torch.float32, device="cuda", requires_grad=True) for k in keys}
+        saved = dict(surf.params); surf.params.update(leaves)
+        if use_kernel:
+            pos = ld.surface_positions(surf, base); pos_b = ld.surface_positions(surf, base_b, rim_xy)
+        else:
+            pos = torch.stack([base[:, 0], base[:, 1], surf.compute_z(base[:, 0], base[:, 1])], dim=1)
+            pos_b = torch.stack([base_b[:, 0], base_b[:, 1], surf.compute_z(rim_xy[:1, 0], rim_xy[:1, 1]).expand(base_b.shape[0])], dim=1)
+        ((pos * w).sum() + (pos_b * wb).sum()).backward()
+        results[use_kernel] = (pos.detach(), pos_b.detach(), torch.cat([leaves[k].grad for k in keys]))
+        surf.params.clear(); surf.params.update(saved)
+    (pa, pba, ga), (pb, pbb, gb) = results[True], results[False]
+    assert float((pa - pb).abs().max()) < 2e-6 * 8.0 and float((pba - pbb).abs().max()) < 2e-6 * 8.0
+    assert torch.equal(pa[:, :2], base[:, :2]) and torch.equal(pba[:, :2], base_b[:, :2])
+    rel = (ga - gb).abs() / gb.abs().max()
+    assert float(gb.abs().max()) > 0 and float(rel.max()) < 2e-5, (ga, gb)
+    for k, a_, b_ in zip(keys, ga.tolist(), gb.tolist()):                      # every scalar on its own scale too
+        assert abs(a_ - b_) <= 1e-3 * abs(b_) + 1e-6 * float(gb.abs().max()), (k, a_, b_)
