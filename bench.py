@@ -8,17 +8,28 @@ W*H*spp / wall-seconds, whole job.  With N > 1 ranks the sample plane is cut int
 to the ranks (strong scaling, total work fixed); the only exchange is one all-reduce (RCCL) of the 4 MB RGBW
 accumulator before develop.
 
+With `--gpus N` and no launcher environment (no WORLD_SIZE) the script starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` on itself as a child process (before anything touches the GPU) and exits with its code.
+
 The same JSON line carries
   roofline      the resource that binds the fused path kernel: wave64 VALU instruction issue.  achieved = VALU instructions per
-                launch (SQ_INSTS_VALU of the committed PMC pass, profiles/r02_pmc_summary.json) / HIP-event time of the kernel
-                measured live; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction (MI355X_MICROARCH.md; the microbenchmark
-                profiles/r02_valu_issue.json reaches 2.2); frac <= 1.  `traffic` and `hbm` come from the same PMC pass.
-                `contract` keeps the SURVEY.md 8(d) algorithmic bytes (88 N_gen + 48 N_isect + 196 N_shade + 104 N_shadow +
-                20 N_splat + 60 H W) of the unfused SoA formulation -- a bookkeeping figure, not a physical bound.
+                launch (SQ_INSTS_VALU of the committed PMC pass of the leg, profiles/r03_pmc[_veach|_ptracer|_lens]_summary.json,
+                scaled by lanes) / HIP-event time of the kernel measured live; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per
+                instruction (MI355X_MICROARCH.md); `peak_at_sustained_clock` prices the same issue rate at the clock the part
+                holds under an all-VALU load (profiles/r02_valu_issue.json: 2.32 nominal cycles per instruction, i.e. ~2.07 GHz).
+                Each PMC pass records the sha256 of csrc/ it was taken from: when it differs from this checkout's the block says
+                `pmc_stale` and states no fraction.  `traffic` and `hbm` come from the same pass.  `contract` keeps the
+                SURVEY.md 8(d) algorithmic bytes (88 N_gen + 48 N_isect + 196 N_shade + 104 N_shadow + 20 N_splat + 60 H W) of
+                the unfused SoA formulation -- a bookkeeping figure, not a physical bound.  Every leg below carries the same block
+                for its dominant kernel (the lens leg two: render and geometry adjoint).
   cpu_baseline  the CPU oracle (scalar C restatement, OpenMP over all host cores) on a bounded sample of the same
                 workload (512x512 at a few spp), rank 0, N = 1 only
   prb           PRB backward (BASELINE config C3: 512x512 @ 64 spp, gradient w.r.t. a 256x256x3 albedo texture on the
                 back wall + all constant albedos / the emitter) in Msamples/s -- measured after the timed steps.
+  veach         BASELINE configs[3]: Veach-MIS scene 1024^2 @ 512 spp forward
+  ptracer       particle tracer, Cornell box 512^2 @ 64 spp, box and Gaussian reconstruction filters (+ its adjoint)
+  lens          BASELINE configs[4] as notebooks/doublet_full_optim.ipynb cell 7 runs it: DesignProblem(num_sources=3), three sensors
+                in one scene, per iteration 3 x (render @ 256 spp + geometry adjoint @ 128 spp) + surface update + Adam
 """
 import argparse
 import ctypes as C
@@ -134,11 +145,12 @@ def issue_model(c):
             "note": "latency-free schedule of this instruction mix per tools/valu_issue_bench.hip (profiles/r02_valu_issue.json): vector issue + transcendentals, scalar instructions hidden behind them up to the scalar unit's own rate"}
 
 
-def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes, pmc_file=None):
+def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes, pmc_file=None, lanes_profiled=None):
     """roofline block of a fused path kernel: bound = wave64 VALU issue.  Instruction count and HBM traffic per launch are read from
     the committed PMC pass of the leg (scaled by lanes when this launch covers a different number of lanes than the profiled one), the
     time is the HIP-event time measured in this run.  A pass taken from other kernel sources than this checkout's is reported as
-    `pmc_stale` and no fraction is stated."""
+    `pmc_stale` and no fraction is stated.  `lanes_profiled`: lanes the profiled launch covered when its grid is not one thread per lane
+    (the regenerating kernels run a fixed-size persistent grid)."""
     pmc_file = pmc_file or PMC_FILE
     rec = pmc_kernel(pmc_name, pmc_file)
     sec = kernel_ms * 1e-3
@@ -151,13 +163,13 @@ def valu_roofline(kernel, pmc_name, kernel_ms, lanes_per_launch, contract_bytes,
         out["note"] = "%s was taken from other kernel sources than this checkout (sha256 of csrc/ differs): instruction counts not trusted, frac not stated; re-run tools/pmc.sh" % pmc_file
         rec = None
     if rec is not None and sec > 0:
-        c = rec["counters"]; scale = lanes_per_launch / float(rec["grid"])
+        c = rec["counters"]; lanes_profiled = float(lanes_profiled or rec["grid"]); scale = lanes_per_launch / lanes_profiled
         insts = c["SQ_INSTS_VALU"] * scale
         out.update({"achieved": round(insts / sec / 1e9, 1), "frac": round(insts / sec / 1e9 / VALU_PEAK_GINST, 4),
                     "frac_of_peak_at_sustained_clock": round(insts / sec / 1e9 / (VALU_PEAK_GINST * VALU_CYCLES_PEAK / sustained), 4) if sustained else None,
                     "insts_per_launch": int(insts), "cycles_per_inst_measured": round(sec * PEAK_CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
                     "cycles_per_inst_peak": VALU_CYCLES_PEAK, "cycles_per_inst_microbench": microbench_cycles(),
-                    "pmc": {"file": pmc_file, "kernel": pmc_name, "lanes_profiled": int(rec["grid"]), "scaled_by_lanes": round(scale, 6),
+                    "pmc": {"file": pmc_file, "kernel": pmc_name, "lanes_profiled": int(lanes_profiled), "grid_threads": int(rec["grid"]), "scaled_by_lanes": round(scale, 6),
                             "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "GRBM_GUI_ACTIVE": c.get("GRBM_GUI_ACTIVE"),
                             "cycles_per_inst_pmc": (round(c["GRBM_GUI_ACTIVE"] / 8 * N_SIMD / c["SQ_INSTS_VALU"], 3) if c.get("GRBM_GUI_ACTIVE") else None),
                             "waves": c.get("SQ_WAVES"), "insts_per_wave": {k[9:].lower(): round(c[k] / c["SQ_WAVES"], 1) for k in
@@ -452,7 +464,8 @@ def main():
               "finite": bool(torch.isfinite(film4).all().item())}
         l4 = max(k4["kernel_launches"], 1)
         c4["roofline"] = valu_roofline("k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>", "k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>",
-                                       k4["kernel_ms"] / l4, k4["n_gen"] / l4, algorithmic_bytes(k4, 1024 * 1024 * n4 / max(world, 1)) / l4, PMC_FILES["veach"])
+                                       k4["kernel_ms"] / l4, k4["n_gen"] / l4, algorithmic_bytes(k4, 1024 * 1024 * n4 / max(world, 1)) / l4, PMC_FILES["veach"],
+                                       lanes_profiled=(1024 * 1024 * 512 if i4.regen else None))  # tools/pmc.sh profiles this same workload; the regen grid is persistent
         sc4.release()
 
     # ---- optional: particle tracer (forward part) -----------------------------------------------------

@@ -464,25 +464,49 @@ def test_baseline_config_1_runs_at_its_stated_size(mi, orc):
 
 
 def test_bench_roofline_reads_the_committed_pmc_pass():
-    """bench.py's roofline block is computed from the committed PMC pass (profiles/r02_pmc_summary.json) and the committed microbenchmark
-    (profiles/r02_valu_issue.json): the kernels it looks up must be in that file under the names the current build gives them, the VALU-issue
-    fraction must be physical (0 < frac <= 1) at the kernel times of the committed bench line, and the all-instruction issue model must
-    sit between the VALU-only figure and 1."""
+    """bench.py's roofline blocks are computed from the committed PMC passes (profiles/r03_pmc*_summary.json, one per leg) and the committed
+    microbenchmark (profiles/r02_valu_issue.json).  The passes must have been taken from the kernel sources of this checkout (the sha256 over
+    csrc/ they record equals the one bench.py computes: a later kernel edit without a new pass makes every fraction `pmc_stale`), the kernels
+    bench.py looks up must be in those files under the names the current build gives them, the VALU-issue fraction must be physical
+    (0 < frac <= 1) at the kernel times of the committed bench line, and the all-instruction issue model must sit between the VALU-only
+    figure and 1.  Every leg of the committed line carries a block that can be recomputed from these files."""
     import importlib.util, json
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
-    for pmc_name, ms, lanes in (("k_render_compact<0, 0>", line["roofline"]["kernel_ms"], 512 * 512 * 256),
-                                ("k_prb_backward_1p<0, false>", line["prb"]["kernel_ms"], 512 * 512 * 64)):
-        assert bench.pmc_kernel(pmc_name) is not None, pmc_name
-        r = bench.valu_roofline(pmc_name, pmc_name, ms, lanes, 1.0)
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_final_bench.json")))
+    sha = bench.csrc_sha256()
+    for f in [bench.PMC_FILE] + list(bench.PMC_FILES.values()):
+        d = json.load(open(os.path.join(ROOT, f)))
+        assert d["csrc_sha256"] == sha, "%s was taken from other kernel sources: re-run tools/pmc.sh" % f
+        assert not bench.pmc_stale(f)
+    for pmc_name, ms, lanes, f in (("k_render_compact<0, 0>", line["roofline"]["kernel_ms"], 512 * 512 * 256, None),
+                                   ("k_prb_backward_1p<0, false>", line["prb"]["kernel_ms"], 512 * 512 * 64, None),
+                                   ("k_ptracer<0, false>", line["ptracer"]["box"]["kernel_ms"], 512 * 512 * 64, bench.PMC_FILES["ptracer"]),
+                                   ("k_ptracer<1, false>", line["lens"]["roofline"]["render"]["kernel_ms"], line["lens"]["roofline"]["render"]["pmc"]["lanes_profiled"], bench.PMC_FILES["lens"]),
+                                   ("k_ptracer_geo_bwd<1>", line["lens"]["roofline"]["geometry_adjoint"]["kernel_ms"], line["lens"]["roofline"]["geometry_adjoint"]["pmc"]["lanes_profiled"], bench.PMC_FILES["lens"])):
+        assert bench.pmc_kernel(pmc_name, f) is not None, pmc_name
+        r = bench.valu_roofline(pmc_name, pmc_name, ms, lanes, 1.0, f)
+        assert "pmc_stale" not in r
         assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and r["hbm"]["frac_of_peak"] < 1.0
         assert abs(r["frac"] * r["cycles_per_inst_measured"] - bench.VALU_CYCLES_PEAK) < 0.01          # frac = peak cycles / measured cycles
+        assert r["frac"] < r["frac_of_peak_at_sustained_clock"] <= 1.0                                  # the sustained clock is below the nominal one
         im = r["issue_model"]
         assert r["frac"] < im["frac_of_model"] <= 1.0 and im["valu"] == r["insts_per_launch"] and im["scalar"] > 0
+    # the regenerating kernel runs a persistent grid: its lanes come from the workload, not from the grid
+    r = bench.valu_roofline("k_render_regen<2>", "k_render_regen<2>", line["veach"]["kernel_ms"], 1024 * 1024 * 512, 1.0, bench.PMC_FILES["veach"], lanes_profiled=1024 * 1024 * 512)
+    assert 0.0 < r["frac"] <= 1.0 and r["pmc"]["scaled_by_lanes"] == 1.0
+    # a pass from other sources is flagged and states no fraction
+    stale = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    if os.path.exists(stale):
+        r = bench.valu_roofline("k", "k_render_compact<0, 0>", 9.0, 512 * 512 * 256, 1.0, "profiles/r02_pmc_summary.json")
+        assert r.get("pmc_stale") is True and r["frac"] is None
     # the committed line itself carries what the contract asks for
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["roofline"]["frac"] <= 1.0 and line["cpu_baseline"]["kind"] == "port" and line["config"]["workload"].startswith("Cornell box")
+    for blk in (line["roofline"], line["prb"]["roofline"], line["veach"]["roofline"], line["ptracer"]["box"]["roofline"], line["ptracer"]["gaussian"]["roofline"],
+                line["lens"]["roofline"]["render"], line["lens"]["roofline"]["geometry_adjoint"]):
+        assert 0.0 < blk["frac"] <= 1.0 and blk["traffic"] > 0 and blk["pmc"]["file"].startswith("profiles/r03_pmc"), blk["kernel"]
+        assert blk["contract"]["algorithmic_bytes_per_launch"] > 0 and "pmc_stale" not in blk
     for leg in ("prb", "veach", "ptracer", "lens"):
         assert leg in line, leg
