@@ -511,8 +511,8 @@ static inline v3 mesh_vertex(const OShape *sh, uint32_t i) { return V3(sh->pos[3
    edge functions (Embree's PlueckerIntersector): for the edge (P, Q) f = dot(cross(P - Q, P + Q), d) with P, Q relative to the ray origin;
    the neighbour sees the same edge as (Q, P) and gets exactly -f in floating point (negation and commutation are exact, rounding is
    sign-symmetric), so a ray is inside at least one of the two.  u, v as mesh.h:430-453 defines them (weights of p1, p2). */
-static __thread int g_watertight = 0;
-static inline int pluecker_watertight(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
+static int g_watertight = 0;   /* set by orc_trace only, which is serial: not thread-local, the per-triangle read stays a plain load */
+static __attribute__((noinline)) int pluecker_watertight(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
     v3 v0 = sub3(p0, ray->o), v1 = sub3(p1, ray->o), v2_ = sub3(p2, ray->o);
     v3 e0 = sub3(v2_, v0), e1 = sub3(v0, v1), e2 = sub3(v1, v2_);
     float U = dot3(cross3(e0, add3(v2_, v0)), ray->d), V = dot3(cross3(e1, add3(v0, v1)), ray->d), W = dot3(cross3(e2, add3(v1, v2_)), ray->d);
@@ -528,7 +528,7 @@ static inline int pluecker_watertight(const Ray *ray, v3 p0, v3 p1, v3 p2, float
 }
 /* Mesh::moeller_trumbore: include/mitsuba/render/mesh.h:430-453 */
 static inline int moeller_trumbore(const Ray *ray, v3 p0, v3 p1, v3 p2, float *t_out, v2 *uv_out) {
-    if (g_watertight) return pluecker_watertight(ray, p0, p1, p2, t_out, uv_out);
+    if (__builtin_expect(g_watertight, 0)) return pluecker_watertight(ray, p0, p1, p2, t_out, uv_out);
     v3 e1 = sub3(p1, p0), e2 = sub3(p2, p0);
     v3 pvec = cross3(ray->d, e2);
     float inv_det = rcpf_(dot3(e1, pvec));
