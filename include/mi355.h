@@ -434,6 +434,20 @@ int mi355_lens_sag(const float *d_eval_xy, const float *d_base_positions, uint32
 int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params,
                             const float *d_grad_positions, float *d_grad_params, void *stream);
 
+/* The rest of a design iteration that the reference runs as Dr.Jit kernels: the spot loss of one field (notebooks/scripts/lens_design/losses.py:31-41,
+   rms_loss_and_center: squared RMS radius of the spot in pixels about its detached centroid, the image normalised by its detached mean) and the
+   optimiser step (src/python/python/ad/optimizers.py:263-302, Adam.step without mask_updates) for all design scalars in one launch.
+     mi355_spot_loss           d_image height x width x 3 -> d_out[5] = { loss, ibar (row), jbar (column), mean(image), sum(I) }
+     mi355_spot_loss_backward  d_grad_image (height x width x 3, overwritten) = d_grad_loss[0] * d loss / d image, from the d_out of the forward call
+     mi355_adam_step           per slot: m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2 (both in place); param_out = param - lr_t m / (sqrt(v) + eps),
+                               lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) formed by the caller (t is per variable); b1, b2, eps are doubles because
+                               1 - b is formed in double before it is rounded to the tensors' float, as with the reference's Python scalars.  `slots` is a HOST array of DEVICE pointers.
+   Pure functions of their arguments on the current HIP device; no scene handle. */
+typedef struct mi355_adam_slot { const float *param, *grad; float *m, *v, *param_out; float lr_t; uint32_t count; } mi355_adam_slot;
+int mi355_spot_loss(const float *d_image, uint32_t height, uint32_t width, float *d_out, void *stream);
+int mi355_spot_loss_backward(const float *d_out, const float *d_grad_loss, uint32_t height, uint32_t width, float *d_grad_image, void *stream);
+int mi355_adam_step(const mi355_adam_slot *slots, uint32_t n, double beta_1, double beta_2, double epsilon, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------------- */
 int mi355_get_counters(mi355_scene *scene, mi355_counters *out, int reset);
 

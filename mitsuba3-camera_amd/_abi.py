@@ -100,6 +100,10 @@ class ParamInfo(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("offset", C.c_uint64), ("size", C.c_uint64)]
 
 
+class AdamSlot(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("param_out", C.c_void_p), ("lr_t", C.c_float), ("count", C.c_uint32)]
+
+
 # every symbol include/mi355.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mi355_last_error", C.c_char_p, []),
@@ -116,6 +120,9 @@ SYMBOLS = [
     ("mi355_scene_sensor_count", C.c_int, [C.c_void_p]),
     ("mi355_lens_sag", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_lens_sag_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355_spot_loss", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_spot_loss_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mi355_adam_step", C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("mi355_trace_rays", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("mi355_render", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_prb_splat_weights", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),

@@ -1338,6 +1338,61 @@ __global__ __launch_bounds__(256) void k_lens_sag_bwd(const float *eval_xy, cons
     if (threadIdx.x < 10 && s_acc[threadIdx.x] != 0.f) atomicAdd(grad_p + threadIdx.x, s_acc[threadIdx.x]);
 }
 
+// ---- the lens-design loop's loss and optimiser step as single launches ----------------------------------------------------------------
+// losses.py:31-41 (rms_loss_and_center): I = mean_c(image / mean(image)), centroid (ibar, jbar) = sum(I * (i, j)) / sum(I), loss =
+// sum(I * ((i - ibar)^2 + (j - jbar)^2)) / sum(I); mean and centroid are detached.  One workgroup, double accumulators (the film is 128^2),
+// out = { loss, ibar, jbar, mean(image), sum(I) }.
+MI_DEV double block_sum_f64(double v, double *s_part) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0; for (uint32_t k = 0; k < blockDim.x / 64u; ++k) t += s_part[k];
+    return t;
+}
+__global__ __launch_bounds__(1024) void k_spot_loss(const float *image, uint32_t H, uint32_t W, float *out) {
+    __shared__ double s_part[16];
+    const uint32_t n = H * W;
+    double s = 0.0, si = 0.0, sj = 0.0;
+    for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
+        const double v = (double) image[3 * (size_t) q] + (double) image[3 * (size_t) q + 1] + (double) image[3 * (size_t) q + 2];
+        s += v; si += v * (double) (q / W); sj += v * (double) (q % W);
+    }
+    s = block_sum_f64(s, s_part); si = block_sum_f64(si, s_part); sj = block_sum_f64(sj, s_part);
+    const double ibar = si / s, jbar = sj / s;
+    double m2 = 0.0;
+    for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
+        const double v = (double) image[3 * (size_t) q] + (double) image[3 * (size_t) q + 1] + (double) image[3 * (size_t) q + 2];
+        const double di = (double) (q / W) - ibar, dj = (double) (q % W) - jbar;
+        m2 += v * (di * di + dj * dj);
+    }
+    m2 = block_sum_f64(m2, s_part);
+    if (threadIdx.x == 0) {
+        const double mean = s / (3.0 * (double) n);
+        out[0] = (float) (m2 / s); out[1] = (float) ibar; out[2] = (float) jbar; out[3] = (float) mean; out[4] = (float) (s / (3.0 * mean));
+    }
+}
+// d loss / d image[p][c] = ((i - ibar)^2 + (j - jbar)^2 - loss) / sum(I) / (3 mean), times the incoming adjoint of the loss
+__global__ __launch_bounds__(256) void k_spot_loss_bwd(const float *fwd, const float *grad_loss, uint32_t H, uint32_t W, float *grad_image) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= H * W) return;
+    const float di = (float) (q / W) - fwd[1], dj = (float) (q % W) - fwd[2];
+    const float g = grad_loss[0] * (fmaf(di, di, dj * dj) - fwd[0]) / (fwd[4] * 3.f * fwd[3]);
+    grad_image[3 * (size_t) q] = g; grad_image[3 * (size_t) q + 1] = g; grad_image[3 * (size_t) q + 2] = g;
+}
+// optimizers.py:263-302 (Adam.step without mask_updates) for up to MI_ADAM_SLOTS small tensors per launch; the table travels as a kernel argument
+#define MI_ADAM_SLOTS 64u
+struct AdamTable { mi355_adam_slot slot[MI_ADAM_SLOTS]; };
+__global__ __launch_bounds__(256) void k_adam(AdamTable t, float beta_1, float one_minus_beta_1, float beta_2, float one_minus_beta_2, float epsilon) {
+    const mi355_adam_slot &a = t.slot[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < a.count; i += 256u) {
+        const float g = a.grad[i];
+        const float m = beta_1 * a.m[i] + one_minus_beta_1 * g, v = beta_2 * a.v[i] + one_minus_beta_2 * g * g;
+        a.m[i] = m; a.v[i] = v;
+        a.param_out[i] = a.param[i] - a.lr_t * m / (sqrtf(v) + epsilon);
+    }
+}
+
 // HDRFilm::develop, hdrfilm.cpp:304-409
 __global__ void k_develop(const float *film, float *image, uint32_t n_pixels) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1552,7 +1607,9 @@ struct mi355_scene {
     float4 *d_rec_a = nullptr, *d_srt_a = nullptr; float *d_rec_b = nullptr, *d_srt_b = nullptr; uint32_t rec_capacity = 0;
     float4 *d_rec_c = nullptr, *d_srt_c = nullptr; float *d_rec_d = nullptr, *d_srt_d = nullptr; uint32_t rec2_capacity = 0;   // derivative splats: second record half
     uint32_t *d_tile_u32 = nullptr; uint32_t tile_capacity = 0; uint32_t splat_cap_override = 0;
-    uint32_t *d_pt_keys = nullptr, *d_pt_order = nullptr, *d_pt_bins = nullptr; uint32_t pt_order_capacity = 0;   // pt_sort_lanes: keys, sorted sample list, 2 x 64 Ki bins
+    uint32_t *d_pt_keys = nullptr, *d_pt_order = nullptr, *d_pt_bins = nullptr; uint32_t pt_order_capacity = 0;   // pt_sort_lanes: keys, 2 sorted sample lists, 2 x 64 Ki bins
+    struct PtOrderTag { uint32_t w[18]; hipStream_t stream; bool valid; } pt_tag[2] = {};   // what each of the two lists was sorted for (pt_sort_lanes)
+    uint32_t pt_next = 0;
     unsigned long long *d_counters = nullptr;   // [0] unused, [1] isect, [2] shade, [3] shadow, [4] redone backward workgroups
     uint64_t n_gen = 0, n_splat = 0;
     hipEvent_t ev[MAX_EVENTS][2]; int n_ev = 0; bool ev_created = false;
@@ -2592,12 +2649,23 @@ static int pt_sort_lanes(mi355_scene *s, const mi355_render_params *p, const Ren
     const uint64_t bins64 = (uint64_t) n_em << (dims * bits);
     if (bins64 > PT_SORT_MAX_BINS) return MI355_OK;                         // (more emitters than the bins hold: keep the natural order)
     const uint32_t bins = (uint32_t) bins64;
+    // The list is a pure function of the sampler streams (seed, lane layout), of how many numbers a stream draws before the emission
+    // sample and of the emitter count -- not of the sensor, the geometry or any parameter value -- so the two most recent lists are kept:
+    // the three sensors of a lens-design iteration render with one seed and differentiate with another (design_problem.py:560-640).
+    mi355_scene::PtOrderTag tag = {};
+    const uint32_t w[18] = { a.seed, a.spp_total, a.max_depth != 0u, a.flags & MI355_FLAG_HIDE_EMITTERS, a.pixel_begin, a.pixel_count, a.s_begin, a.s_count, a.n_local,
+                             a.tile, a.tile_stride, a.passes, bits, four_d ? 1u : 0u, s->ds.shutter_open_time > 0.f ? 1u : 0u, s->ds.features != 0u ? 1u : 0u, n_em, bins };
+    memcpy(tag.w, w, sizeof(w)); tag.stream = st; tag.valid = true;
     if (s->pt_order_capacity < a.n_local) {
         for (void *b : { (void *) s->d_pt_keys, (void *) s->d_pt_order }) if (b) HIP_TRY(hipFree(b));
-        s->d_pt_keys = s->d_pt_order = nullptr; s->pt_order_capacity = 0;
-        HIP_TRY(hipMalloc((void **) &s->d_pt_keys, (size_t) a.n_local * 4)); HIP_TRY(hipMalloc((void **) &s->d_pt_order, (size_t) a.n_local * 4));
+        s->d_pt_keys = s->d_pt_order = nullptr; s->pt_order_capacity = 0; s->pt_tag[0].valid = s->pt_tag[1].valid = false;
+        HIP_TRY(hipMalloc((void **) &s->d_pt_keys, (size_t) a.n_local * 4)); HIP_TRY(hipMalloc((void **) &s->d_pt_order, 2 * (size_t) a.n_local * 4));
         s->pt_order_capacity = a.n_local;
     }
+    for (uint32_t k = 0; k < 2u; ++k)
+        if (s->pt_tag[k].valid && s->pt_tag[k].stream == st && !memcmp(s->pt_tag[k].w, tag.w, sizeof(tag.w))) { *order = s->d_pt_order + (size_t) k * s->pt_order_capacity; s->pt_next = k ^ 1u; return MI355_OK; }
+    const uint32_t slot = s->pt_next; s->pt_next ^= 1u; s->pt_tag[slot].valid = false;
+    uint32_t *list = s->d_pt_order + (size_t) slot * s->pt_order_capacity;
     if (!s->d_pt_bins) HIP_TRY(hipMalloc((void **) &s->d_pt_bins, 2 * (size_t) PT_SORT_MAX_BINS * 4));
     uint32_t *hist = s->d_pt_bins, *cursor = s->d_pt_bins + PT_SORT_MAX_BINS;
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t) bins * 4, st));
@@ -2605,9 +2673,10 @@ static int pt_sort_lanes(mi355_scene *s, const mi355_render_params *p, const Ren
     if (s->ds.features != 0u) hipLaunchKernelGGL(k_pt_keys<true>, g, dim3(256), 0, st, s->ds, a, bits, four_d ? 1u : 0u, s->d_pt_keys, hist);
     else hipLaunchKernelGGL(k_pt_keys<false>, g, dim3(256), 0, st, s->ds, a, bits, four_d ? 1u : 0u, s->d_pt_keys, hist);
     hipLaunchKernelGGL(k_pt_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) hist, cursor, bins);
-    hipLaunchKernelGGL(k_pt_scatter, g, dim3(256), 0, st, (const uint32_t *) s->d_pt_keys, cursor, s->d_pt_order, a.n_local);
+    hipLaunchKernelGGL(k_pt_scatter, g, dim3(256), 0, st, (const uint32_t *) s->d_pt_keys, cursor, list, a.n_local);
     HIP_TRY(hipGetLastError());
-    *order = s->d_pt_order;
+    s->pt_tag[slot] = tag;
+    *order = list;
     return MI355_OK;
 }
 extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params *p, float *d_film_rgbw, void *stream) {
@@ -3007,6 +3076,33 @@ extern "C" int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_ba
     if (!(radial_extent > 0.f)) return fail(MI355_ERR_INVALID, "radial_extent must be positive");
     if (!n) return MI355_OK;
     hipLaunchKernelGGL(k_lens_sag_bwd, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t) stream, d_eval_xy, d_base_positions, n, radial_extent, d_params, d_grad_positions, d_grad_params);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_spot_loss(const float *d_image, uint32_t height, uint32_t width, float *d_out, void *stream) {
+    if (!d_image || !d_out) return fail(MI355_ERR_INVALID, "null argument");
+    if (!height || !width || (uint64_t) height * width > 0x7fffffffull) return fail(MI355_ERR_INVALID, "bad image size");
+    hipLaunchKernelGGL(k_spot_loss, dim3(1), dim3(1024), 0, (hipStream_t) stream, d_image, height, width, d_out);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_spot_loss_backward(const float *d_out, const float *d_grad_loss, uint32_t height, uint32_t width, float *d_grad_image, void *stream) {
+    if (!d_out || !d_grad_loss || !d_grad_image) return fail(MI355_ERR_INVALID, "null argument");
+    if (!height || !width || (uint64_t) height * width > 0x7fffffffull) return fail(MI355_ERR_INVALID, "bad image size");
+    hipLaunchKernelGGL(k_spot_loss_bwd, dim3((height * width + 255u) / 256u), dim3(256), 0, (hipStream_t) stream, d_out, d_grad_loss, height, width, d_grad_image);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+extern "C" int mi355_adam_step(const mi355_adam_slot *slots, uint32_t n, double beta_1, double beta_2, double epsilon, void *stream) {
+    if (!slots && n) return fail(MI355_ERR_INVALID, "null argument");
+    if (!(beta_1 >= 0.0 && beta_1 < 1.0 && beta_2 >= 0.0 && beta_2 < 1.0 && epsilon > 0.0)) return fail(MI355_ERR_INVALID, "Adam: beta_1, beta_2 in [0, 1), epsilon > 0");
+    for (uint32_t i = 0; i < n; ++i)
+        if (!slots[i].param || !slots[i].grad || !slots[i].m || !slots[i].v || !slots[i].param_out) return fail(MI355_ERR_INVALID, "Adam: null pointer in slot");
+    for (uint32_t b = 0; b < n; b += MI_ADAM_SLOTS) {
+        AdamTable t; const uint32_t k = n - b < MI_ADAM_SLOTS ? n - b : MI_ADAM_SLOTS;
+        memset(&t, 0, sizeof(t)); memcpy(t.slot, slots + b, (size_t) k * sizeof(mi355_adam_slot));
+        hipLaunchKernelGGL(k_adam, dim3(k), dim3(256), 0, (hipStream_t) stream, t, (float) beta_1, (float) (1.0 - beta_1), (float) beta_2, (float) (1.0 - beta_2), (float) epsilon);   // (1 - beta formed in double, as the Python scalars of the reference are)
+    }
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

@@ -671,10 +671,48 @@ def unit_square_mesh():
 # ------------------------------------------------------------------------------------------------
 # losses.py / design_problem.py
 # ------------------------------------------------------------------------------------------------
+_SPOT_OP = None
+
+
+def _spot_op():
+    """losses.py:31-41 as two launches (mi355_spot_loss / _backward) instead of ~25 elementwise and reduction kernels per field."""
+    global _SPOT_OP
+    if _SPOT_OP is not None:
+        return _SPOT_OP
+    import ctypes as C
+    torch = _torch()
+
+    class _SpotOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, image):
+            img = image.detach().contiguous().float()
+            out = torch.empty(5, dtype=torch.float32, device=img.device)
+            with torch.cuda.device(img.device):
+                abi.check(abi.lib().mi355_spot_loss(C.c_void_p(img.data_ptr()), img.shape[0], img.shape[1], C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(torch.cuda.current_stream(img.device).cuda_stream)))
+            ctx.saved = (out, img.shape)
+            ctx.mark_non_differentiable(out)
+            return out[0].clone(), out
+
+        @staticmethod
+        def backward(ctx, grad_loss, _grad_out):
+            out, shape = ctx.saved
+            g = grad_loss.detach().reshape(1).contiguous().float(); gi = torch.empty(shape, dtype=torch.float32, device=out.device)
+            with torch.cuda.device(out.device):
+                abi.check(abi.lib().mi355_spot_loss_backward(C.c_void_p(out.data_ptr()), C.c_void_p(g.data_ptr()), shape[0], shape[1], C.c_void_p(gi.data_ptr()),
+                                                             C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
+            return gi
+    _SPOT_OP = _SpotOp
+    return _SPOT_OP
+
+
 def rms_loss_and_center(image):
     """losses.py:31-41: squared RMS radius (in pixels) of the spot in `image` (H x W x 3 torch tensor) and its centroid (row, column); centroid
-    and normalisation detached."""
+    and normalisation detached.  Device images go through one kernel each way; the torch expression below is the same arithmetic."""
     torch = _torch()
+    if image.is_cuda and image.dim() == 3 and image.shape[2] == 3:
+        loss, out = _spot_op().apply(image)
+        return loss, out[1], out[2]
     scaled = image / image.detach().mean()
     H, W = image.shape[0], image.shape[1]
     ii, jj = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=image.device), torch.arange(W, dtype=torch.float32, device=image.device), indexing='ij')
@@ -798,14 +836,14 @@ class FieldSource:
 
     def evaluate_rms_loss(self, image, recenter=False):
         """:267-279: the spot's squared RMS radius in mm^2 and the upsample flag (spot smaller than a tenth of the image)."""
+        torch = _torch()
+        pixel_loss, ibar, jbar = rms_loss_and_center(image)
+        host_loss, host_i, host_j = torch.stack([pixel_loss.detach().reshape(()), ibar.reshape(()), jbar.reshape(())]).tolist()    # one read-back for the three
         if recenter:
-            pixel_loss, ibar, jbar = rms_loss_and_center(image)
-            self.center_camera_on_pixel(ibar, jbar)
-        else:
-            pixel_loss = rms_loss(image)
-        upsample_flag = bool(pixel_loss.detach() < (self.resolution[0] * 0.1) ** 2)
+            self.center_camera_on_pixel(host_i, host_j)
+        upsample_flag = bool(host_loss < (self.resolution[0] * 0.1) ** 2)
         physical_loss = pixel_loss * self.get_pixel_size() ** 2
-        self.losses.append(float(physical_loss.detach()))
+        self.losses.append(host_loss * self.get_pixel_size() ** 2)
         return physical_loss, upsample_flag
 
 

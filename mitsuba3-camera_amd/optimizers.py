@@ -141,8 +141,10 @@ class Adam(Optimizer):
             self.variables[k] = (p.detach() - step).requires_grad_(True)
 
     def _step_fused(self):
-        """The same update (optimizers.py:263-302) for ALL variables in a handful of multi-tensor launches instead of nine launches per
-        variable: a lens design holds ~30 one-element variables, and 270 tiny launches were 2 of the 30 ms of a design iteration."""
+        """The same update (optimizers.py:263-302) for ALL variables at once instead of nine launches per variable: a lens design holds ~30
+        one-element variables, and 270 tiny launches were 2 of the 30 ms of a design iteration.  On the GPU: ONE launch of `mi355_adam_step`
+        (m and v updated in place, the new values written into one fresh buffer the new variables are views of); elsewhere a handful of
+        multi-tensor calls."""
         import torch
         ks, ps, gs, ms, vs, lrs = [], [], [], [], [], []
         for k, p in list(self.variables.items()):
@@ -156,6 +158,8 @@ class Adam(Optimizer):
             ks.append(k); ps.append(p.detach()); gs.append(g_p); ms.append(self.state[k][0]); vs.append(self.state[k][1]); lrs.append(self._lr(k) * lr_scale)
         if not ks:
             return
+        if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for group in (ps, gs, ms, vs) for t in group):
+            return self._step_kernel(ks, ps, gs, ms, vs, lrs)
         m_t = torch._foreach_mul(ms, self.beta_1); torch._foreach_add_(m_t, torch._foreach_mul(gs, 1 - self.beta_1))
         v_t = torch._foreach_mul(vs, self.beta_2); torch._foreach_add_(v_t, torch._foreach_mul(torch._foreach_mul(gs, 1 - self.beta_2), gs))
         den = torch._foreach_sqrt(v_t); torch._foreach_add_(den, self.epsilon)
@@ -163,6 +167,29 @@ class Adam(Optimizer):
         new = torch._foreach_sub(ps, step)
         for k, m, v, n in zip(ks, m_t, v_t, new):
             self.state[k] = (m, v)
+            self.variables[k] = n.requires_grad_(True)
+
+    def _step_kernel(self, ks, ps, gs, ms, vs, lrs):
+        import ctypes as C
+        import torch
+        from . import _abi as abi
+        dev = ps[0].device
+        if any(t.device != dev for group in (ps, gs, ms, vs) for t in group):
+            raise RuntimeError("Adam: variables, gradients and state must live on one device")
+        counts = [p.numel() for p in ps]
+        flat = torch.empty(sum(counts), dtype=torch.float32, device=dev)
+        slots = (abi.AdamSlot * len(ks))()
+        base = flat.data_ptr(); off = 0; new = []
+        for i, (p, g, m, v, lr, n) in enumerate(zip(ps, gs, ms, vs, lrs, counts)):
+            if m.data_ptr() == v.data_ptr():                             # (reset() hands out two tensors; be safe against an aliased pair)
+                v = v.clone(); self.state[ks[i]] = (m, v)
+            sl = slots[i]
+            sl.param = p.data_ptr(); sl.grad = g.data_ptr(); sl.m = m.data_ptr(); sl.v = v.data_ptr(); sl.param_out = base + 4 * off; sl.lr_t = lr; sl.count = n
+            new.append(flat[off:off + n].view(p.shape)); off += n
+        with torch.cuda.device(dev):
+            abi.check(abi.lib().mi355_adam_step(C.cast(slots, C.c_void_p), len(ks), self.beta_1, self.beta_2, self.epsilon,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        for k, n in zip(ks, new):
             self.variables[k] = n.requires_grad_(True)
 
     def reset(self, key):

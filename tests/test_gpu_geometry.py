@@ -505,3 +505,60 @@ def test_lens_sag_kernels_match_the_torch_expression(mi, torch_cuda):
     assert float(gb.abs().max()) > 0 and float(rel.max()) < 2e-5, (ga, gb)
     for k, a_, b_ in zip(keys, ga.tolist(), gb.tolist()):                      # every scalar on its own scale too
         assert abs(a_ - b_) <= 1e-3 * abs(b_) + 1e-6 * float(gb.abs().max()), (k, a_, b_)
+
+
+@pytest.mark.gpu
+def test_spot_loss_kernel_matches_the_torch_expression(mi, torch_cuda):
+    """mi355_spot_loss / _backward (losses.py:31-41, rms_loss_and_center) against the same expression written with torch operations on a CPU
+    copy in float64: loss, centroid and the image gradient, for a blurred off-centre spot with a coloured background."""
+    torch = torch_cuda
+    ld = mi.lens_design
+    rng = np.random.default_rng(5)
+    H, W = 48, 64
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    img = (np.exp(-((ii - 30.3) ** 2 / 18 + (jj - 17.8) ** 2 / 40))[:, :, None] * np.array([1.0, 0.7, 0.4]) + 0.01 * rng.random((H, W, 3))).astype(np.float32)
+    a = torch.tensor(img, device="cuda", requires_grad=True)
+    la, ia, ja = ld.rms_loss_and_center(a)
+    (3.0 * la).backward()
+    b = torch.tensor(img.astype(np.float64), requires_grad=True)                # the CPU branch of the same function = the torch expression
+    lb, ib, jb = ld.rms_loss_and_center(b)
+    (3.0 * lb).backward()
+    assert abs(float(la) - float(lb)) < 1e-5 * float(lb) and abs(float(ia) - float(ib)) < 1e-4 and abs(float(ja) - float(jb)) < 1e-4
+    ga, gb = a.grad.cpu().double(), b.grad
+    assert float((ga - gb).abs().max()) < 1e-4 * float(gb.abs().max())
+    assert not ia.requires_grad and not ja.requires_grad
+
+
+@pytest.mark.gpu
+def test_adam_kernel_matches_the_per_variable_update(mi, torch_cuda):
+    """mi355_adam_step (all variables in one launch) against the statement-for-statement update of optimizers.py:263-302 that the optimiser
+    runs for few variables: three steps, 9 variables of mixed sizes with per-variable learning rates; values equal to float rounding, and
+    a variable without a gradient is left alone."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    init = {"v%d" % k: rng.normal(size=(1 if k % 3 else 5,)).astype(np.float32) for k in range(9)}
+    grads = [{k: rng.normal(size=v.shape).astype(np.float32) for k, v in init.items()} for _ in range(3)]
+    outs = []
+    for fused in (True, False):
+        opt = mi.Adam(lr=0.05)
+        for k, v in init.items():
+            opt[k] = torch.tensor(v, device="cuda")
+        opt.set_learning_rate({"v2": 0.2, "v7": 0.01})
+        for step, g in enumerate(grads):
+            for k in init:
+                if k == "v4" and step == 1:
+                    continue                                                        # no gradient this step: t advances, the value stays
+                opt[k].grad = torch.tensor(g[k], device="cuda")
+            if fused:
+                opt.step()
+            else:
+                real = dict(opt.variables)                                          # the per-variable branch is taken for <= 4 variables: one at a time
+                for k in list(real):
+                    opt.variables = {k: real[k]}
+                    opt.step()
+                    real[k] = opt.variables[k]
+                opt.variables = real
+        outs.append({k: opt[k].detach().cpu().numpy().copy() for k in init})
+    for k in init:
+        assert np.allclose(outs[0][k], outs[1][k], rtol=2e-6, atol=1e-7), (k, outs[0][k], outs[1][k])
+        assert not np.allclose(outs[0][k], init[k])
