@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--lens-subdiv", type=int, default=7, help="icosphere level of the lens surface meshes (the notebook uses 7)")
     ap.add_argument("--only", default="", help="comma-separated legs to run besides the headline one: prb,veach,ptracer,lens,cpu (default: all)")
     ap.add_argument("--no-ab", action="store_true", help="skip the A/B launches inside the legs (profiling runs: one variant per kernel name)")
-    ap.add_argument("--wavefront", action="store_true", help="A/B: MI355_MODE_WAVEFRONT (re-pack the workgroup's live paths after every bounce)")
+    ap.add_argument("--repack-always", "--wavefront", dest="wavefront", action="store_true", help="A/B: MI355_MODE_REPACK_ALWAYS (re-pack the workgroup's live paths after every bounce; still one fused launch)")
     ap.add_argument("--static", action="store_true", help="A/B: MI355_MODE_STATIC (never re-pack)")
     ap.add_argument("--regen", action="store_true", help="A/B: path regeneration inside a wave (MI355_FLAG_REGEN)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -272,7 +272,7 @@ def main():
     if args.static:
         integ.mode = mi.abi.MODE_STATIC
     if args.wavefront:
-        integ.mode = mi.abi.MODE_WAVEFRONT
+        integ.mode = mi.abi.MODE_REPACK_ALWAYS
     h = scene.handle(local_rank)
     dev = torch.device("cuda", local_rank)
     W = H = args.res
@@ -333,7 +333,7 @@ def main():
     lanes_per_step = npix * args.spp
     value = lanes_per_step * args.steps / dt / 1e6
 
-    MODE_NAME = "wavefront" if args.wavefront else ("static" if args.static else ("fused+regen" if args.regen else "fused"))
+    MODE_NAME = "fused, re-pack after every bounce" if args.wavefront else ("static" if args.static else ("fused+regen" if args.regen else "fused"))
     KERNEL_NAME = {"static": "k_render<path,film>", "fused+regen": "k_render_regen"}.get(MODE_NAME, "k_render_compact")
     # ---- roofline of the dominant kernel (this rank's launches) ------------------------------------
     launches = max(cnt["kernel_launches"], 1)

@@ -219,7 +219,10 @@ typedef struct mi355_scene_desc {
 enum { MI355_MODE_FUSED = 0,           /* default: one launch per pass, path state in registers; the path integrator re-packs the
                                           live paths of a workgroup (wave ballot + prefix sum, SoA state exchanged through LDS) from
                                           bounce 2 on whenever that empties a whole wave */
-       MI355_MODE_WAVEFRONT = 1,       /* re-pack after EVERY bounce, unconditionally; path integrator only */
+       MI355_MODE_REPACK_ALWAYS = 1,   /* re-pack after EVERY bounce, unconditionally; path integrator only.  Still ONE fused launch with the path
+                                          state in registers: no per-stage kernels, no SoA streams in HBM (that "wavefront" formulation is not built:
+                                          DESIGN.md section 2).  An A/B switch against the adaptive default: same film, 9.7-9.9 against 9.7 ms in round 1 */
+       MI355_MODE_WAVEFRONT = MI355_MODE_REPACK_ALWAYS,   /* name used up to ABI v8; misleading (see above), kept so old callers compile */
        MI355_MODE_STATIC = 2 };        /* never re-pack: a lane keeps its path until the longest path of its wave ends */
 
 enum { MI355_INTEGRATOR_PATH = 0,      /* src/integrators/path.cpp */

@@ -1,4 +1,4 @@
-"""mitsuba3-camera_amd -- MI355X-native wavefront path tracing + Path-Replay-Backprop.
+"""mitsuba3-camera_amd -- MI355X-native path tracing (the reference's wavefront megakernel as fused per-lane kernels) + Path-Replay-Backprop.
 
 Host-side mirror of the slice of Mitsuba 3's Python API that drives the `path` / `prb` hot
 path (load_dict, cornell_box, traverse, render, Integrator.render/render_backward); all

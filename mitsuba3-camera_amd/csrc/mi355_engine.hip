@@ -2683,7 +2683,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
     Phase ph(PHASE_RENDER);
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     if (!d_film_rgbw) return fail(MI355_ERR_INVALID, "null film");
-    if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_WAVEFRONT && p->mode != MI355_MODE_STATIC) return fail(MI355_ERR_INVALID, "unknown mode");
+    if (p->mode != MI355_MODE_FUSED && p->mode != MI355_MODE_REPACK_ALWAYS && p->mode != MI355_MODE_STATIC) return fail(MI355_ERR_INVALID, "unknown mode");
 
     HIP_TRY(hipSetDevice(s->device));
     if (a.n_local == 0) return MI355_OK;
@@ -2712,10 +2712,10 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         return MI355_OK;
     }
     // path integrator: re-pack the workgroup's live paths from bounce 2 on, whenever that empties a wave (MODE_FUSED);
-    // after every bounce unconditionally (MODE_WAVEFRONT); never (MODE_STATIC)
+    // after every bounce unconditionally (MODE_REPACK_ALWAYS); never (MODE_STATIC)
     // (bit 31 stands for every bounce >= 31 and must stay set: the count exchange is also the loop's exit test when max_depth = -1)
-    a.compact_mask = p->mode == MI355_MODE_WAVEFRONT ? 0xffffffffu : 0xfffffffcu;
-    a.compact_adaptive = p->mode == MI355_MODE_WAVEFRONT ? 0u : 1u;
+    a.compact_mask = p->mode == MI355_MODE_REPACK_ALWAYS ? 0xffffffffu : 0xfffffffcu;
+    a.compact_adaptive = p->mode == MI355_MODE_REPACK_ALWAYS ? 0u : 1u;
     if (p->integrator == MI355_INTEGRATOR_PATH && a.passes > 1u) {          // samples_per_pass: the static kernel walks the passes of a stream
         if (full) hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
         else hipLaunchKernelGGL((k_render<MI355_INTEGRATOR_PATH, OUT_FILM, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, nof, s->d_counters);
@@ -2727,7 +2727,7 @@ extern "C" int mi355_render_accumulate(mi355_scene *s, const mi355_render_params
         if (flat) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, 2>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else if (full) hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, true>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else hipLaunchKernelGGL((k_render_compact<MI355_INTEGRATOR_PRB, false>), grid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
-    } else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN) && p->mode != MI355_MODE_WAVEFRONT) {       // enough samples per pixel to keep a wave's pool full
+    } else if (a.s_count >= 128u && (p->flags & MI355_FLAG_REGEN) && p->mode != MI355_MODE_REPACK_ALWAYS) {       // enough samples per pixel to keep a wave's pool full
         uint32_t n_waves = (a.pixel_count + a.ppw - 1) / a.ppw; dim3 rgrid((n_waves + WAVES - 1) / WAVES);
         if (flat) hipLaunchKernelGGL(k_render_regen<2>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);
         else if (full) hipLaunchKernelGGL(k_render_regen<true>, rgrid, block, 0, st, s->ds, a, d_film_rgbw, s->d_counters);

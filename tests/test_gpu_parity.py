@@ -226,8 +226,8 @@ def test_path_regeneration_matches_static(mi, orc, torch_cuda, spp, max_depth, r
 
 
 @pytest.mark.parametrize("spp,max_depth,rr_depth", [(16, 6, 5), (64, -1, 2), (3, 4, 5), (128, 2, 5)])
-def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_depth, rr_depth):
-    """Re-packing modes: MODE_FUSED (default: from bounce 2 on, when it empties a wave), MODE_WAVEFRONT (after every bounce),
+def test_repack_modes_match_fused(mi, orc, torch_cuda, cbox32, spp, max_depth, rr_depth):
+    """Re-packing modes: MODE_FUSED (default: from bounce 2 on, when it empties a wave), MODE_REPACK_ALWAYS (after every bounce; called MODE_WAVEFRONT up to ABI v8),
     MODE_STATIC (never).  Lanes are still pure functions of (seed, lane id), so the films must agree (up to float-atomic
     order) with each other and with the oracle's, and the event counts must be identical."""
     integ = mi.PathIntegrator({"max_depth": max_depth, "rr_depth": rr_depth})
@@ -237,7 +237,7 @@ def test_wavefront_mode_matches_fused(mi, orc, torch_cuda, cbox32, spp, max_dept
     static = integ.render(cbox32, seed=8, spp=spp, develop=False)
     c_static = integ.counters(cbox32, reset=True)
     assert torch_cuda.allclose(static, fused, rtol=1e-4, atol=1e-4)
-    integ.mode = mi.abi.MODE_WAVEFRONT
+    integ.mode = mi.abi.MODE_REPACK_ALWAYS
     integ.counters(cbox32, reset=True)
     wf = integ.render(cbox32, seed=8, spp=spp, develop=False)
     c_wf = integ.counters(cbox32, reset=True)
