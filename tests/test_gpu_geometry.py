@@ -13,6 +13,8 @@ where it applies: with the TENT filter the derivative of the splat weights is pi
 float rounding of a pixel centre can take the other side of the kink on the device (fp32) than in the oracle (fp64); such an event
 moves the handful of vertices of one triangle by ~1e-3 (seen once in seven seeds), so that case asserts on all but 5 % of the vertices.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -79,8 +81,24 @@ def _compare(mi, g, g_ref, lay, tol=1e-3, frac_ok=1.0, disabled=()):
         if frac_ok >= 1.0:
             assert e.max() < tol, "kind %d index %d: max rel err %.3e" % (k, i, e.max())
         else:
+            _log_partial(k, i, e, a, b, tol, frac_ok)
             assert (e < tol).mean() >= frac_ok and np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3, "kind %d index %d: %.3e, %.3f ok" % (k, i, e.max(), (e < tol).mean())
     return seen
+
+
+def _log_partial(kind, index, e, a, b, tol, frac_ok):
+    """The tent-filter cases are asserted on a FRACTION of the components (the filter's kink: fp32 on the device, fp64 in the oracle); which
+    components miss the bar and by how much goes to gpurun_out/geometry_partial_parity.txt (committed as profiles/r03_tent_filter_vertices.txt)."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if not os.path.isdir(out):
+        return
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    bad = np.nonzero(e >= tol)[0]
+    with open(os.path.join(out, "geometry_partial_parity.txt"), "a") as f:
+        f.write("%s  kind %d index %d: %d components, %d (%.2f %%) at or above %.0e of the block's largest reference component (asserted: >= %.0f %% below); "
+                "max %.3e, |a - b|_2 / |b|_2 = %.3e\n" % (test, kind, index, e.size, bad.size, 100.0 * bad.size / e.size, tol, 100 * frac_ok, e.max(), np.linalg.norm(a - b) / np.linalg.norm(b)))
+        for j in bad[np.argsort(-e[bad])][:12]:
+            f.write("    vertex %6d axis %s: device % .6e  oracle % .6e  error / max|oracle| = %.3e\n" % (j // 3, "xyz"[j % 3], a[j], b[j], e[j]))
 
 
 @pytest.mark.parametrize("case", ["cap-lens-gaussian", "cap-lens-tent", "cap-lens-box", "cap-lens-fixed-normals", "diffuse-floor", "glass-ball", "glass-ball-updated",
@@ -92,7 +110,7 @@ def test_geometry_backward_matches_oracle(mi, orc, torch_cuda, case):
     update = None; rr_depth = 5; max_depth = 4; spp = 16; seed = 2; res = 32; frac_ok = 1.0
     if case.startswith("cap-lens"):
         rf = case.split("-")[2] if case.split("-")[2] in ("gaussian", "tent", "box") else "gaussian"
-        d = _cap_lens_scene(mi, res, rfilter=rf); frac_ok = 0.95 if rf == "tent" else 1.0
+        d = _cap_lens_scene(mi, res, rfilter=rf)       # (the tent case was asserted on 95 % of the components up to round 2; measured now: every component, max 6e-7 -- profiles/r03_tent_filter_vertices.txt)
         if case != "cap-lens-fixed-normals":      # after a vertex update the normals follow the positions (mesh.cpp:138-139); before it they are data
             update = ("lens", lambda p: np.stack([p[:, 0], p[:, 1], 1.0 + (p[:, 2] - 1.0) * 1.05], axis=1))
     elif case == "diffuse-floor":               # a diffuse quad mesh under an area light: a connection at every vertex, roulette on

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 def grad_close(a, b, tol=1e-3, what=""):
     """The north star's gradient bar: max |a - b| <= tol * max |b| (1e-3 unless a test states why not).  The measured ratio of every
-    call is appended to gpurun_out/grad_parity.txt so that the committed profiles/r02_grad_parity.txt shows the margin of each test."""
+    call is appended to gpurun_out/grad_parity.txt so that the committed profiles/r03_grad_parity.txt shows the margin of each test."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     scale = max(float(np.abs(b).max()), 1e-30)
     err = float(np.abs(a - b).max()) / scale
