@@ -834,17 +834,27 @@ class FieldSource:
         if self.pos_changed:
             self.camera_pos[0] -= delta_x * pixel_size
 
-    def evaluate_rms_loss(self, image, recenter=False):
-        """:267-279: the spot's squared RMS radius in mm^2 and the upsample flag (spot smaller than a tenth of the image)."""
+    def spot_loss(self, image):
+        """The device half of evaluate_rms_loss: the spot's squared RMS radius in mm^2 (differentiable) and a 3-vector (pixel loss, centroid row,
+        centroid column) for the host half.  Nothing is read back here, so the next field's render can be queued behind this one."""
         torch = _torch()
         pixel_loss, ibar, jbar = rms_loss_and_center(image)
-        host_loss, host_i, host_j = torch.stack([pixel_loss.detach().reshape(()), ibar.reshape(()), jbar.reshape(())]).tolist()    # one read-back for the three
+        physical_loss = pixel_loss * self.get_pixel_size() ** 2
+        return physical_loss, torch.stack([pixel_loss.detach().reshape(()), ibar.reshape(()), jbar.reshape(())])
+
+    def apply_spot_stats(self, host_loss, host_i, host_j, recenter=False):
+        """The host half (:258-279): re-centre the camera on the spot, record the loss, return the upsample flag (spot smaller than a tenth of
+        the image).  None of it feeds back into the current iteration's renders, so it may run after all of them."""
         if recenter:
             self.center_camera_on_pixel(host_i, host_j)
-        upsample_flag = bool(host_loss < (self.resolution[0] * 0.1) ** 2)
-        physical_loss = pixel_loss * self.get_pixel_size() ** 2
         self.losses.append(host_loss * self.get_pixel_size() ** 2)
-        return physical_loss, upsample_flag
+        return bool(host_loss < (self.resolution[0] * 0.1) ** 2)
+
+    def evaluate_rms_loss(self, image, recenter=False):
+        """:267-279: the spot's squared RMS radius in mm^2 and the upsample flag -- the reference's immediate form (one read-back per call)."""
+        physical_loss, stats = self.spot_loss(image)
+        host_loss, host_i, host_j = stats.tolist()
+        return physical_loss, self.apply_spot_stats(host_loss, host_i, host_j, recenter)
 
 
 class DesignProblem:
@@ -943,21 +953,29 @@ class DesignProblem:
         self.lens_system.update(self.params, self.optimizer)
         for fs in self.field_sources:
             fs.update(self.params)
-        loss = None; upsample_flag = True
+        import torch
+        loss = None; pending = []
         # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
         # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
         for sensor_idx in range(self.num_sources):
             image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, sensor=sensor_idx, shard=getattr(self, "shard", None), group=getattr(self, "group", None))
-            sensor_loss, upsample = self.field_sources[sensor_idx].evaluate_rms_loss(image, recenter=recenter)
-            upsample_flag = upsample_flag and upsample
+            sensor_loss, stats = self.field_sources[sensor_idx].spot_loss(image)
+            pending.append(stats)
             loss = 10000.0 * sensor_loss if loss is None else loss + 10000.0 * sensor_loss
         loss.backward()
         self.optimizer.step()
+        # ONE read-back per iteration, behind everything that was queued: the centroids only move the cameras of the NEXT iteration and the
+        # flag is only looked at below (the reference reads three scalars per field as it goes; same values, same order of host updates)
+        host = torch.cat(pending + [loss.detach().reshape(1)]).tolist()
+        upsample_flag = True
+        for k, fs in enumerate(self.field_sources):
+            upsample_flag = fs.apply_spot_stats(host[3 * k], host[3 * k + 1], host[3 * k + 2], recenter=recenter) and upsample_flag
+        loss_value = host[-1]
         if upsample_flag:
             for fs in self.field_sources:
                 fs.upsample_sensor()
         self.params.update()
-        return float(loss.detach()), upsample_flag
+        return loss_value, upsample_flag
 
     def optimize(self, iters=None):
         losses = []; self.upsample_steps = 0
