@@ -2576,8 +2576,11 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         }
         cnt.shadow += wave_count(cast);
         active = next_active; ray = next_ray;
-        hit = scene_intersect<FULL>(sc, ray, active, stk);
-        cnt.isect += wave_count(active);
+        // ptracer.cpp:264-269 intersects the sampled ray and only THEN masks the lane with `depth < max_depth`: after the last vertex a path may
+        // shade, that intersection is computed and never read (it draws no random number either).  It is skipped here -- wave-uniform, `depth`
+        // is -- and on the lens doublet it was the one incoherent traversal of every light path (a cosine-distributed bounce off the film).
+        if (max_depth >= 0 && depth + 1 >= max_depth) active = false;
+        else { hit = scene_intersect<FULL>(sc, ray, active, stk); cnt.isect += wave_count(active); }
         depth++;
         if (max_depth >= 0) active = active && depth < max_depth;
         active = active && hit.t != MI_INF;

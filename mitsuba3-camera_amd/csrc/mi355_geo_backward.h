@@ -221,7 +221,8 @@ MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth
         }
         const bool was_active = active; const Ray in_ray = ray; const Hit in_hit = hit;
         active = next_active; ray = next_ray;
-        hit = scene_intersect<FULL>(sc, ray, active, stk);
+        if (max_depth >= 0 && depth + 1 >= max_depth) active = false;       // the reference's last intersection is never read (see ptracer_sample)
+        else hit = scene_intersect<FULL>(sc, ray, active, stk);
         depth++;
         if (max_depth >= 0) active = active && depth < max_depth;
         active = active && hit.t != MI_INF;

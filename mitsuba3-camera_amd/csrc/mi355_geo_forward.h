@@ -319,7 +319,8 @@ MI_DEV void ptracer_sample_geo(const DScene &sc, const GeoTangent &gt, Pcg32 &rn
             o = dh.p + dh.ng * mag; d = wo;
         }
         active = next_active; ray = next_ray;
-        hit = scene_intersect<FULL>(sc, ray, active, stk);
+        if (max_depth >= 0 && depth + 1 >= max_depth) active = false;       // the reference's last intersection is never read (see ptracer_sample)
+        else hit = scene_intersect<FULL>(sc, ray, active, stk);
         depth++;
         if (max_depth >= 0) active = active && depth < max_depth;
         active = active && hit.t != MI_INF;

@@ -298,6 +298,7 @@ typedef struct {
     float *lens; uint32_t lens_count; float film_px, film_py;   /* realisticlens: interface table, physical half extents */
     float pupil[64 * 4];                                          /* exit-pupil bounds (min.x, min.y, max.x, max.y) per film-radius segment */
     uint64_t c_isect, c_shade, c_shadow;                  /* event counters */
+    uint64_t c_isect_dead;                                /* light tracer: intersections the reference computes and never reads (orc_dead_intersections) */
     /* Scene::sensors(): every sensor of the scene; the fields above (`sensor` ... `pupil`) are those of sensor `cur_sensor`, the one the
        `Sensor *` argument of Integrator::render picks (mi355_render_params.sensor; integrator.h:74-97) */
     mi355_sensor_desc *all_sensors; float **all_lens; float *all_pupil; int *pupil_done; uint32_t n_sensors, cur_sensor;
@@ -471,6 +472,9 @@ ORC_API void orc_get_counters(OScene *s, uint64_t out[3], int reset) {
     out[0] = s->c_isect; out[1] = s->c_shade; out[2] = s->c_shadow;
     if (reset) s->c_isect = s->c_shade = s->c_shadow = 0;
 }
+/* Light tracer (orc_ptracer_render): how many intersections the reference's loop computed and never read (ptracer.cpp:264-269) -- NOT part of
+   c_isect, so that c_isect is what an implementation that skips them performs. */
+ORC_API uint64_t orc_dead_intersections(OScene *s, int reset) { uint64_t v = s->c_isect_dead; if (reset) s->c_isect_dead = 0; return v; }
 
 /* ----------------------------------------------------------------------------------------
  * rays and intersections
@@ -1416,7 +1420,7 @@ static float sample_lens_ray(const OScene *sc, v2 sample_pos, v2 aperture_sample
 /* ----------------------------------------------------------------------------------------
  * PathIntegrator::sample -- src/integrators/path.cpp:95-287 (JIT masking semantics)
  * ---------------------------------------------------------------------------------------- */
-typedef struct { uint64_t isect, shade, shadow; } Cnt;
+typedef struct { uint64_t isect, shade, shadow, isect_dead; } Cnt;
 
 /* keep_stream (samples_per_pass): every sampler call in the loop of path.cpp:142-281 is unmasked and the loop masks by `active` alone, so a
    lane draws six numbers in EVERY iteration it enters -- also in the one that leaves the scene (:196, :212-213, :272) */
@@ -1943,7 +1947,10 @@ static void ptracer_sample(OScene *sc, const mi355_render_params *rp, pcg32 *rng
         }
         if (!active) break;
         ray = spawn_ray(si.p, si.n, wo_world);
-        pi = scene_intersect(sc, &ray); cnt->isect++; si = compute_si(sc, &ray, &pi);
+        /* :264-269: the reference intersects the sampled ray and THEN masks by depth < max_depth, so the intersection after the last vertex that may
+           be shaded is computed and never read.  It is performed here as written, but counted apart (c_isect_dead): the device skips it. */
+        pi = scene_intersect(sc, &ray); if (max_depth >= 0 && depth + 1 >= max_depth) cnt->isect_dead++; else cnt->isect++;
+        si = compute_si(sc, &ray, &pi);
         depth++;
         if (max_depth >= 0) active = active && depth < max_depth;
         active = active && si.shape >= 0;
@@ -2018,12 +2025,14 @@ ORC_API uint64_t orc_ptracer_accumulate(OScene *sc, const mi355_render_params *r
 #else
         float *film = films;
 #endif
-        Cnt cnt = { 0, 0, 0 };
+        Cnt cnt = { 0, 0, 0, 0 };
         g_importance_mode = 1;
         #pragma omp for schedule(dynamic, 4096)
         for (int64_t i = 0; i < (int64_t) lanes; ++i) ptracer_lane(sc, rp, pt_shard_lane(sc, rp, (uint64_t) i), sample_scale, film, &cnt);
         g_importance_mode = 0;
         ci += cnt.isect; cs += cnt.shade; csh += cnt.shadow;
+        #pragma omp atomic
+        sc->c_isect_dead += cnt.isect_dead;
     }
     for (int t = 0; t < n_threads; ++t) for (size_t i = 0; i < fsz; ++i) film_rgbw[i] += films[fsz * (size_t) t + i];
     free(films);
@@ -2091,7 +2100,7 @@ ORC_API uint64_t orc_ptracer_backward(OScene *sc, const mi355_render_params *rp,
 #else
         double *acc = accs; float *gl = grads;
 #endif
-        Cnt cnt = { 0, 0, 0 };
+        Cnt cnt = { 0, 0, 0, 0 };
         g_importance_mode = 1; g_ptg.grad_image = grad_image; g_ptg.acc = acc;
         g_ptg.grad = gl; g_ptg.layout = layout; g_ptg.bsdf_slot = bsdf_slot; g_ptg.tex_slot = tex_slot;
         #pragma omp for schedule(dynamic, 4096)
@@ -2186,7 +2195,7 @@ ORC_API uint64_t orc_render_accumulate(OScene *sc, const mi355_render_params *rp
 #else
         float *film = films;
 #endif
-        Cnt cnt = { 0, 0, 0 };
+        Cnt cnt = { 0, 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
         for (int64_t q = 0; q < (int64_t) pn; ++q) {
             const uint32_t passes = rp->passes ? rp->passes : 1u, streams = rp->spp / passes;
@@ -2293,7 +2302,7 @@ ORC_API void orc_render_backward(OScene *sc, const mi355_render_params *rp, cons
         float *gl = grads;
 #endif
         GradCtx g = { gl, layout, (uint32_t) np, bsdf_slot, tex_slot, em_slot };
-        Cnt cnt = { 0, 0, 0 };
+        Cnt cnt = { 0, 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
         for (int64_t q = 0; q < (int64_t) pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
             uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;
@@ -2342,7 +2351,7 @@ ORC_API uint64_t orc_render_forward(OScene *sc, const mi355_render_params *rp, c
 #else
         float *film = films;
 #endif
-        Cnt cnt = { 0, 0, 0 };
+        Cnt cnt = { 0, 0, 0, 0 };
         #pragma omp for schedule(dynamic, 64)
         for (int64_t q = 0; q < (int64_t) pn; ++q) for (uint32_t s = s0; s < s0 + sn; ++s) {
             uint32_t lane = shard_pixel(rp, (uint32_t) q) * rp->spp + s;

@@ -74,6 +74,7 @@ def lib(abi):
     l.orc_shape_surface_area.argtypes = [C.c_void_p, C.c_uint32]
     l.orc_texture_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
     l.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_dead_intersections.restype = C.c_uint64; l.orc_dead_intersections.argtypes = [C.c_void_p, C.c_int]
     l.orc_num_threads.restype = C.c_int
     l.orc_exit_pupil_bounds.argtypes = [C.c_void_p, C.c_void_p]
     l.orc_ptracer_accumulate.restype = C.c_uint64
@@ -249,7 +250,8 @@ class OracleScene:
     def counters(self, reset=False):
         c = np.zeros(3, dtype=np.uint64)
         self.l.orc_get_counters(self.h, _p(c), 1 if reset else 0)
-        return {"n_isect": int(c[0]), "n_shade": int(c[1]), "n_shadow": int(c[2])}
+        dead = int(self.l.orc_dead_intersections(self.h, 1 if reset else 0))     # light tracer: computed by the reference, never read (ptracer.cpp:264-269)
+        return {"n_isect": int(c[0]), "n_shade": int(c[1]), "n_shadow": int(c[2]), "n_isect_dead": dead}
 
 
 def geo_mesh_hit_jacobian(l, tri, normals, o, d, flip=False):
