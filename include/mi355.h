@@ -484,7 +484,11 @@ int mi355_scene_info(const mi355_scene *scene, uint32_t out[8]);
      mi355_prb_splat_weights kernel -> hook(weight, W*H)
      mi355_render_backward   kernels -> hook(grad_params, total_floats)     (d_grad_params must be zero on entry on all ranks but one)
    mi355_render_accumulate never calls it.  The hook is a collective: every rank reaches it, also a rank whose shard is empty.  It
-   returns 0 on success; anything else fails the call with MI355_ERR_DEVICE.  fn = NULL removes the hook. */
+   returns 0 on success; anything else fails the call with MI355_ERR_DEVICE.  fn = NULL removes the hook.
+   A call that FAILS before the exchange (an allocation of the tape or the record queue, an invalid argument on one rank only) returns its
+   error WITHOUT reaching the hook: the other ranks are then waiting in a collective this rank will never join, so the caller must abort
+   the job on any error of a hooked call -- as with any failed collective.  (Argument errors are the same on every rank by construction:
+   every rank passes the same parameters but for its shard.) */
 typedef int (*mi355_reduce_fn)(void *user, float *d_buffer, uint64_t count, void *stream);
 int mi355_set_reduce_hook(mi355_scene *scene, mi355_reduce_fn fn, void *user);
 
