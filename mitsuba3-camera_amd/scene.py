@@ -431,6 +431,9 @@ class Sensor:
             self.x_fov = 0.0
         else:
             self.x_fov = float(np.float32(parse_fov(props, self.film.width / float(self.film.height))))
+            if float(props.get("principal_point_offset_x", 0.0)) != 0.0 or float(props.get("principal_point_offset_y", 0.0)) != 0.0:
+                # perspective.cpp:147-149, :215-221, :296-301: not carried by the engine -- refuse rather than render with the offset ignored
+                raise PluginError("perspective: a non-zero principal_point_offset is outside the path in this build")
         smp = props.get("sampler", {"type": "independent"})
         if smp.get("type", "independent") != "independent":
             raise PluginError('sampler plugin "%s" is outside the path (independent)' % smp.get("type"))

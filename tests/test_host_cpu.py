@@ -75,6 +75,8 @@ def test_load_dict_errors_and_scope(mi):
         mi.load_dict({"type": "scene", "r": {"type": "rectangle", "bsdf": {"type": "ref", "id": "nope"}}})
     with pytest.raises(mi.PluginError):                             # camera scale (perspective.cpp:144-145)
         mi.load_dict({"type": "scene", "sensor": {"type": "perspective", "to_world": mi.ScalarTransform4f.scale(2.0)}})
+    with pytest.raises(mi.PluginError):                             # perspective.cpp:147-149: an offset the engine does not carry is refused, not ignored
+        mi.load_dict({"type": "scene", "sensor": {"type": "perspective", "principal_point_offset_x": 0.1}})
     with pytest.raises(mi.PluginError):
         mi.PathIntegrator({"rr_depth": 0})
     with pytest.raises(mi.PluginError):
