@@ -337,7 +337,7 @@ def test_veach_lane_radiance(mi, orc, torch_cuda, veach64, integrator_name, max_
     ref = o.lane_radiance(o.params(integ, seed, spp), 0, n)
     got = integ.lane_radiance(veach64, seed, spp, 0, n).cpu().numpy()
     assert np.isfinite(got).all()
-    # glossy lobes amplify ulp-level differences (v_exp / v_rcp / v_rsq / sincos of gfx950 vs glibc).  Measured (tools/lane_parity.py,
+    # glossy lobes amplify ulp-level differences (v_exp / v_rcp / v_rsq / sincos of gfx950 vs glibc).  Measured (tests/tools/lane_parity.py,
     # profiles/r02_lane_parity.txt): 99.98 % of the lanes within rtol 2e-4, every lane within 2e-3, means equal to 5 digits; a
     # -DMI_EXACT_MATH build is listed next to it.
     same = got[:, 3] == ref[:, 3]

@@ -1,7 +1,7 @@
 """Development check of the geometry adjoint (GPU): device render_backward(geometry=True) against the oracle's multi-dual derivative."""
 import sys, os, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package, load_oracle
 mi = load_package(); orc = load_oracle()
 ld = mi.lens_design

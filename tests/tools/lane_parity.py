@@ -1,9 +1,9 @@
 """Lane-level agreement with the oracle on the glossy scene (test_veach_lane_radiance's lanes) at several tolerances, for the library
 named by MI355_LIB -- run once with the shipped build and once with a -DMI_EXACT_MATH build to see what the hardware approximations
-(v_rcp / v_rsq / v_sqrt / v_exp / v_sin) buy.  Usage (GPU box):  [MI355_LIB=build/libmi355_exact.so] python tools/lane_parity.py"""
+(v_rcp / v_rsq / v_sqrt / v_exp / v_sin) buy.  Usage (GPU box):  [MI355_LIB=build/libmi355_exact.so] python tests/tools/lane_parity.py"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package, load_oracle
 mi = load_package(); orc = load_oracle(); orc.lib(mi.abi)
 scene = mi.load_dict(mi.veach_mis_scene(64)); o = orc.OracleScene(scene, mi.abi)
