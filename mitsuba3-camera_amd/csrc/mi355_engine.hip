@@ -1199,11 +1199,19 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DSc
     const GeoBwdSink sink = { grad_rgb, d_grad, d_nrm_adj, n_ior_lds ? s_ior_dyn : nullptr, FULL == 1 ? reinterpret_cast<uint32_t *>(smem) : nullptr };
     const uint32_t slot = min(t, tape.stride - 1u);
     for (uint32_t pass = 0; pass < a.passes; ++pass) {
-        const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, stk, tape, slot);
+        uint32_t n_sweep;
+        const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, stk, tape, slot, n_sweep);
 #ifndef MI_GEO_NO_SWEEP
-        if (FULL == 1) { __syncthreads(); vertex_adj_clear(sink.tab); __syncthreads(); }
-        ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, sink);
-        if (FULL == 1) { __syncthreads(); vertex_adj_flush(sink); __syncthreads(); }
+        if (FULL == 1) {
+            // (the barrier that separates the walk's traversal stacks from the table also tells whether ANY path of the workgroup has something to
+            //  sweep: sorted by emitter, whole workgroups carry the light of a field source this sensor does not see)
+            if (__syncthreads_or(n_sweep != 0u)) {
+                vertex_adj_clear(sink.tab); __syncthreads();
+                ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, n_sweep, sink);
+                __syncthreads(); vertex_adj_flush(sink);
+            }
+            __syncthreads();
+        } else ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, n_sweep, sink);
 #endif
     }
     __syncthreads();

@@ -157,7 +157,11 @@ MI_DEV void tape_store(const GeoTape &tp, uint32_t lane, uint32_t k, const Ray &
 // vertices on the tape.
 template <int FULL>
 MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                                 uint32_t *stk, const GeoTape &tp, uint32_t lane) {
+                                 uint32_t *stk, const GeoTape &tp, uint32_t lane, uint32_t &n_sweep) {
+    // n_sweep (out): 1 + the index of the LAST vertex that made a sensor connection.  The image adjoint enters a path only at its connections,
+    // so every vertex behind the last one has a zero adjoint and the sweep starts there -- for a light path that never reached this sensor's
+    // view (the light of the OTHER field sources of a lens-design scene: two paths in three) it does not start at all.
+    n_sweep = 0u;
     const bool timed = sc.shutter_open_time > 0.f;
     if (max_depth != 0 && !hide_emitters) {                                // sample_visible_emitters: static emitter and sensor -> no derivative;
         if (timed) (void) next_1d(rng);                                     // the stream advances exactly as in ptracer_sample
@@ -232,13 +236,13 @@ MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth
             if (active) active = next_1d(rng) < q;
             rr = 1.f / q; throughput = throughput * rr;                     // roulette probability detached
         }
-        if (was_active && nv < MI_TAPE_MAX_VERTS) { tape_store(tp, lane, nv, in_ray, T_in, in_hit, W, rr, flags); nv++; }
+        if (was_active && nv < MI_TAPE_MAX_VERTS) { tape_store(tp, lane, nv, in_ray, T_in, in_hit, W, rr, flags); nv++; if (flags & MI_TF_CONN) n_sweep = nv; }
     }
     return nv;
 }
 // Backward sweep over the `nv` tape records of one light sample, last vertex first: gradients into the sink.  No ray is traced here.
 template <int FULL>
-MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, const GeoBwdSink &sink) {
+MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, uint32_t n_sweep, const GeoBwdSink &sink) {
     gv3 lo = ga::mk<float>(0.f, 0.f, 0.f), ld = lo, lT = lo;               // lambda: adjoint of the ray / throughput LEAVING the current vertex
     ga::Sensor<float> se;
     {
@@ -250,7 +254,7 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
         se.crop_w = (float) sc.crop_w; se.crop_h = (float) sc.crop_h; se.crop_x = (float) sc.crop_x; se.crop_y = (float) sc.crop_y;
         se.normalization = sc.normalization;
     }
-    for (int32_t k = (int32_t) nv - 1; k >= 0; --k) {
+    for (int32_t k = (int32_t) n_sweep - 1; k >= 0; --k) {                  // (n_sweep <= nv: see ptracer_geo_walk)
         const float *b = tp.base + (size_t) k * MI_TAPE_FIELDS * tp.stride + lane; const size_t s = tp.stride;
         Ray r; r.o = V3(b[0], b[s], b[2 * s]); r.d = V3(b[3 * s], b[4 * s], b[5 * s]); r.maxt = MI_LARGEST;
         const v3 T = V3(b[6 * s], b[7 * s], b[8 * s]);
@@ -336,9 +340,10 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
 template <int FULL>
 MI_DEV void ptracer_sample_geo_bwd(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                                    float sample_scale, uint32_t *stk, const GeoTape &tp, uint32_t lane, const GeoBwdSink &sink) {
-    const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, max_depth, rr_depth, hide_emitters, lane_on, stk, tp, lane);
+    uint32_t n_sweep;
+    const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, max_depth, rr_depth, hide_emitters, lane_on, stk, tp, lane, n_sweep);
 #ifndef MI_GEO_NO_SWEEP
-    ptracer_geo_sweep<FULL>(sc, sample_scale, tp, lane, nv, sink);
+    ptracer_geo_sweep<FULL>(sc, sample_scale, tp, lane, nv, n_sweep, sink);
 #endif
 }
 
