@@ -794,7 +794,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     if params is not None:
         params.update(skip=diff_keys)      # (the differentiable ones are pushed by the render op itself, every time: their tensors may be edited in place)
     if not diff_keys:
-        return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
+        return integrator.render(scene, sensor, seed=seed, spp=spp, evaluate=False, shard=shard, group=group)     # util.py:376-384: develop=True, evaluate=False
     sensor = scene.sensor_index(sensor)
 
     class _RenderOp(torch.autograd.Function):
@@ -802,7 +802,9 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         def forward(ctx, *tensors):
             for k, t in zip(diff_keys, tensors):
                 params._push(k, t); params._dirty.discard(k)
-            return integrator.render(scene, sensor, seed=seed, spp=spp, shard=shard, group=group)
+            # util.py:376-384: _RenderOp.eval renders with develop=True, evaluate=False -- the image is queued, not waited for, so the host goes
+            # on to queue the loss and the next field's render while this one runs (Integrator.render's own default stays evaluate=True)
+            return integrator.render(scene, sensor, seed=seed, spp=spp, evaluate=False, shard=shard, group=group)
 
         @staticmethod
         def backward(ctx, grad_out):
