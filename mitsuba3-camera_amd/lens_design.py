@@ -557,9 +557,40 @@ class LensSystem:
         ap_radius = self.elements[self.aperture_index].surface.radial_extent
         return z_exit, z_entrance, ap_radius / self.pupil_rear_matrix[0, 0], ap_radius / self.pupil_front_matrix[1, 1]
 
+    def _differentiable_EFL_matrix(self):
+        """get_EFL_paraxial_matrix (lens.py:884-912) on the scalars AS THEY ARE: optimised scalars are 1-element tensors with a graph behind them
+        (after update()), and the constrained rear surface must stay a differentiable function of them -- in the reference these are Dr.Jit
+        floats and AD follows the constraint.  2 x 2 products spelled out so that floats and tensors mix."""
+        def val(x):
+            return x.reshape(()) if _torch().is_tensor(x) else float(x)
+        M = ((1.0, 0.0), (0.0, 1.0)); n_mat = len(self.materials)
+        for idx in range(1, len(self.elements)):
+            thickness = val(self.elements[idx].surface.params['z0']) - val(self.elements[idx - 1].surface.params['z0'])
+            curvature = -val(self.elements[idx].surface.params['c']) / self.elements[idx].surface.radial_extent
+            ior_i = val(self.materials[idx].params['ior']); ior_f = val(self.materials[(idx + 1) % n_mat].params['ior'])
+            m10 = -(ior_f - ior_i) * curvature / ior_f; m11 = ior_i / ior_f
+            # lens_matrix = [[1, 0], [m10, m11]]; transit = [[1, t], [0, 1]]; elem = lens @ transit = [[1, t], [m10, m10 t + m11]]
+            E = ((1.0, 0.0), (m10, m11)) if idx == 1 else ((1.0, thickness), (m10, m10 * thickness + m11))
+            M = ((E[0][0] * M[0][0] + E[0][1] * M[1][0], E[0][0] * M[0][1] + E[0][1] * M[1][1]),
+                 (E[1][0] * M[0][0] + E[1][1] * M[1][0], E[1][0] * M[0][1] + E[1][1] * M[1][1]))
+        return M
+
     def get_rear_surface_params(self, f):
         """lens.py:970-997: curvature (dimensionless) and axial position of the rear surface that give the system the focal length `f`
-        and put its paraxial focus on the film plane."""
+        and put its paraxial focus on the film plane.  Plain floats while every scalar involved is one; 1-element tensors that carry the
+        constraint's derivative as soon as one of them is an optimiser variable (ConstrainedEFLProblem)."""
+        torch = _torch()
+        involved = [self.materials[0].params['ior'], self.materials[1].params['ior']] + [m.params['ior'] for m in self.materials[1:]] \
+            + [e.surface.params[k] for e in self.elements[1:] for k in ('c', 'z0')]
+        if any(torch.is_tensor(v) and v.requires_grad for v in involved):
+            M = self._differentiable_EFL_matrix(); C, D = M[1][0], M[1][1]
+            val = lambda x: x.reshape(()) if torch.is_tensor(x) else float(x)
+            k = val(self.materials[0].params['ior']) / val(self.materials[1].params['ior'])
+            z2 = val(self.elements[1].surface.params['z0'])
+            surf_z0 = f * k * (C * z2 + D) / (1.0 + f * k * C)
+            surf_c = -(1.0 / f + C) / ((C * (z2 - surf_z0) + D) * (1 - k))
+            as1 = lambda x: x.reshape(1) if torch.is_tensor(x) else x
+            return {'c': as1(surf_c * self.elements[0].surface.radial_extent), 'z0': as1(surf_z0)}
         Mk = self.get_EFL_paraxial_matrix()
         C, D = Mk[1, 0], Mk[1, 1]
         k = _f(self.materials[0].params['ior']) / _f(self.materials[1].params['ior'])
@@ -945,12 +976,15 @@ class DesignProblem:
         self.lens_system.add_to_optimizer(self.optimizer, dev)
         return self
 
+    def _update_lens_system(self):
+        self.lens_system.update(self.params, self.optimizer)
+
     def step(self, it, recenter=True):
         """One iteration of optimize() (:508-565): update the scene from the optimizer, update the field cameras, render every field
         differentiably, back-propagate the summed spot loss (x 10000, as the notebook scales it), take the optimizer step.  Returns
         (loss, upsample_flag)."""
         from .integrators import render
-        self.lens_system.update(self.params, self.optimizer)
+        self._update_lens_system()
         for fs in self.field_sources:
             fs.update(self.params)
         import torch
@@ -1007,6 +1041,35 @@ class DesignProblem:
                 self.params[key + ".size"] = saved[0]; self.params[key + ".crop_size"] = saved[1]; self.params[key + ".crop_offset"] = saved[2]
             self.params.update()
         return image
+
+
+class ConstrainedEFLProblem(DesignProblem):
+    """design_problem.py:656-803: the design problem with the system's effective focal length held at `target_focal_length`.  The rear surface's
+    first-order parameters (c, z0) leave the optimiser; in every iteration they are re-derived from the other surfaces and the glasses
+    (LensSystem.fixed_EFL_update -> get_rear_surface_params), and the gradient follows that constraint."""
+
+    def __init__(self, lens_system, resolution, spp, learning_rate, target_focal_length, iters, film_diagonal=35.0, num_sources=1, max_field_angle=5.0,
+                 init_camera_z=0.9, fov=135.0):
+        self.target_focal_length = float(target_focal_length)
+        lens_system.disable_var_in_surface('c', 0); lens_system.disable_var_in_surface('z0', 0)          # :673-676
+        s1 = lens_system.get_rear_surface_params(self.target_focal_length)                                 # :678-682
+        lens_system.elements[0].surface.params['c'] = _f(s1['c']); lens_system.elements[0].surface.params['z0'] = _f(s1['z0'])
+        lens_system.compute_paraxial_quantities()
+        super().__init__(lens_system, resolution, spp, learning_rate, iters, film_diagonal=film_diagonal, num_sources=num_sources,
+                         max_field_angle=max_field_angle, init_camera_z=init_camera_z, fov=fov)
+
+    def _update_lens_system(self):
+        self.lens_system.fixed_EFL_update(self.params, self.optimizer, self.target_focal_length)        # :722
+
+    def optimize(self, iters=None):
+        """:705-803: as DesignProblem.optimize, the learning rate dropping to a tenth at 50 % and at 70 % of the iterations (:786-788)."""
+        losses = []; self.upsample_steps = 0
+        for it in range(self.iters if iters is None else iters):
+            loss, up = self.step(it)
+            losses.append(loss); self.upsample_steps += int(up)
+            if it in (int(0.5 * self.iters), int(0.7 * self.iters)):
+                self.optimizer.set_learning_rate(0.1 * self.optimizer.lr_default)
+        return losses
 
 
 def radical_inverse_2(index, scramble=0):

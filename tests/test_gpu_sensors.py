@@ -254,6 +254,32 @@ def test_three_field_design_problem(mi, orc, torch_cuda):
     scene.release()
 
 
+def test_constrained_focal_length_problem(mi, torch_cuda):
+    """design_problem.py:656-803, ConstrainedEFLProblem (notebooks/design-problem-multi-spot-efl.ipynb): the rear surface's c and z0 leave the
+    optimiser and are re-derived from the other surfaces in every iteration so that the system keeps its focal length; the gradient follows
+    the constraint.  Eight iterations on the doublet at icosphere level 5: the focal length stays at the target to 1e-4 mm while the other
+    surfaces move, the rear surface moves with them, the paraxial focus stays on the film, and the loss stays where the constraint put it."""
+    torch = torch_cuda
+    ld = mi.lens_design
+    system = _doublet(ld, 5, constrained=False)
+    problem = ld.ConstrainedEFLProblem(system, resolution=(32, 32), spp=16, learning_rate=3e-5, target_focal_length=50.0, iters=8, num_sources=3,      # (the notebook's rate)
+                                       max_field_angle=5.0, init_camera_z=0.01).prepare()
+    keys = set(problem.optimizer.keys())
+    assert "lens0_c" not in keys and "lens0_z0" not in keys and "lens0_K" in keys and "lens1_c" in keys and len(keys) == 28
+    assert abs(system.compute_EFL() - 50.0) < 1e-6
+    c0 = float(ld._f(system.elements[0].surface.params['c'])); c1 = float(ld._f(system.elements[1].surface.params['c'])); handle = problem.scene._handle
+    losses = problem.optimize()
+    assert len(losses) == 8 and np.isfinite(losses).all() and max(losses) < 2.0 * losses[0]        # (in focus from the start: eight small steps keep it there)
+    assert problem.scene._handle is handle
+    assert abs(system.compute_EFL() - 50.0) < 1e-4, system.compute_EFL()                       # the constraint held through the steps ...
+    assert abs(system.compute_BFL() - ld._f(system.elements[0].surface.params['z0'])) < 1e-4        # ... and the paraxial focus is on the film
+    assert abs(ld._f(system.elements[1].surface.params['c']) - c1) > 1e-5                       # the free surfaces moved ...
+    assert abs(ld._f(system.elements[0].surface.params['c']) - c0) > 1e-7                       # ... and the constrained one followed them
+    for k in ("lens1_c", "lens1_z0", "lens2_c"):                                               # the last step's gradients reached the free scalars
+        assert problem.optimizer[k].grad is None                                               # (a step replaces the variables: fresh leaves)
+    problem.scene.release()
+
+
 def test_geometry_gradients_refuse_an_emitter_mesh(mi, torch_cuda):
     """The geometry adjoint treats emitters as static (the sampled emitter position / direction carries no derivative), so a gradient slot on
     a mesh that carries an area emitter would silently miss the term Dr.Jit's AD includes: MI355_ERR_UNSUPPORTED, as the forward design

@@ -196,3 +196,42 @@ def test_tracer_check_reproduces_the_notebooks_numbers_at_its_mesh_level(mi, orc
     assert abs(err_u - ref["u"]) < 0.05 * ref["u"], (err_u, ref["u"])
     assert abs(err_y - ref["y"]) < 0.3 * ref["y"], (err_y, ref["y"])
     assert (err_u < ref["atol_asked"]) == ref["u_is_close"] and (err_y < ref["atol_asked"]) == ref["y_is_close"]
+
+
+def test_focal_length_constraint_is_differentiable(mi):
+    """ConstrainedEFLProblem (design_problem.py:656-703) re-derives the rear surface's c and z0 from the OTHER surfaces in every iteration
+    (LensSystem.fixed_EFL_update -> get_rear_surface_params, lens.py:970-997, :1023-1042), and in the reference Dr.Jit's AD follows that
+    constraint.  Here: with optimiser-like scalars (1-element tensors that require grad) get_rear_surface_params returns tensors whose
+    gradients equal central finite differences of the plain-float evaluation, and the constrained system keeps its focal length."""
+    import torch
+    ld = mi.lens_design
+    system = _doublet(ld, 3, constrained=False)
+    base = {(e, k): float(system.elements[e].surface.params[k]) for e in (1, 2) for k in ('c', 'z0')}
+    plain = system.get_rear_surface_params(50.0)
+    assert isinstance(plain['c'], float) and isinstance(plain['z0'], float)
+    leaves = {}
+    for (e, k), v in base.items():
+        leaves[(e, k)] = torch.tensor([v], dtype=torch.float64, requires_grad=True); system.elements[e].surface.params[k] = leaves[(e, k)]
+    out = system.get_rear_surface_params(50.0)
+    assert torch.is_tensor(out['c']) and out['c'].shape == (1,) and abs(float(out['c'].detach()) - plain['c']) < 1e-12 and abs(float(out['z0'].detach()) - plain['z0']) < 1e-10
+    for name in ('c', 'z0'):
+        for t in leaves.values():
+            t.grad = None
+        out = system.get_rear_surface_params(50.0); out[name].sum().backward()
+        for (e, k), t in leaves.items():
+            h = 1e-6 * max(1.0, abs(base[(e, k)]))
+            vals = []
+            for sgn in (+1, -1):
+                for (e2, k2), v2 in base.items():
+                    system.elements[e2].surface.params[k2] = v2 + (sgn * h if (e2, k2) == (e, k) else 0.0)
+                vals.append(system.get_rear_surface_params(50.0)[name])
+            fd = (vals[0] - vals[1]) / (2 * h)
+            for (e2, k2), t2 in leaves.items():
+                system.elements[e2].surface.params[k2] = t2
+            assert abs(float(t.grad) - fd) <= 1e-5 * max(abs(fd), 1e-6) + 1e-9, (name, e, k, float(t.grad), fd)
+    # the constrained system has the focal length it was asked for, and its paraxial focus on the film plane (z = 0)
+    for (e, k), v in base.items():
+        system.elements[e].surface.params[k] = v
+    s1 = system.get_rear_surface_params(50.0)
+    system.elements[0].surface.params['c'] = s1['c']; system.elements[0].surface.params['z0'] = s1['z0']; system.compute_paraxial_quantities()
+    assert abs(system.compute_EFL() - 50.0) < 1e-9 and abs(system.compute_BFL() - s1['z0']) < 1e-9
