@@ -235,3 +235,58 @@ def test_focal_length_constraint_is_differentiable(mi):
     s1 = system.get_rear_surface_params(50.0)
     system.elements[0].surface.params['c'] = s1['c']; system.elements[0].surface.params['z0'] = s1['z0']; system.compute_paraxial_quantities()
     assert abs(system.compute_EFL() - 50.0) < 1e-9 and abs(system.compute_BFL() - s1['z0']) < 1e-9
+
+
+def _cooke_triplet(ld, subdiv):
+    """notebooks/design-problem-multi-spot-efl.ipynb cell 6: the Cooke triplet "from OSLO", six surfaces, three glasses with air between them."""
+    surfs = [{'radial_extent': 6.5, 'c': -17.285, 'z0': 42.95}, {'radial_extent': 6.5, 'c': 141.25, 'z0': 44.95}, {'radial_extent': 5.0, 'c': 19.3, 'z0': 50.95},
+             {'radial_extent': 5.0, 'c': -20.25, 'z0': 51.95}, {'radial_extent': 6.5, 'c': -158.65, 'z0': 57.95}, {'radial_extent': 6.5, 'c': 21.25, 'z0': 59.95}]
+    surfaces = [ld.EvenAsphericSurface(K=0, radial_extent=s['radial_extent'], c=1.0 / s['c'], z0=s['z0']) for s in surfs]
+    mats = [ld.LensMaterial("sk16", 1.62041, 60.32), ld.LensMaterial(), ld.LensMaterial("f4", 1.616592, 36.63), ld.LensMaterial(), ld.LensMaterial("sk16", 1.62041, 60.32)]
+    system = ld.LensSystem(surfaces, mats, aperture_index=None, subdiv_levels=subdiv)
+    system.disable_all_materials()
+    s1 = system.get_rear_surface_params(50.0)
+    system.elements[0].surface.params['c'] = s1['c']; system.elements[0].surface.params['z0'] = s1['z0']
+    system.compute_paraxial_quantities()
+    return system
+
+
+def test_cooke_triplet_matches_the_second_notebooks_stored_outputs(mi):
+    """design-problem-multi-spot-efl.ipynb, stored output of cell 6 (float32 Dr.Jit arithmetic there, double here):
+        Focal length target:  [49.99998092651367]  vs.  50.0
+        BFL focus target:  [43.05345153808594]  vs.  [43.05345916748047]
+        Exit pupil position:  -25.17422180175781
+        Entrance pupil position:  -7.629394502828291e-07"""
+    ld = mi.lens_design
+    system = _cooke_triplet(ld, 3)
+    assert abs(system.compute_EFL() - 49.99998092651367) < 5e-5
+    assert abs(system.compute_BFL() - 43.05345153808594) < 2e-5 and abs(ld._f(system.elements[0].surface.params['z0']) - 43.05345916748047) < 2e-5
+    assert abs((system.rear_z - system.exit_pupil_position) - (-25.17422180175781)) < 1e-4
+    assert abs(system.front_z - system.entrance_pupil_position) < 1e-5
+    assert system.size() == 6 and [m.name for m in system.materials] == ['air', 'sk16', 'air', 'f4', 'air', 'sk16']     # (film-side air first; the world side wraps around to it)
+
+
+def test_tracer_check_on_the_cooke_triplet_at_the_notebooks_mesh_level(mi, orc):
+    """The same notebook's cell 9 prints what the reference's tracer check measured on the six subdivision-7 surfaces:
+        [0.0016724765300750732]   y is close:  False          [3.399315755814314e-05]   u is close:  False
+    (ConstrainedEFLProblem(num_sources=5, max_field_angle=7.5, init_camera_z=0.001); both ABOVE its atol 2e-5 on this lens.)  The oracle
+    twin of prb_basic.trace on this build's meshes gives the same verdict and the same magnitudes (see the comment at the assertions)."""
+    ld = mi.lens_design
+    system = _cooke_triplet(ld, 7)
+    problem = ld.DesignProblem(system, resolution=(16, 16), spp=4, learning_rate=1e-4, iters=1, num_sources=5, max_field_angle=7.5, init_camera_z=0.001)
+    geo = mi.load_dict(problem._build_preliminary_scene("prb_basic"))
+    o = orc.OracleScene(geo, mi.abi)
+
+    def tracer(ray):
+        rays = np.zeros((ray.o.shape[0], 8), dtype=np.float32); rays[:, :3] = ray.o; rays[:, 3:6] = ray.d; rays[:, 6] = np.float32(3.4028234663852886e38)
+        out = o.trace(rays, system.size() + 1, geo.integrator().max_depth)
+        return out[:, 0:3], out[:, 3:6], out[:, 9] != 0, out[:, 6:9]
+    err_y, err_u = problem.test_geo_tracer(tracer)
+    ref_y, ref_u = 0.0016724765300750732, 3.399315755814314e-05
+    # On the doublet this build reproduces the reference's slope error to 0.2 % (test above); on the triplet it measures 6.0e-5 / 2.8e-3 against the
+    # notebook's 3.4e-5 / 1.7e-3, and here the error GROWS with the subdivision level (2.7e-5, 3.0e-5, 6.0e-5 at levels 5, 6, 7): at level 7
+    # it is float32 rounding of the 0.05 mm edges the vertex normals next to the pole are formed from (ulp(50) / 0.05 = 8e-5), a quantity that
+    # depends on the mesh's vertex order, not a smooth function of the design.  So: the same verdict as the notebook printed, and its magnitude.
+    assert 0.5 * ref_u < err_u < 2.5 * ref_u, (err_u, ref_u)
+    assert 0.5 * ref_y < err_y < 2.5 * ref_y, (err_y, ref_y)
+    assert err_u > 2e-5 and err_y > 2e-5                                      # "u is close: False", "y is close: False"
