@@ -1235,14 +1235,17 @@ __global__ __launch_bounds__(256) void k_vertex_normals(const float *positions, 
 // Adjoint of the same computation as a per-vertex GATHER over the incident (face, corner) pairs, like the forward pass: the adjoints of the
 // (normalised) vertex normals of a face's corners go through the normalisation (stored lengths) and through face_normal_terms, and the vertex
 // keeps its own corner's share.  Every face is evaluated once per corner (3 x the arithmetic of a per-face scatter), but nothing is scattered:
-// the per-face version issued 9 memory-side float atomics per face and took 80 us per 166 k-face lens surface, 0.75 ms of a design iteration.
-// grad_pos is updated with plain loads and stores: no other kernel writes the mesh's slice while this one runs (same stream, after the sweep).
+// the per-face version issued 9 memory-side float atomics per face and took 80 us per 166 k-face lens surface.  EIGHT lanes share a vertex --
+// each takes every eighth incident face, the shares are summed with three shuffles -- because one thread per vertex left 1.3 waves per SIMD
+// to cover three dependent loads per face (62 us); grad_pos is updated with plain loads and stores: no other kernel writes the mesh's slice
+// while this one runs (same stream, after the sweep).
+#define MI_VNB_LANES 8u
 __global__ __launch_bounds__(256) void k_vertex_normals_bwd(const float *positions, const float *normals, const float *nrm_len, const uint32_t *faces, const uint32_t *adj_off,
                                                             const uint32_t *adj, uint32_t vtx_offset, uint32_t tri_offset, uint32_t n_vertices, const float *nrm_adj, float *grad_pos) {
-    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
-    if (v >= n_vertices) return;
-    gv3 acc = ga::mk<float>(0.f, 0.f, 0.f); bool touched = false;
-    for (uint32_t e = adj_off[vtx_offset + v]; e < adj_off[vtx_offset + v + 1u]; ++e) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, v = t / MI_VNB_LANES, sub = t % MI_VNB_LANES;
+    const bool valid = v < n_vertices;
+    gv3 acc = ga::mk<float>(0.f, 0.f, 0.f); int touched = 0;
+    if (valid) for (uint32_t e = adj_off[vtx_offset + v] + sub; e < adj_off[vtx_offset + v + 1u]; e += MI_VNB_LANES) {
         const uint32_t f = adj[e] >> 2, corner = adj[e] & 3u;
         const uint32_t *fi = faces + 3 * (size_t) (tri_offset + f);
         gv3 p[3], aN[3]; bool any = false;
@@ -1257,9 +1260,14 @@ __global__ __launch_bounds__(256) void k_vertex_normals_bwd(const float *positio
         gv3 av[3]; ga::face_normal_terms_adj(p[0], p[1], p[2], aN, av);
         const gv3 mine = corner == 0u ? av[0] : (corner == 1u ? av[1] : av[2]);
         if (!(mine.x == mine.x && mine.y == mine.y && mine.z == mine.z)) continue;       // degenerate face
-        acc = acc + mine; touched = true;
+        acc = acc + mine; touched = 1;
     }
-    if (!touched) return;
+#pragma unroll
+    for (int off = (int) MI_VNB_LANES / 2; off > 0; off >>= 1) {            // (all 256 threads take part: the groups are aligned runs of 8 lanes of a wave)
+        acc.x += __shfl_down(acc.x, off, (int) MI_VNB_LANES); acc.y += __shfl_down(acc.y, off, (int) MI_VNB_LANES); acc.z += __shfl_down(acc.z, off, (int) MI_VNB_LANES);
+        touched |= __shfl_down(touched, off, (int) MI_VNB_LANES);
+    }
+    if (!valid || sub != 0u || !touched) return;
     float *g = grad_pos + 3 * (size_t) v;
     g[0] += acc.x; g[1] += acc.y; g[2] += acc.z;
 }
@@ -2937,7 +2945,7 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
                 for (uint32_t i = 0; i < s->shapes.size(); ++i) {           // vertex-normal adjoints -> positions, for normals that follow the positions
                     const DShape &sh = s->shapes[i];
                     if (sh.type != MI355_SHAPE_MESH || !(sh.flags & DSHAPE_NRM_DEP) || sh.grad_offset == 0xffffffffu) continue;
-                    hipLaunchKernelGGL(k_vertex_normals_bwd, dim3((s->vcount[i] + 255u) / 256u), dim3(256), 0, st, (const float *) s->d_positions, (const float *) s->d_normals, (const float *) s->d_nrm_len,
+                    hipLaunchKernelGGL(k_vertex_normals_bwd, dim3((uint32_t) (((uint64_t) s->vcount[i] * MI_VNB_LANES + 255u) / 256u)), dim3(256), 0, st, (const float *) s->d_positions, (const float *) s->d_normals, (const float *) s->d_nrm_len,
                                        (const uint32_t *) s->d_faces, (const uint32_t *) s->d_vadj_off, (const uint32_t *) s->d_vadj, sh.vtx_offset, sh.tri_offset, s->vcount[i],
                                        (const float *) s->d_nrm_adj, d_grad_params + sh.grad_offset);
                 }
