@@ -873,6 +873,24 @@ def test_particle_tracer_deferred_splat(mi, orc, torch_cuda, rfilter):
     assert np.allclose(acc.cpu().numpy(), direct, rtol=1e-4, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("res", [832, 1024, 1408])
+def test_particle_tracer_deferred_splat_on_large_films(mi, torch_cuda, res):
+    """The scatter pass of the deferred splat keeps three words per film tile plus a 32 KB permutation in dynamic LDS: 2704 tiles (832^2) fit the
+    64 KB a launch gets by default, 4096 (1024^2) and 7744 (1408^2, the largest below SPLAT_MAX_TILES) need the raised limit
+    (hipFuncSetAttribute in splat_queue_flush).  Same film as the direct atomics on all three."""
+    torch = torch_cuda
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    scene = mi.load_dict(d)
+    integ = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5})
+    deferred = integ.render(scene, seed=2, spp=1, develop=False)
+    integ.direct_splat = True
+    direct = integ.render(scene, seed=2, spp=1, develop=False)
+    scale = float(direct[..., :3].max())
+    assert scale > 0 and torch.isfinite(deferred).all()
+    assert float((deferred - direct).abs().max()) < 1e-4 * scale
+    scene.release()
+
+
 def test_particle_tracer_gradient_reference_test06(mi, orc, torch_cuda, kats):
     """src/integrators/tests/test_ptracer.py:204-225 (test06_ptracer_gradients) as written there, against ITS hard-coded number:
     traverse -> keep the radiance -> set it to 1 -> render (seed 0) -> loss = mean(image) -> render_backward(seed 3, 64 spp in 4 passes)
