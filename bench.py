@@ -566,6 +566,10 @@ def main():
         b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
         rr_ms, rr_k = timed_l(lambda: il.render(scl, sensor=1, seed=0, spp=256, shard=lshard))          # same seed as the previous call: the sorted lane list is reused
         br_ms, br_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=1, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
+        # the three fields from ONE pass over the light paths (mi355_render_accumulate_sensors): what DesignProblem.step calls when unsharded
+        rm_ms = rm_k = None
+        if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):
+            rm_ms, rm_k = timed_l(lambda: il.render_sensors(scl, list(range(n_src)), seed=next(fresh), spp=256))
         ru_ms = ru_k = bu_ms = bu_k = None
         if not args.no_ab:
             il.no_lane_sort = True                      # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
@@ -588,6 +592,7 @@ def main():
             r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
         lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
                 "sensors": per_sensor, "roofline": lens_roof, "sensor_edit_us": round(edit_us, 2),
+                "render_all_sensors_one_pass_ms": rm_ms, "render_all_sensors_one_pass_kernels_ms": rm_k,
                 "lane_order_reused_sensor1": {"render_256spp_ms": rr_ms, "render_kernels_ms": rr_k, "render_backward_geometry_ms": br_ms, "render_backward_kernels_ms": br_k},
                 "unsorted_lanes_sensor0": {"render_256spp_ms": ru_ms, "render_kernels_ms": ru_k, "render_backward_geometry_ms": bu_ms, "render_backward_kernels_ms": bu_k}, "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
                 "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",

@@ -437,6 +437,19 @@ int mi355_lens_sag(const float *d_eval_xy, const float *d_base_positions, uint32
 int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_positions, uint32_t n, float radial_extent, const float *d_params,
                             const float *d_grad_positions, float *d_grad_params, void *stream);
 
+/* Several sensors, ONE light-traced pass (particle tracer, forward).  notebooks/scripts/lens_design/design_problem.py:525-537 renders every field of a
+   design iteration with the SAME seed (`mi.render(scene, params, seed=it, ..., sensor=sensor_idx)`), and AdjointIntegrator::render's light paths depend
+   on the seed and on the film SIZE only (integrator.cpp:575-600: one sampler stream per film pixel and sample): the fields' cameras therefore see the same
+   light paths, and only the sensor connection at every vertex (ptracer.cpp:232-236, perspective.cpp:282-340) is per camera.  This call traces the paths
+   once and connects every vertex to each of the `n_sensors` cameras: the same films as `n_sensors` calls of mi355_render_accumulate with that seed, up to
+   the order of the float additions.  Requirements (else MI355_ERR_UNSUPPORTED): perspective sensors, one film size without a crop window, one
+   reconstruction filter, one pass, the whole job on this GPU.
+     d_film   H x virt_w x 4 floats (RGBW), zeroed by the caller: sensor k's film occupies the columns [k * pitch + x0, k * pitch + x0 + W) of every row
+              (mi355_multi_film_layout: pitch = roundup(W, 16) + 32, x0 = 16, virt_w = n_sensors * pitch); the columns in between receive the filter
+              taps that leave a film and are to be ignored.  Develop a film by copying its columns out and calling mi355_film_develop on the copy. */
+int mi355_multi_film_layout(uint32_t film_w, uint32_t n_sensors, uint32_t *pitch, uint32_t *x0, uint32_t *virt_w);
+int mi355_render_accumulate_sensors(mi355_scene *scene, const mi355_render_params *params, uint32_t n_sensors, const uint32_t *sensors, float *d_film, void *stream);
+
 /* The rest of a design iteration that the reference runs as Dr.Jit kernels: the spot loss of one field (notebooks/scripts/lens_design/losses.py:31-41,
    rms_loss_and_center: squared RMS radius of the spot in pixels about its detached centroid, the image normalised by its detached mean) and the
    optimiser step (src/python/python/ad/optimizers.py:263-302, Adam.step without mask_updates) for all design scalars in one launch.

@@ -12,7 +12,7 @@ from . import _abi as abi
 from ._abi import Mi355Error
 from .transforms import Transform4f, ScalarTransform4f
 from .scene import (Scene, Shape, BSDF, Emitter, Texture, Sensor, Film, PluginError, load_dict, cornell_box, veach_mis_scene, parse_fov)
-from .integrators import (Integrator, PathIntegrator, PRBIntegrator, ParticleTracerIntegrator, make_integrator, SceneParameters, traverse, render,
+from .integrators import (Integrator, PathIntegrator, PRBIntegrator, ParticleTracerIntegrator, make_integrator, SceneParameters, traverse, render, render_fields,
                           sample_tea_32, shard_pixels, shard_tiles, shard_of, scene_param_layout)
 
 from .optimizers import Adam, SGD, Optimizer

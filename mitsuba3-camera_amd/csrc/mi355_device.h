@@ -189,6 +189,14 @@ struct DScene {
     uint32_t sample_exit_pupil; float film_diagonal; const float *pupil;   // exit-pupil bounds, 64 x (min.x, min.y, max.x, max.y)
 };
 
+// Several perspective sensors served by ONE light-traced pass (mi355_render_accumulate_sensors): the light paths of a launch depend on the
+// seed and on the film SIZE only, so the fields of a lens-design scene -- same seed, same film size, one camera each -- share them; only the
+// sensor connection at every vertex is made once per camera.  The films lie side by side in one virtual film (x_offset, DSensorSet::virt_w is
+// the kernel's crop_w), so the deferred splat sorts and accumulates all of them in one go.
+#define MI_MULTI_MAX 4
+struct DSensorView { float cam_to_world[12]; float camera_to_sample[16]; float image_rect[4]; float normalization, near_clip, far_clip, x_offset; };
+struct DSensorSet { uint32_t n; float film_w, film_h; uint32_t pad; DSensorView v[MI_MULTI_MAX]; };
+
 // Record tables in LDS (the north star's "BSDF params staged in LDS").  The BASIC kernel variants (FULL == 0: all-diffuse scenes of flat
 // primitives -- the headline configurations) stage the shape / bsdf / emitter / primitive-finish records once per workgroup (lt_fill,
 // 4.6 KB) and index them per lane with ds_read instead of per-lane global gathers: forward kernel 8.92 -> 8.71 ms on the Cornell box
@@ -2265,6 +2273,24 @@ MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, float sx_, float sy_
     weight = importance * inv_dist * inv_dist;
     return true;
 }
+// The perspective branch of sensor_sample_direction for one camera of a DSensorSet (uv in that camera's own film, before its x_offset)
+MI_DEV bool sensor_view_sample_direction(const DSensorView &sv, float film_w, float film_h, v3 p, v2 &uv, v3 &ds_p, float &weight) {
+    const float *tw = sv.cam_to_world;
+    v3 rel = p - V3(tw[3], tw[7], tw[11]);
+    v3 ref_p = V3(tw[0] * rel.x + tw[4] * rel.y + tw[8] * rel.z, tw[1] * rel.x + tw[5] * rel.y + tw[9] * rel.z, tw[2] * rel.x + tw[6] * rel.y + tw[10] * rel.z);
+    if (!(ref_p.z >= sv.near_clip && ref_p.z <= sv.far_clip)) return false;
+    v3 screen = xf_point_proj(sv.camera_to_sample, ref_p);
+    if (!(screen.x >= 0.f && screen.x <= 1.f && screen.y >= 0.f && screen.y <= 1.f)) return false;
+    uv.x = screen.x * film_w; uv.y = screen.y * film_h;
+    float dist = norm3(ref_p), inv_dist = 1.f / dist;
+    v3 local_d = ref_p * inv_dist;
+    ds_p = V3(tw[3], tw[7], tw[11]);
+    float ct = local_d.z, inv_ct = 1.f / ct, qx = local_d.x * inv_ct, qy = local_d.y * inv_ct;
+    bool valid = ct > 0.f && qx >= sv.image_rect[0] && qx <= sv.image_rect[2] && qy >= sv.image_rect[1] && qy <= sv.image_rect[3];
+    float importance = valid ? sv.normalization * inv_ct * inv_ct * inv_ct : 0.f;
+    weight = importance * inv_dist * inv_dist;
+    return true;
+}
 // Shape::sample_position: rectangle.cpp:166-180, sphere.cpp:210-229
 template <int FULL>
 MI_DEV void shape_sample_position(const DScene &sc, const DShape &sh, float sx, float sy, v3 &p, v3 &n, float &pdf) {
@@ -2470,10 +2496,11 @@ MI_DEV uint32_t ptracer_emission_cell(const DScene &sc, Pcg32 rng, int32_t max_d
     return (ei << (2u * bits)) | cell;
 }
 
-template <int FULL, bool GRAD = false>
+template <int FULL, bool GRAD = false, bool MULTI = false>
 MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
                            float sample_scale, float *film, uint32_t *stk, Counters3 &cnt, const PtGradSink *sink = nullptr, const SplatQueue *queue = nullptr,
-                           int walk = 1, v3 *S = nullptr) {
+                           int walk = 1, v3 *S = nullptr, const DSensorSet *set = nullptr) {
+    // MULTI (forward only): `set` lists the cameras; `sc` carries the virtual film they share (see DSensorSet)
     // GRAD, `all` mode: walk 1 adds every connection's <gather, splat> to *S (and does the radiance gradients); walk 2 starts from that
     // total, emits S / albedo at every diffuse vertex and subtracts the vertex's own connection afterwards.
     const bool timed = sc.shutter_open_time > 0.f;
@@ -2494,12 +2521,22 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         SI si = si_from_position(p, n, (int32_t) em.shape);
         float ssx = next_1d(rng), ssy = next_1d(rng);                       // sensor->sample_direction's 2D sample (front-element point of a lens)
         v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-        bool seen = lane_on && connect && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
         if (connect) (void) next_1d(rng);                                   // sample_wavelengths: the radiance itself in RGB mode
+        if (MULTI) {
+            for (uint32_t k = 0; k < set->n; ++k) {
+                const bool seen = lane_on && connect && sensor_view_sample_direction(set->v[k], set->film_w, set->film_h, si.p, uv, ds_p, sensor_weight);
+                uv.x += set->v[k].x_offset;
+                const bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight), sample_scale, film, stk,
+                                                             V3(0.f, 0.f, 0.f), ei, sink, queue, walk == 1);
+                cnt.shadow += wave_count(cast);
+            }
+        } else {
+        bool seen = lane_on && connect && sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
         v3 weight = ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight);
         const float wu = idx_weight * pos_weight * sensor_weight;
         bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, weight, sample_scale, film, stk, V3(wu, wu, wu), ei, sink, queue, walk == 1);
         cnt.shadow += wave_count(cast);
+        }
     }
     // ---- prepare_ray, ptracer.cpp:174-191 -> Scene::sample_emitter_ray (scene.cpp:262-297) -> AreaLight::sample_ray (area.cpp:92-115)
     if (timed) (void) next_1d(rng);
@@ -2527,7 +2564,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
     while (__any(active)) {
         MI_SCENE_RELOAD(scb); const DScene &sc = scb;                       // scene constants are re-fetched per bounce, not carried in spilled SGPRs
         cnt.shade += wave_count(active);
-        bool cast = false, next_active = false;
+        bool cast = false, next_active = false; uint32_t cast_mask = 0u;
         Ray next_ray = ray;
         if (active) {
             SI si = compute_si<FULL>(sc, ray, hit);
@@ -2535,11 +2572,21 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
             bool seen;
-            { MI_SCENE_RELOAD(sc1); seen = sensor_sample_direction<FULL>(sc1, si.p, ssx, ssy, uv, ds_p, sensor_weight); }   // (camera matrices: live here only)
             v3 dv = V3(0.f, 0.f, 0.f);
+            if (MULTI) {
+                for (uint32_t k = 0; k < set->n; ++k) {                     // one connection per camera; the two numbers drawn above are every camera's (a pinhole ignores them)
+                    seen = sensor_view_sample_direction(set->v[k], set->film_w, set->film_h, si.p, uv, ds_p, sensor_weight);
+                    uv.x += set->v[k].x_offset;
+                    MI_SCENE_RELOAD(sc2);
+                    const bool c = connect_sensor<FULL, GRAD>(sc2, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, V3(0.f, 0.f, 0.f), ei, sink, queue, walk == 1, nullptr);
+                    if (c) cast_mask |= 1u << k;
+                }
+            } else {
+            { MI_SCENE_RELOAD(sc1); seen = sensor_sample_direction<FULL>(sc1, si.p, ssx, ssy, uv, ds_p, sensor_weight); }   // (camera matrices: live here only)
             { MI_SCENE_RELOAD(sc2);
               cast = connect_sensor<FULL, GRAD>(sc2, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, tu * sensor_weight, ei, sink, queue,
                                                 walk == 1, (GRAD && S) ? &dv : nullptr); }
+            }
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
             TexTaps taps;
             MI_SCENE_RELOAD(sc3);
@@ -2574,7 +2621,8 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             next_active = next_active && (throughput.x != 0.f || throughput.y != 0.f || throughput.z != 0.f);
             next_ray = spawn_ray(si.p, si.n, wo_world);
         }
-        cnt.shadow += wave_count(cast);
+        if (MULTI) { for (uint32_t k = 0; k < set->n; ++k) cnt.shadow += wave_count(((cast_mask >> k) & 1u) != 0u); }
+        else cnt.shadow += wave_count(cast);
         active = next_active; ray = next_ray;
         // ptracer.cpp:264-269 intersects the sampled ray and only THEN masks the lane with `depth < max_depth`: after the last vertex a path may
         // shade, that intersection is computed and never read (it draws no random number either).  It is skipped here -- wave-uniform, `depth`

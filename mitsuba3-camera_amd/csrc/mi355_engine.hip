@@ -938,6 +938,27 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_FWD_WAVES) void k_ptracer_geo(DScene 
         ptracer_sample_geo<FULL>(sc, gt, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, gfilm, stk, &queue);
 }
 
+// Several cameras, one light-traced pass (mi355_render_accumulate_sensors; DSensorSet in mi355_device.h).  Forward only.
+template <int FULL>
+__global__ __launch_bounds__(BLOCK, FULL ? MI_PT_WAVES_FULL : MI_PT_WAVES_BASIC) void k_ptracer_multi(DScene sc, RenderArgs a, float sample_scale, float *film, unsigned long long *g_counters,
+                                                                                                     SplatQueue queue, const uint32_t *order, DSensorSet set) {
+    MI_LT_FILL(FULL, sc);
+    __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    uint32_t *stk = STK_PTR(smem, FULL, wave, lane_id);
+    const uint32_t i = (order ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * BLOCK + threadIdx.x;
+    const bool on = i < a.n_local;
+    const uint32_t ii = on ? (order ? order[i] : i) : 0u;
+    const uint32_t lane = shard_pixel(a, ii / a.s_count) * a.spp_total + a.s_begin + ii % a.s_count;
+    Pcg32 rng; sampler_seed(rng, a.seed, lane);
+    Counters3 cnt = {};
+    ptracer_sample<FULL, false, true>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, sample_scale, film, stk, cnt, nullptr, &queue, 1, nullptr, &set);
+    flush_counters(s_cnt, cnt, g_counters);
+}
+
 // ---- coherent lanes for the light tracer (pt_sort_lanes) ---------------------------------------------------------------------------
 // Light samples are independent streams, so the 64 lanes of a wave start 64 unrelated rays and walk 64 unrelated subtrees of the scene
 // BVH (lens doublet: 54 % of the VALU lanes busy, 10-19 GB fetched per launch, profiles/r02_pmc_lens_summary.txt).  The ASSIGNMENT of
@@ -3147,6 +3168,66 @@ extern "C" int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_ba
     if (!n) return MI355_OK;
     hipLaunchKernelGGL(k_lens_sag_bwd, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t) stream, d_eval_xy, d_base_positions, n, radial_extent, d_params, d_grad_positions, d_grad_params);
     HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+// Several perspective sensors of equal film size in ONE light-traced pass (see DSensorSet).  d_film: H x virt_w x 4 floats, sensor k's film in the
+// columns [k * pitch + MI_SPLAT_TILE, k * pitch + MI_SPLAT_TILE + W), pitch = roundup(W, 16) + 32, virt_w = n * pitch (mi355_multi_film_layout).
+extern "C" int mi355_multi_film_layout(uint32_t film_w, uint32_t n_sensors, uint32_t *pitch, uint32_t *x0, uint32_t *virt_w) {
+    if (!film_w || !n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    const uint32_t pt = (film_w + MI_SPLAT_TILE - 1u) / MI_SPLAT_TILE * MI_SPLAT_TILE + 2u * MI_SPLAT_TILE;
+    if (pitch) *pitch = pt; if (x0) *x0 = MI_SPLAT_TILE; if (virt_w) *virt_w = n_sensors * pt;
+    return MI355_OK;
+}
+extern "C" int mi355_render_accumulate_sensors(mi355_scene *s, const mi355_render_params *p, uint32_t n_sensors, const uint32_t *sensors, float *d_film, void *stream) {
+    Phase ph(PHASE_RENDER);
+    if (!s || !p || !sensors || !d_film) return fail(MI355_ERR_INVALID, "null argument");
+    if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer only");
+    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    if ((p->passes ? p->passes : 1u) != 1u || p->pixel_count || p->spp_count || p->pixel_tile) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: whole job, one pass");
+    for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
+    const DScene &f = s->sensors[sensors[0]].snap;
+    for (uint32_t k = 0; k < n_sensors; ++k) {                              // one lane layout, one film geometry, one filter: what the cameras must share
+        const DScene &g = s->sensors[sensors[k]].snap;
+        if (g.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: perspective sensors only");
+        if (g.film_w != f.film_w || g.film_h != f.film_h || g.crop_w != g.film_w || g.crop_h != g.film_h || g.crop_x || g.crop_y || g.rfilter != f.rfilter || g.filter_radius != f.filter_radius ||
+            memcmp(g.filter_coeff, f.filter_coeff, sizeof(f.filter_coeff)) || (g.shutter_open_time > 0.f) != (f.shutter_open_time > 0.f))
+            return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the films must have one size (no crop window), one reconstruction filter and one shutter setting");
+    }
+    mi355_render_params p0 = *p; p0.sensor = sensors[0];
+    RenderArgs a; int rc = make_args(s, &p0, &a); if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    if (a.n_local == 0) return MI355_OK;
+    hipStream_t st = (hipStream_t) stream; dim3 grid((a.n_local + BLOCK - 1) / BLOCK), block(BLOCK);
+    if ((rc = ensure_geometry(s, st))) return rc;
+    if (s->emitters.empty()) return MI355_OK;
+    uint32_t pitch, x0, virt_w; mi355_multi_film_layout(f.film_w, n_sensors, &pitch, &x0, &virt_w);
+    DSensorSet set; memset(&set, 0, sizeof(set)); set.n = n_sensors; set.film_w = (float) f.film_w; set.film_h = (float) f.film_h;
+    for (uint32_t k = 0; k < n_sensors; ++k) {
+        const DScene &g = s->sensors[sensors[k]].snap; DSensorView &v = set.v[k];
+        memcpy(v.cam_to_world, g.cam_to_world, sizeof(v.cam_to_world)); memcpy(v.camera_to_sample, g.camera_to_sample, sizeof(v.camera_to_sample)); memcpy(v.image_rect, g.image_rect, sizeof(v.image_rect));
+        v.normalization = g.normalization; v.near_clip = g.near_clip; v.far_clip = g.far_clip; v.x_offset = (float) (k * pitch + x0);
+    }
+    Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
+    if ((rc = tm.begin())) return rc;
+    const float sample_scale = (float) (f.crop_w * f.crop_h) / (float) ((uint64_t) p->spp * f.film_w * f.film_h);
+    const DScene real = s->ds;                                              // the kernels and the splat passes see the VIRTUAL film: every camera's columns side by side
+    s->ds.crop_w = virt_w;
+    SplatQueue q; const uint32_t *order = nullptr;
+    rc = splat_queue_setup(s, &p0, a, st, false, q);
+    if (!rc) rc = pt_sort_lanes(s, &p0, a, st, &order);
+    if (!rc) {
+        if (order) grid.x = xcd_grid(grid.x);
+        const bool full = s->ds.features != 0u, flat = full && s->ds.n_bvh_shapes == 0u;
+        if (flat) hipLaunchKernelGGL((k_ptracer_multi<2>), grid, block, 0, st, s->ds, a, sample_scale, d_film, s->d_counters, q, order, set);
+        else if (full) hipLaunchKernelGGL((k_ptracer_multi<true>), grid, block, 0, st, s->ds, a, sample_scale, d_film, s->d_counters, q, order, set);
+        else hipLaunchKernelGGL((k_ptracer_multi<false>), grid, block, 0, st, s->ds, a, sample_scale, d_film, s->d_counters, q, order, set);
+        if (hipGetLastError() != hipSuccess) rc = fail(MI355_ERR_DEVICE, "k_ptracer_multi launch failed");
+    }
+    if (!rc) rc = splat_queue_flush(s, q, st, false, d_film);
+    s->ds = real;
+    if (rc) return rc;
+    if ((rc = tm.end())) return rc;
+    s->n_gen += a.n_local;
     return MI355_OK;
 }
 extern "C" int mi355_spot_loss(const float *d_image, uint32_t height, uint32_t width, float *d_out, void *stream) {

@@ -85,6 +85,10 @@ class HipBackend:
     def accumulate(self, scene, p, film):
         abi.check(abi.lib().mi355_render_accumulate(scene.handle(), C.byref(p), C.c_void_p(film.data_ptr()), _stream_ptr(film.device)))
 
+    def accumulate_sensors(self, scene, p, sensors, film):
+        arr = (C.c_uint32 * len(sensors))(*[int(k) for k in sensors])
+        abi.check(abi.lib().mi355_render_accumulate_sensors(scene.handle(), C.byref(p), len(sensors), arr, C.c_void_p(film.data_ptr()), _stream_ptr(film.device)))
+
     def develop(self, scene, film, img, sensor=0):
         abi.check(abi.lib().mi355_film_develop(scene.handle(), int(sensor), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), _stream_ptr(film.device)))
 
@@ -353,6 +357,49 @@ class ParticleTracerIntegrator(Integrator):
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
         return super().render(scene, sensor, seed, spp, develop, evaluate, shard, group)
+
+    def sensors_share_light_paths(self, scene, sensors):
+        """True when mi355_render_accumulate_sensors can serve `sensors` with ONE light-traced pass: perspective cameras, one film size without a
+        crop window, one reconstruction filter (the light paths of AdjointIntegrator::render depend on the seed and the film size only)."""
+        if not hasattr(self.backend, "accumulate_sensors") or not (1 <= len(sensors) <= 4):
+            return False
+        ss = [scene.sensors()[scene.sensor_index(k)] for k in sensors]
+        f0 = ss[0].film
+        for se in ss:
+            f = se.film
+            if se.type != abi.SENSOR_PERSPECTIVE or (f.width, f.height) != (f0.width, f0.height) or (f.crop_width, f.crop_height, f.crop_offset_x, f.crop_offset_y) != (f.width, f.height, 0, 0):
+                return False
+            if (f.rfilter, f.rfilter_param) != (f0.rfilter, f0.rfilter_param) or (se.shutter_open_time > 0) != (ss[0].shutter_open_time > 0):
+                return False
+        return True
+
+    def render_sensors(self, scene, sensors, seed=0, spp=0, develop=True, evaluate=True):
+        """Integrator.render(scene, sensor=k, seed, spp) for every k of `sensors` from ONE pass over the light paths (mi355_render_accumulate_sensors):
+        design_problem.py:525-537 renders each field with the same seed, so the fields share their light paths and differ in the sensor connection
+        only.  Returns the list of images (or of RGBW accumulators), equal to the separate renders up to the order of the float additions."""
+        torch = _torch()
+        be = self.backend
+        dev = be.device(scene)
+        sensors = [scene.sensor_index(k) for k in sensors]
+        if not self.sensors_share_light_paths(scene, sensors):
+            return [self.render(scene, k, seed, spp, develop, evaluate) for k in sensors]
+        f = scene.sensors()[sensors[0]].film
+        spp = self._resolve_spp(scene, spp, sensors[0])
+        pitch, x0, virt_w = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        abi.check(abi.lib().mi355_multi_film_layout(f.width, len(sensors), C.byref(pitch), C.byref(x0), C.byref(virt_w)))
+        stack = torch.zeros((f.height, virt_w.value, 4), dtype=torch.float32, device=dev)
+        be.accumulate_sensors(scene, self._params(scene, seed, spp, sensor=sensors[0]), sensors, stack)
+        out = []
+        for k, sensor in enumerate(sensors):
+            film = stack[:, k * pitch.value + x0.value: k * pitch.value + x0.value + f.width, :].contiguous()
+            if not develop:
+                out.append(film); continue
+            img = torch.empty((f.height, f.width, 3), dtype=torch.float32, device=dev)
+            be.develop(scene, film, img, sensor)
+            out.append(img)
+        if evaluate:
+            be.synchronize(dev)
+        return out
 
     def render_forward(self, *a, **k):
         raise PluginError("ptracer: render_forward over the colour parameters is not built (render_backward is; for mesh vertices see render_forward_geometry)")
@@ -814,3 +861,44 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             return tuple(params.grad(k).clone() for k in diff_keys)
 
     return _RenderOp.apply(*[params[k] for k in diff_keys])
+
+
+def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0):
+    """mi.render(scene, params, sensor=k, seed=seed, ...) for every k of `sensors`, as ONE differentiable operation: the primal images come from
+    one pass over the light paths when the sensors allow it (ParticleTracerIntegrator.render_sensors), the adjoint is the sum of the sensors'
+    render_backward calls.  Returns the tuple of images.  (design_problem.py:525-537 renders the fields of an iteration one after the other with
+    one seed; the results are those of that loop.)"""
+    torch = _torch()
+    if integrator is None:
+        integrator = scene.integrator()
+    sensors = [scene.sensor_index(k) for k in sensors]
+    if not hasattr(integrator, "render_sensors") or not integrator.sensors_share_light_paths(scene, sensors):
+        return tuple(render(scene, params, sensor=k, integrator=integrator, seed=seed, seed_grad=seed_grad, spp=spp, spp_grad=spp_grad) for k in sensors)
+    if spp_grad == 0:
+        spp_grad = spp
+    if seed_grad == 0:
+        seed_grad = sample_tea_32(seed, 1)[0]          # util.py:517
+    elif seed_grad == seed:
+        raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
+    diff_keys = [k for k in (params.keys() if params is not None else []) if getattr(params[k], "requires_grad", False)]
+    if params is not None:
+        params.update(skip=diff_keys)
+    if not diff_keys:
+        return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False))
+
+    class _FieldsOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *tensors):
+            for k, t in zip(diff_keys, tensors):
+                params._push(k, t); params._dirty.discard(k)
+            return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False))
+
+        @staticmethod
+        def backward(ctx, *grad_outs):
+            params.zero_grad()
+            for sensor, g in zip(sensors, grad_outs):                  # render_backward ACCUMULATES into the gradient buffer: the sum over the fields
+                if g is not None:
+                    integrator.render_backward(scene, params, g.contiguous(), sensor, seed=seed_grad, spp=spp_grad)
+            return tuple(params.grad(k).clone() for k in diff_keys)
+
+    return _FieldsOp.apply(*[params[k] for k in diff_keys])

@@ -991,8 +991,17 @@ class DesignProblem:
         loss = None; pending = []
         # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
         # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
+        # The fields of an iteration are rendered with ONE seed (:525-537), so their cameras see the same light paths: unsharded, the primal images
+        # come from one pass over those paths (integrators.render_fields; up to four cameras per pass); the adjoint stays one pass per field.
+        shard = getattr(self, "shard", None); images = {}
+        if shard is None and getattr(self, "share_light_paths", True):
+            from .integrators import render_fields
+            for first in range(0, self.num_sources, 4):
+                group_ids = list(range(first, min(first + 4, self.num_sources)))
+                for k, im in zip(group_ids, render_fields(self.scene, self.params, group_ids, seed=it, spp=2 * self.spp, spp_grad=self.spp)):
+                    images[k] = im
         for sensor_idx in range(self.num_sources):
-            image = render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, sensor=sensor_idx, shard=getattr(self, "shard", None), group=getattr(self, "group", None))
+            image = images[sensor_idx] if sensor_idx in images else render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, sensor=sensor_idx, shard=shard, group=getattr(self, "group", None))
             sensor_loss, stats = self.field_sources[sensor_idx].spot_loss(image)
             pending.append(stats)
             loss = 10000.0 * sensor_loss if loss is None else loss + 10000.0 * sensor_loss

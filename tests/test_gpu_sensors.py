@@ -280,6 +280,67 @@ def test_constrained_focal_length_problem(mi, torch_cuda):
     problem.scene.release()
 
 
+def test_fields_share_one_pass_over_the_light_paths(mi, orc, torch_cuda):
+    """mi355_render_accumulate_sensors / integrators.render_fields: the fields of a design iteration are rendered with one seed
+    (design_problem.py:525-537), so their cameras see the same light paths and ONE traced pass serves them all.  On the three-field doublet:
+    every camera's image equals its own mi.render (and so the oracle's: test_three_field_design_problem) to float-atomic order; the
+    gradients that flow back through the shared operation equal the sum of the three separate operations'; on the Cornell box (BASIC
+    kernels, Gaussian filter, a visible emitter) two cameras likewise; sensors that cannot share a pass fall back to one pass each."""
+    torch = torch_cuda
+    render_fields = mi.render_fields
+    problem = _problem(mi, constrained=False).prepare()
+    scene, params, system = problem.scene, problem.params, problem.lens_system
+    system.update(params, problem.optimizer)
+    integ = scene.integrator()
+    assert integ.sensors_share_light_paths(scene, [0, 1, 2])
+    together = integ.render_sensors(scene, [0, 1, 2], seed=4, spp=32)
+    for k in range(3):
+        alone = integ.render(scene, sensor=k, seed=4, spp=32)
+        assert float(alone.max()) > 0 and float((together[k] - alone).abs().max()) < 1e-5 * float(alone.max()), k
+    acc = integ.render_sensors(scene, [2, 0], seed=4, spp=32, develop=False)          # any subset, any order; the raw accumulators
+    assert acc[0].shape == (32, 32, 4) and float((acc[0] - integ.render(scene, sensor=2, seed=4, spp=32, develop=False)).abs().max()) < 1e-5 * float(acc[0].max())
+    # the differentiable operation: same images, same gradients as three mi.render calls
+    def grads(shared):
+        for v in problem.optimizer.variables.values():
+            v.grad = None
+        system.update(params, problem.optimizer)
+        if shared:
+            images = render_fields(scene, params, [0, 1, 2], seed=9, spp=32, spp_grad=16)
+        else:
+            images = [mi.render(scene, params, sensor=k, seed=9, spp=32, spp_grad=16) for k in range(3)]
+        yy, xx = torch.meshgrid(torch.arange(32.0, device="cuda"), torch.arange(32.0, device="cuda"), indexing="ij")
+        loss = sum((im.sum(dim=2) * ((xx - 15.5 - k) ** 2 + (yy - 15.5) ** 2)).sum() for k, im in enumerate(images))
+        loss.backward()
+        return [im.detach() for im in images], {k: v.grad.clone() for k, v in problem.optimizer.variables.items() if v.grad is not None}
+    im_a, g_a = grads(True); im_b, g_b = grads(False)
+    for a, b in zip(im_a, im_b):
+        assert float((a - b).abs().max()) < 1e-5 * float(b.max())
+    assert set(g_a) == set(g_b) and len(g_a) == 30
+    for k in g_a:
+        assert float((g_a[k] - g_b[k]).abs().max()) <= 2e-4 * max(float(g_b[k].abs().max()), 1e-12) + 1e-9, (k, g_a[k], g_b[k])
+    handle = scene._handle
+    losses = [problem.step(it)[0] for it in range(3)]                                 # DesignProblem.step goes through it
+    assert np.isfinite(losses).all() and scene._handle is handle
+    scene.release()
+    # BASIC kernels, Gaussian filter, an emitter the cameras see directly
+    both = small_cbox(mi, 16); both["second"] = _second_sensor(mi, film={'type': 'hdrfilm', 'width': 16, 'height': 16, 'rfilter': {'type': 'gaussian'}, 'pixel_format': 'rgb'})
+    cb = mi.load_dict(both)
+    pt = mi.ParticleTracerIntegrator({"max_depth": 4, "rr_depth": 5})
+    if pt.sensors_share_light_paths(cb, [0, 1]):
+        two = pt.render_sensors(cb, [0, 1], seed=3, spp=64)
+        for k in range(2):
+            one = pt.render(cb, sensor=k, seed=3, spp=64)
+            assert float(one.max()) > 0 and float((two[k] - one).abs().max()) < 1e-5 * float(one.max()), k
+    other = small_cbox(mi, 16); other["second"] = _second_sensor(mi)                  # 24 x 12 film, tent filter: cannot share a pass with the 16 x 16 Gaussian one
+    cb2 = mi.load_dict(other)
+    assert not pt.sensors_share_light_paths(cb2, [0, 1])
+    sep = pt.render_sensors(cb2, [0, 1], seed=3, spp=16)
+    assert sep[0].shape == (16, 16, 3) and sep[1].shape == (12, 24, 3)
+    p = pt._params(cb2, 3, 16); arr = (C.c_uint32 * 2)(0, 1); film = torch.zeros((16, 200, 4), device="cuda")
+    assert mi.abi.lib().mi355_render_accumulate_sensors(cb2.handle(), C.byref(p), 2, arr, C.c_void_p(film.data_ptr()), None) == mi.abi.ERR_UNSUPPORTED
+    cb.release(); cb2.release()
+
+
 def test_geometry_gradients_refuse_an_emitter_mesh(mi, torch_cuda):
     """The geometry adjoint treats emitters as static (the sampled emitter position / direction carries no derivative), so a gradient slot on
     a mesh that carries an area emitter would silently miss the term Dr.Jit's AD includes: MI355_ERR_UNSUPPORTED, as the forward design
