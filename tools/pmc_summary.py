@@ -21,8 +21,9 @@ def main(d, out):
         for i, r in enumerate(csv.DictReader(open(stats[0]))):
             if i < 6:
                 lines.append("%-60s calls=%s avg_ms=%.4f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    meta = {}
+    agg = {}
+    by_grid = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
+    meta = {}; metas = {}
     out_json = {"source": os.path.basename(os.path.normpath(d)), "csrc_sha256": csrc_sha256(), "kernels": {}}
     if stats:
         for r in csv.DictReader(open(stats[0])):
@@ -32,8 +33,13 @@ def main(d, out):
             k = r["Kernel_Name"].split("(")[0][-40:]
             if not ("k_render" in k or "k_prb" in k or "k_splat" in k or "k_ptracer" in k or "k_pt_" in k):
                 continue
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
+            by_grid[k][int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            metas[(k, int(r["Grid_Size"]))] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    # A kernel is launched with several grid sizes (the lens leg renders at 256 spp and, inside an update, at 1 spp): the counters of the LARGEST
+    # launches are the ones bench.py scales by lanes -- averaging over all of them mixed a 16 384-thread launch into a 4 194 304-thread one.
+    for k, grids in by_grid.items():
+        g = max(grids)
+        agg[k] = grids[g]; meta[k] = metas[(k, g)]
     for k, c in agg.items():
         m = {n: sum(v) / len(v) for n, v in c.items()}
         lines.append("")
