@@ -570,6 +570,9 @@ def main():
         rm_ms = rm_k = None
         if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):
             rm_ms, rm_k = timed_l(lambda: il.render_sensors(scl, list(range(n_src)), seed=next(fresh), spp=256))
+        bm_ms = bm_k = None
+        if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):       # ... and their geometry adjoints from one walk and one sweep (mi355_render_backward_sensors)
+            bm_ms, bm_k = timed_l(lambda: (pl.zero_grad(), il.render_backward_sensors(scl, pl, [gin_l] * n_src, list(range(n_src)), seed=next(fresh), spp=128)))
         ru_ms = ru_k = bu_ms = bu_k = None
         if not args.no_ab:
             il.no_lane_sort = True                      # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
@@ -593,6 +596,7 @@ def main():
         lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
                 "sensors": per_sensor, "roofline": lens_roof, "sensor_edit_us": round(edit_us, 2),
                 "render_all_sensors_one_pass_ms": rm_ms, "render_all_sensors_one_pass_kernels_ms": rm_k,
+                "render_backward_all_sensors_one_pass_ms": bm_ms, "render_backward_all_sensors_one_pass_kernels_ms": bm_k,
                 "lane_order_reused_sensor1": {"render_256spp_ms": rr_ms, "render_kernels_ms": rr_k, "render_backward_geometry_ms": br_ms, "render_backward_kernels_ms": br_k},
                 "unsorted_lanes_sensor0": {"render_256spp_ms": ru_ms, "render_kernels_ms": ru_k, "render_backward_geometry_ms": bu_ms, "render_backward_kernels_ms": bu_k}, "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
                 "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",

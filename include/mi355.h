@@ -449,6 +449,13 @@ int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_position
               taps that leave a film and are to be ignored.  Develop a film by copying its columns out and calling mi355_film_develop on the copy. */
 int mi355_multi_film_layout(uint32_t film_w, uint32_t n_sensors, uint32_t *pitch, uint32_t *x0, uint32_t *virt_w);
 int mi355_render_accumulate_sensors(mi355_scene *scene, const mi355_render_params *params, uint32_t n_sensors, const uint32_t *sensors, float *d_film, void *stream);
+/* ... and its adjoint with respect to mesh vertex positions and IORs (mi355_render_backward with MI355_FLAG_GEOMETRY_GRADS | MI355_FLAG_SKIP_COLOUR_GRADS,
+   which `params->flags` must carry): util.py:517 derives ONE differential seed from the primal seed, so the fields of an iteration differentiate over the
+   same light paths too -- one forward walk onto the path tape, one backward sweep in which a vertex gathers the image adjoint of every camera it connected
+   to; the sum of `n_sensors` calls of mi355_render_backward, up to the order of the float additions.  d_grad_in: HOST array of `n_sensors` device pointers,
+   H x W x 3 each, or NULL for a sensor whose image carries no adjoint.  d_grad_params is accumulated into, as by mi355_render_backward. */
+int mi355_render_backward_sensors(mi355_scene *scene, const mi355_render_params *params, uint32_t n_sensors, const uint32_t *sensors, const float *const *d_grad_in,
+                                  float *d_grad_params, void *stream);
 
 /* The rest of a design iteration that the reference runs as Dr.Jit kernels: the spot loss of one field (notebooks/scripts/lens_design/losses.py:31-41,
    rms_loss_and_center: squared RMS radius of the spot in pixels about its detached centroid, the image normalised by its detached mean) and the

@@ -123,6 +123,7 @@ SYMBOLS = [
     ("mi355_lens_sag_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355_multi_film_layout", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("mi355_render_accumulate_sensors", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    ("mi355_render_backward_sensors", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     ("mi355_spot_loss", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_spot_loss_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mi355_adam_step", C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_void_p]),

@@ -1241,9 +1241,10 @@ __global__ __launch_bounds__(256) void k_splat_tiles(DScene sc, SplatQueue q, co
 #ifndef MI_GEO_BWD_WAVES
 #define MI_GEO_BWD_WAVES 3                 // 168 VGPRs + 116 B of scratch at 3 waves beat 219 unspilled at 2 (lens doublet 9.15 -> 7.96 ms)
 #endif
-template <int FULL>
+template <int FULL, bool MULTI = false>
 __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DScene sc, RenderArgs a, float sample_scale, const float *grad_rgb, float *d_grad, float *d_nrm_adj,
-                                                               GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds, const uint32_t *order) {
+                                                               GeoTape tape, uint32_t lane_first, uint32_t n_chunk, uint32_t n_ior_lds, const uint32_t *order,
+                                                               DSensorSet set, GeoGradSet gset) {      // (set, gset: read when MULTI -- several cameras, one pass)
     MI_LT_FILL(FULL, sc);                                                  // BASIC variants: record tables staged in LDS
     __shared__ __attribute__((aligned(16))) float smem[STACK_FLOATS(FULL)];
     extern __shared__ float s_ior_dyn[];
@@ -1264,18 +1265,18 @@ __global__ __launch_bounds__(BLOCK, MI_GEO_BWD_WAVES) void k_ptracer_geo_bwd(DSc
     const uint32_t slot = min(t, tape.stride - 1u);
     for (uint32_t pass = 0; pass < a.passes; ++pass) {
         uint32_t n_sweep;
-        const uint32_t nv = ptracer_geo_walk<FULL>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, stk, tape, slot, n_sweep);
+        const uint32_t nv = ptracer_geo_walk<FULL, MULTI>(sc, rng, (int32_t) a.max_depth, (int32_t) a.rr_depth, (a.flags & MI355_FLAG_HIDE_EMITTERS) != 0, on, stk, tape, slot, n_sweep, &set);
 #ifndef MI_GEO_NO_SWEEP
         if (FULL == 1) {
             // (the barrier that separates the walk's traversal stacks from the table also tells whether ANY path of the workgroup has something to
             //  sweep: sorted by emitter, whole workgroups carry the light of a field source this sensor does not see)
             if (__syncthreads_or(n_sweep != 0u)) {
                 vertex_adj_clear(sink.tab); __syncthreads();
-                ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, n_sweep, sink);
+                ptracer_geo_sweep<FULL, MULTI>(sc, sample_scale, tape, slot, nv, n_sweep, sink, &set, &gset);
                 __syncthreads(); vertex_adj_flush(sink);
             }
             __syncthreads();
-        } else ptracer_geo_sweep<FULL>(sc, sample_scale, tape, slot, nv, n_sweep, sink);
+        } else ptracer_geo_sweep<FULL, MULTI>(sc, sample_scale, tape, slot, nv, n_sweep, sink, &set, &gset);
 #endif
     }
     __syncthreads();
@@ -2944,14 +2945,45 @@ extern "C" int mi355_ptracer_forward_design(mi355_scene *s, const mi355_render_p
     HIP_TRY(hipGetLastError());
     return splat_queue_flush(s, q, st, true, d_film_rgbw);
 }
-static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream);
+struct MultiAdjoint { DSensorSet set; GeoGradSet grads; };                  // mi355_render_backward_sensors: several cameras, one walk and one sweep
+static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream, const MultiAdjoint *multi = nullptr);
 extern "C" int mi355_render_backward(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight,
                                      float *d_grad_params, void *stream) {
     Phase ph(PHASE_RENDER_BACKWARD);
     int rc = render_backward_impl(s, p, d_grad_in, d_weight, d_grad_params, stream); if (rc) return rc;
     return reduce_hook(s, d_grad_params, s->grad_total, stream);             // the gradient of the whole job, on every rank
 }
-static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream) {
+// The adjoint of mi355_render_accumulate_sensors' films with respect to vertex positions and IORs: the cameras of `sensors` differentiate with one
+// seed, hence over the same light paths -- ONE forward walk onto the tape, ONE backward sweep in which every vertex gathers the image adjoint of
+// each camera that it connected to.  d_grad_in[k]: H x W x 3 for sensor k, or NULL (that image carries no adjoint).
+extern "C" int mi355_render_backward_sensors(mi355_scene *s, const mi355_render_params *p, uint32_t n_sensors, const uint32_t *sensors, const float *const *d_grad_in,
+                                             float *d_grad_params, void *stream) {
+    Phase ph(PHASE_RENDER_BACKWARD);
+    if (!s || !p || !sensors || !d_grad_in || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
+    if (p->integrator != MI355_INTEGRATOR_PTRACER || !(p->flags & MI355_FLAG_GEOMETRY_GRADS) || !(p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))
+        return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer's geometry / IOR adjoint only (MI355_FLAG_GEOMETRY_GRADS | MI355_FLAG_SKIP_COLOUR_GRADS)");
+    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    if ((p->passes ? p->passes : 1u) != 1u || p->pixel_count || p->spp_count || p->pixel_tile) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: whole job, one pass");
+    for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
+    const DScene &f = s->sensors[sensors[0]].snap;
+    MultiAdjoint m; memset(&m, 0, sizeof(m)); m.set.n = n_sensors; m.set.film_w = (float) f.film_w; m.set.film_h = (float) f.film_h;
+    const float *first_grad = nullptr;
+    for (uint32_t k = 0; k < n_sensors; ++k) {
+        const DScene &g = s->sensors[sensors[k]].snap; DSensorView &v = m.set.v[k];
+        if (g.sensor_type != MI355_SENSOR_PERSPECTIVE) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: perspective sensors only");
+        if (g.film_w != f.film_w || g.film_h != f.film_h || g.crop_w != g.film_w || g.crop_h != g.film_h || g.crop_x || g.crop_y || g.rfilter != f.rfilter || g.filter_radius != f.filter_radius ||
+            memcmp(g.filter_coeff, f.filter_coeff, sizeof(f.filter_coeff)) || (g.shutter_open_time > 0.f) != (f.shutter_open_time > 0.f))
+            return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the films must have one size (no crop window), one reconstruction filter and one shutter setting");
+        memcpy(v.cam_to_world, g.cam_to_world, sizeof(v.cam_to_world)); memcpy(v.camera_to_sample, g.camera_to_sample, sizeof(v.camera_to_sample)); memcpy(v.image_rect, g.image_rect, sizeof(v.image_rect));
+        v.normalization = g.normalization; v.near_clip = g.near_clip; v.far_clip = g.far_clip; v.x_offset = 0.f;
+        m.grads.g[k] = d_grad_in[k]; if (d_grad_in[k] && !first_grad) first_grad = d_grad_in[k];
+    }
+    if (!first_grad) return MI355_OK;                                       // no image carries an adjoint: the gradient is zero
+    mi355_render_params p0 = *p; p0.sensor = sensors[0];
+    int rc = render_backward_impl(s, &p0, first_grad, nullptr, d_grad_params, stream, &m); if (rc) return rc;
+    return reduce_hook(s, d_grad_params, s->grad_total, stream);
+}
+static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, const float *d_grad_in, const float *d_weight, float *d_grad_params, void *stream, const MultiAdjoint *multi) {
     RenderArgs a; int rc = make_args(s, p, &a); if (rc) return rc;
     const bool pt = p->integrator == MI355_INTEGRATOR_PTRACER;
     if (!d_grad_in || (!d_weight && !pt) || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
@@ -3004,8 +3036,14 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
                 //  9.15 ms on the lens doublet: fused, a workgroup reads its tape rows back while they are still in L2)
                 for (uint32_t first = 0; first < a.n_local; first += chunk) {
                     const uint32_t n = std::min<uint32_t>(chunk, a.n_local - first); const dim3 g(order ? xcd_grid((n + BLOCK - 1) / BLOCK) : (n + BLOCK - 1) / BLOCK);
-                    if (s->ds.features != 0u) hipLaunchKernelGGL(k_ptracer_geo_bwd<true>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
-                    else hipLaunchKernelGGL(k_ptracer_geo_bwd<false>, g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order);
+                    if (multi) {
+                        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer_geo_bwd<true, true>), g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order, multi->set, multi->grads);
+                        else hipLaunchKernelGGL((k_ptracer_geo_bwd<false, true>), g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order, multi->set, multi->grads);
+                    } else {
+                        DSensorSet no_set; GeoGradSet no_grads; memset(&no_set, 0, sizeof(no_set)); memset(&no_grads, 0, sizeof(no_grads));
+                        if (s->ds.features != 0u) hipLaunchKernelGGL((k_ptracer_geo_bwd<true, false>), g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order, no_set, no_grads);
+                        else hipLaunchKernelGGL((k_ptracer_geo_bwd<false, false>), g, pblock, n_ior * sizeof(float), st, s->ds, a, sample_scale, d_grad_in, d_grad_params, s->d_nrm_adj, tape, first, n, n_ior, order, no_set, no_grads);
+                    }
                 }
                 HIP_TRY(hipGetLastError());
                 for (uint32_t i = 0; i < s->shapes.size(); ++i) {           // vertex-normal adjoints -> positions, for normals that follow the positions

@@ -25,6 +25,9 @@
 #define MI_TF_LOBE_MASK 3u
 #define MI_TF_CONN 4u
 #define MI_TF_CONT 8u
+#define MI_TF_CONN_K(k) ((k) == 0u ? MI_TF_CONN : (8u << (k)))   // several cameras (DSensorSet): camera k's connection bit (16, 32, 64 for k = 1, 2, 3)
+#define MI_TF_CONN_ANY (MI_TF_CONN | 16u | 32u | 64u)
+#define MI_TF_SHIFT 8
 
 struct GeoTape { float *base; uint32_t stride; };      // stride = lanes of the launch; field f of vertex k of lane i at base[(k * FIELDS + f) * stride + i]
 struct GeoBwdSink {
@@ -34,6 +37,8 @@ struct GeoBwdSink {
     float *s_ior;                // LDS: 2 floats per bsdf (adjoint of int_ior, ext_ior), or nullptr -> global atomics
     uint32_t *tab;               // LDS: the workgroup's vertex-adjoint table (vertex_adj_add), or nullptr -> global atomics
 };
+struct GeoGradSet { const float *g[MI_MULTI_MAX]; };   // several cameras in one pass: dLoss / d image of each (nullptr: that camera's image carries no adjoint)
+
 
 // ---- vertex adjoints, summed per workgroup before they leave the CU ----------------------------------------------------------------
 // Every mesh-vertex hit scatters 18 floats (position and normal adjoints of the triangle's three corners).  As device-scope float atomics
@@ -150,14 +155,14 @@ MI_DEV void tape_store(const GeoTape &tp, uint32_t lane, uint32_t k, const Ray &
     b[0] = ray.o.x; b[s] = ray.o.y; b[2 * s] = ray.o.z; b[3 * s] = ray.d.x; b[4 * s] = ray.d.y; b[5 * s] = ray.d.z;
     b[6 * s] = T.x; b[7 * s] = T.y; b[8 * s] = T.z; b[9 * s] = hit.t; b[10 * s] = hit.u; b[11 * s] = hit.v;
     b[12 * s] = W.x; b[13 * s] = W.y; b[14 * s] = W.z; b[15 * s] = rr;
-    b[16 * s] = __uint_as_float(hit.prim); b[17 * s] = __uint_as_float((hit.shape << 4) | flags);
+    b[16 * s] = __uint_as_float(hit.prim); b[17 * s] = __uint_as_float((hit.shape << MI_TF_SHIFT) | flags);
 }
 
 // One light sample, forward walk: mirrors ptracer_sample call for call and writes one tape record per vertex.  Returns the number of
 // vertices on the tape.
-template <int FULL>
+template <int FULL, bool MULTI = false>
 MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth, int32_t rr_depth, bool hide_emitters, bool lane_on,
-                                 uint32_t *stk, const GeoTape &tp, uint32_t lane, uint32_t &n_sweep) {
+                                 uint32_t *stk, const GeoTape &tp, uint32_t lane, uint32_t &n_sweep, const DSensorSet *set = nullptr) {
     // n_sweep (out): 1 + the index of the LAST vertex that made a sensor connection.  The image adjoint enters a path only at its connections,
     // so every vertex behind the last one has a zero adjoint and the sweep starts there -- for a light path that never reached this sensor's
     // view (the light of the OTHER field sources of a lens-design scene: two paths in three) it does not start at all.
@@ -198,16 +203,19 @@ MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth
             const v3 refl = bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance);
             float ssx = next_1d(rng), ssy = next_1d(rng);
             v2 uv; uv.x = uv.y = 0.f; v3 ds_p = V3(0.f, 0.f, 0.f); float sensor_weight = 0.f;
-            bool seen = sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
             const bool diffuse = !FULL || bsdf.type == MI355_BSDF_DIFFUSE;
-            bool want = seen && diffuse && sensor_weight != 0.f && max3(throughput) != 0.f;
-            Ray sensor_ray = spawn_ray_to(si.p, si.n, ds_p);
-            if (!want) { sensor_ray.o = sensor_ray.d = V3(0.f, 0.f, 1.f); sensor_ray.maxt = 0.f; }
-            bool occluded = scene_ray_test<FULL>(sc, sensor_ray, want, stk);
-            if (want && !occluded) {
-                const v3 local_d = si_to_local(si, sensor_ray.d);
-                const float wi_g = dot3(si.n, -ray.d), wo_g = dot3(si.n, sensor_ray.d);
-                if (wi_g * si.wi.z > 0.f && wo_g * local_d.z > 0.f && si.wi.z > 0.f && local_d.z > 0.f) flags |= MI_TF_CONN;
+            for (uint32_t cam = 0; cam < (MULTI ? set->n : 1u); ++cam) {     // one connection test per camera (one camera unless MULTI)
+                bool seen = MULTI ? sensor_view_sample_direction(set->v[cam], set->film_w, set->film_h, si.p, uv, ds_p, sensor_weight)
+                                  : sensor_sample_direction<FULL>(sc, si.p, ssx, ssy, uv, ds_p, sensor_weight);
+                bool want = seen && diffuse && sensor_weight != 0.f && max3(throughput) != 0.f;
+                Ray sensor_ray = spawn_ray_to(si.p, si.n, ds_p);
+                if (!want) { sensor_ray.o = sensor_ray.d = V3(0.f, 0.f, 1.f); sensor_ray.maxt = 0.f; }
+                bool occluded = scene_ray_test<FULL>(sc, sensor_ray, want, stk);
+                if (want && !occluded) {
+                    const v3 local_d = si_to_local(si, sensor_ray.d);
+                    const float wi_g = dot3(si.n, -ray.d), wo_g = dot3(si.n, sensor_ray.d);
+                    if (wi_g * si.wi.z > 0.f && wo_g * local_d.z > 0.f && si.wi.z > 0.f && local_d.z > 0.f) flags |= MI_TF_CONN_K(cam);
+                }
             }
             float s1 = next_1d(rng), s2x = next_1d(rng), s2y = next_1d(rng);
             BSample bs; v3 bsdf_val; bsdf_sample<FULL>(bsdf, refl, si.wi, s1, s2x, s2y, true, bs, bsdf_val, true);
@@ -236,13 +244,14 @@ MI_DEV uint32_t ptracer_geo_walk(const DScene &sc, Pcg32 &rng, int32_t max_depth
             if (active) active = next_1d(rng) < q;
             rr = 1.f / q; throughput = throughput * rr;                     // roulette probability detached
         }
-        if (was_active && nv < MI_TAPE_MAX_VERTS) { tape_store(tp, lane, nv, in_ray, T_in, in_hit, W, rr, flags); nv++; if (flags & MI_TF_CONN) n_sweep = nv; }
+        if (was_active && nv < MI_TAPE_MAX_VERTS) { tape_store(tp, lane, nv, in_ray, T_in, in_hit, W, rr, flags); nv++; if (flags & MI_TF_CONN_ANY) n_sweep = nv; }
     }
     return nv;
 }
 // Backward sweep over the `nv` tape records of one light sample, last vertex first: gradients into the sink.  No ray is traced here.
-template <int FULL>
-MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, uint32_t n_sweep, const GeoBwdSink &sink) {
+template <int FULL, bool MULTI = false>
+MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTape &tp, uint32_t lane, uint32_t nv, uint32_t n_sweep, const GeoBwdSink &sink,
+                              const DSensorSet *set = nullptr, const GeoGradSet *gset = nullptr) {
     gv3 lo = ga::mk<float>(0.f, 0.f, 0.f), ld = lo, lT = lo;               // lambda: adjoint of the ray / throughput LEAVING the current vertex
     ga::Sensor<float> se;
     {
@@ -260,8 +269,8 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
         const v3 T = V3(b[6 * s], b[7 * s], b[8 * s]);
         Hit h; h.t = b[9 * s]; h.u = b[10 * s]; h.v = b[11 * s];
         const v3 Wv = V3(b[12 * s], b[13 * s], b[14 * s]); const float rr = b[15 * s];
-        h.prim = __float_as_uint(b[16 * s]); const uint32_t sf = __float_as_uint(b[17 * s]); h.shape = sf >> 4;
-        const uint32_t flags = sf & 15u;
+        h.prim = __float_as_uint(b[16 * s]); const uint32_t sf = __float_as_uint(b[17 * s]); h.shape = sf >> MI_TF_SHIFT;
+        const uint32_t flags = sf & ((1u << MI_TF_SHIFT) - 1u);
         const DShape &sh = sc.shapes[h.shape];
         const DBsdf &bsdf = sc.bsdfs[sh.bsdf];
         const SI si = compute_si<FULL>(sc, r, h);
@@ -289,14 +298,37 @@ MI_DEV void ptracer_geo_sweep(const DScene &sc, float sample_scale, const GeoTap
             ga::dielectric_weight_partials(si.wi.z, bsdf.rel_eta, vx.lobe == ga::LOBE_REFLECT, vx.W, vx.dW, vx.dWe);
         vx.refl = G3(Wv); vx.K = sample_scale * MI_INV_PI;
         vx.Gv = vx.Gx = vx.Gy = ga::mk<float>(0.f, 0.f, 0.f);
+        ga::Shade<float> a; a.p = a.ng = a.ns = a.sh_s = a.sh_t = ga::mk<float>(0.f, 0.f, 0.f);
+        gv3 ad = ga::mk<float>(0.f, 0.f, 0.f), aT = ad, ao = ad; float arel = 0.f;
+        if (MULTI) {
+            // transport_adjoint is linear in (lambda, G) and ACCUMULATES: the continuation's share goes in with camera 0, every further camera
+            // adds its own connection (lambda = 0).  A camera without an image adjoint (gset->g[k] == nullptr) contributes nothing.
+            if (flags & MI_TF_CONN_ANY) vx.refl = G3(bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance));
+            const gv3 zero = ga::mk<float>(0.f, 0.f, 0.f);
+            for (uint32_t cam = 0; cam < set->n; ++cam) {
+                const bool conn = (flags & MI_TF_CONN_K(cam)) != 0u && gset->g[cam] != nullptr;
+                if (cam != 0u && !conn) continue;
+                const DSensorView &sv = set->v[cam];
+                ga::Sensor<float> sk = se;
+                sk.R[0] = sv.cam_to_world[0]; sk.R[1] = sv.cam_to_world[1]; sk.R[2] = sv.cam_to_world[2]; sk.R[3] = sv.cam_to_world[4]; sk.R[4] = sv.cam_to_world[5]; sk.R[5] = sv.cam_to_world[6];
+                sk.R[6] = sv.cam_to_world[8]; sk.R[7] = sv.cam_to_world[9]; sk.R[8] = sv.cam_to_world[10];
+                sk.cam_o = ga::mk<float>(sv.cam_to_world[3], sv.cam_to_world[7], sv.cam_to_world[11]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sk.M[i] = sv.camera_to_sample[i];
+                sk.normalization = sv.normalization;
+                vx.conn = conn; vx.Gv = vx.Gx = vx.Gy = zero;
+                if (conn) { float px, py; ga::film_position(sk, shd.p, px, py); film_gather_adj(sc, gset->g[cam], px, py, vx.Gv, vx.Gx, vx.Gy); }
+                if (cam == 0u) ga::transport_adjoint(shd, vx, sk, lo, ld, lT, a, ad, aT, arel);
+                else ga::transport_adjoint(shd, vx, sk, zero, zero, zero, a, ad, aT, arel);
+            }
+        } else {
         if (vx.conn) {
             vx.refl = G3(bsdf.texture >= 0 ? texture_eval(sc, sc.textures[bsdf.texture], si.uv, nullptr) : ld3(bsdf.reflectance));
             float px, py; ga::film_position(se, shd.p, px, py);
             film_gather_adj(sc, sink.grad_rgb, px, py, vx.Gv, vx.Gx, vx.Gy);
         }
-        ga::Shade<float> a; a.p = a.ng = a.ns = a.sh_s = a.sh_t = ga::mk<float>(0.f, 0.f, 0.f);
-        gv3 ad = ga::mk<float>(0.f, 0.f, 0.f), aT = ad, ao = ad; float arel = 0.f;
         ga::transport_adjoint(shd, vx, se, lo, ld, lT, a, ad, aT, arel);
+        }
         if (sh.type == MI355_SHAPE_MESH) {
             const uint32_t *fi = sc.faces + 3 * (size_t) (sh.tri_offset + h.prim);
             const uint32_t l0 = fi[0], l1 = fi[1], l2 = fi[2], i0 = sh.vtx_offset + l0, i1 = sh.vtx_offset + l1, i2 = sh.vtx_offset + l2;

@@ -89,6 +89,11 @@ class HipBackend:
         arr = (C.c_uint32 * len(sensors))(*[int(k) for k in sensors])
         abi.check(abi.lib().mi355_render_accumulate_sensors(scene.handle(), C.byref(p), len(sensors), arr, C.c_void_p(film.data_ptr()), _stream_ptr(film.device)))
 
+    def backward_sensors(self, scene, p, sensors, grad_ins, grads):
+        arr = (C.c_uint32 * len(sensors))(*[int(k) for k in sensors])
+        ptrs = (C.c_void_p * len(sensors))(*[None if g is None else g.data_ptr() for g in grad_ins])
+        abi.check(abi.lib().mi355_render_backward_sensors(scene.handle(), C.byref(p), len(sensors), arr, ptrs, C.c_void_p(grads.data_ptr()), _stream_ptr(grads.device)))
+
     def develop(self, scene, film, img, sensor=0):
         abi.check(abi.lib().mi355_film_develop(scene.handle(), int(sensor), C.c_void_p(film.data_ptr()), C.c_void_p(img.data_ptr()), _stream_ptr(film.device)))
 
@@ -400,6 +405,40 @@ class ParticleTracerIntegrator(Integrator):
         if evaluate:
             be.synchronize(dev)
         return out
+
+    def render_backward_sensors(self, scene, params, grad_ins, sensors, seed=0, spp=0):
+        """render_backward(scene, params, grad_ins[k], sensor=sensors[k], seed, spp) summed over k from ONE walk and ONE sweep over the light paths
+        (mi355_render_backward_sensors) -- when the sensors share their light paths and only geometry / IOR parameters ask for a gradient (the
+        lens-design step); otherwise the calls are made one after the other.  `grad_ins[k]` may be None."""
+        torch = _torch()
+        be = self.backend
+        sensors = [scene.sensor_index(k) for k in sensors]
+        one_pass = (hasattr(be, "backward_sensors") and self.sensors_share_light_paths(scene, sensors) and params is not None
+                    and params.wants_geometry() and not params.wants_colour())
+        if not one_pass:
+            grads = None
+            for k, g in zip(sensors, grad_ins):
+                if g is not None:
+                    grads = self.render_backward(scene, params, g, k, seed=seed, spp=spp)
+            return grads if grads is not None else params.grad_buffer(be.device(scene))
+        dev = be.device(scene)
+        f = scene.sensors()[sensors[0]].film
+        spp = self._resolve_spp(scene, spp, sensors[0])
+        gs = []
+        for g in grad_ins:
+            if g is None:
+                gs.append(None); continue
+            g = torch.as_tensor(g, dtype=torch.float32, device=dev).contiguous()
+            if tuple(g.shape) != (f.crop_height, f.crop_width, 3):
+                raise ValueError("grad_in must have shape (H, W, 3)")
+            gs.append(g)
+        p = self._params(scene, seed, spp, sensor=sensors[0])
+        p.flags |= abi.FLAG_GEOMETRY_GRADS | abi.FLAG_SKIP_COLOUR_GRADS
+        if hasattr(be, "enable_grads"):
+            be.enable_grads(scene, params)
+        grads = params.grad_buffer(dev)
+        be.backward_sensors(scene, p, sensors, gs, grads)
+        return grads
 
     def render_forward(self, *a, **k):
         raise PluginError("ptracer: render_forward over the colour parameters is not built (render_backward is; for mesh vertices see render_forward_geometry)")
@@ -896,9 +935,9 @@ def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, 
         @staticmethod
         def backward(ctx, *grad_outs):
             params.zero_grad()
-            for sensor, g in zip(sensors, grad_outs):                  # render_backward ACCUMULATES into the gradient buffer: the sum over the fields
-                if g is not None:
-                    integrator.render_backward(scene, params, g.contiguous(), sensor, seed=seed_grad, spp=spp_grad)
+            # the fields differentiate with ONE seed as well (util.py:517): one walk and one sweep over the light paths when only geometry / IOR
+            # parameters ask for gradients, else one render_backward per field -- either way the gradient buffer ends up with the sum over the fields
+            integrator.render_backward_sensors(scene, params, [None if g is None else g.contiguous() for g in grad_outs], sensors, seed=seed_grad, spp=spp_grad)
             return tuple(params.grad(k).clone() for k in diff_keys)
 
     return _FieldsOp.apply(*[params[k] for k in diff_keys])

@@ -299,6 +299,30 @@ def test_fields_share_one_pass_over_the_light_paths(mi, orc, torch_cuda):
         assert float(alone.max()) > 0 and float((together[k] - alone).abs().max()) < 1e-5 * float(alone.max()), k
     acc = integ.render_sensors(scene, [2, 0], seed=4, spp=32, develop=False)          # any subset, any order; the raw accumulators
     assert acc[0].shape == (32, 32, 4) and float((acc[0] - integ.render(scene, sensor=2, seed=4, spp=32, develop=False)).abs().max()) < 1e-5 * float(acc[0].max())
+    # the adjoint of the three films from ONE walk and ONE sweep (mi355_render_backward_sensors) against three render_backward calls; one camera
+    # without an image adjoint (None) contributes nothing
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    gins = [torch.rand((32, 32, 3), device="cuda", generator=gen) for _ in range(3)]
+    for drop in (None, 1):
+        use = [None if k == drop else gins[k] for k in range(3)]
+        params.zero_grad(); g_one = integ.render_backward_sensors(scene, params, use, [0, 1, 2], seed=11, spp=16).clone()
+        params.zero_grad()
+        for k in range(3):
+            if use[k] is not None:
+                integ.render_backward(scene, params, use[k], sensor=k, seed=11, spp=16, geometry=True, colour=False)
+        g_sum = params.grad_buffer(g_one.device).clone()
+        lay, _ = mi.scene_param_layout(scene)
+        seen_blocks = 0
+        for kind, index, off, size in lay:
+            if kind not in (mi.abi.PARAM_VERTEX_POSITIONS, mi.abi.PARAM_BSDF_IOR):
+                continue
+            a_, b_ = g_one[off:off + size], g_sum[off:off + size]
+            m_ = float(b_.abs().max())
+            if m_ == 0:
+                assert float(a_.abs().max()) == 0; continue
+            seen_blocks += 1
+            assert float((a_ - b_).abs().max()) < 1e-3 * m_, (drop, kind, index, float((a_ - b_).abs().max()) / m_)
+        assert seen_blocks >= 3
     # the differentiable operation: same images, same gradients as three mi.render calls
     def grads(shared):
         for v in problem.optimizer.variables.values():
