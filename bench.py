@@ -559,7 +559,7 @@ def main():
                 lr_ = max(cr["kernel_launches"], 1); lanes_r = cr["n_gen"] / lr_
                 lens_roof["render"] = valu_roofline("k_ptracer<1, false> (+ k_pt_*, k_splat_*)", "k_ptracer<1, false>", rs_k, lanes_r, (48 * cr["n_isect"] + 60 * cr["n_shadow"]) / lr_, PMC_FILES["lens"])
                 lanes_b = 128 * 128 * 128 / max(world, 1)
-                lens_roof["geometry_adjoint"] = valu_roofline("k_ptracer_geo_bwd<1> (+ k_pt_*, k_vertex_normals_bwd)", "k_ptracer_geo_bwd<1>", bs_k, lanes_b,
+                lens_roof["geometry_adjoint"] = valu_roofline("k_ptracer_geo_bwd<1, false> (+ k_pt_*, k_vertex_normals_bwd)", "k_ptracer_geo_bwd<1, false>", bs_k, lanes_b,
                                                               180.0 * cr["n_shade"] / max(cr["n_gen"], 1) * lanes_b, PMC_FILES["lens"])
             per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
         r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)

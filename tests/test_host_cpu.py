@@ -485,7 +485,7 @@ def test_bench_roofline_reads_the_committed_pmc_pass():
                                    ("k_prb_backward_1p<0, false>", line["prb"]["kernel_ms"], 512 * 512 * 64, None),
                                    ("k_ptracer<0, false>", line["ptracer"]["box"]["kernel_ms"], 512 * 512 * 64, bench.PMC_FILES["ptracer"]),
                                    ("k_ptracer<1, false>", line["lens"]["roofline"]["render"]["kernel_ms"], line["lens"]["roofline"]["render"]["pmc"]["lanes_profiled"], bench.PMC_FILES["lens"]),
-                                   ("k_ptracer_geo_bwd<1>", line["lens"]["roofline"]["geometry_adjoint"]["kernel_ms"], line["lens"]["roofline"]["geometry_adjoint"]["pmc"]["lanes_profiled"], bench.PMC_FILES["lens"])):
+                                   ("k_ptracer_geo_bwd<1, false>", line["lens"]["roofline"]["geometry_adjoint"]["kernel_ms"], line["lens"]["roofline"]["geometry_adjoint"]["pmc"]["lanes_profiled"], bench.PMC_FILES["lens"])):
         assert bench.pmc_kernel(pmc_name, f) is not None, pmc_name
         r = bench.valu_roofline(pmc_name, pmc_name, ms, lanes, 1.0, f)
         assert "pmc_stale" not in r

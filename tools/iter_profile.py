@@ -21,11 +21,11 @@ for it in range(8):
     for fs in prob.field_sources:
         fs.update(prob.params)
     losses = []
+    imgs = T("render, 3 fields in one pass", lambda: mi.render_fields(prob.scene, prob.params, [0, 1, 2], seed=it, spp=256, spp_grad=128))
     for i in range(3):
-        img = T("render x3", lambda: mi.render(prob.scene, prob.params, seed=it, spp=256, spp_grad=128, sensor=i))
-        losses.append(T("loss x3", lambda: 10000.0 * prob.field_sources[i].evaluate_rms_loss(img, recenter=True)[0]))
+        losses.append(T("loss x3", lambda: 10000.0 * prob.field_sources[i].evaluate_rms_loss(imgs[i], recenter=True)[0]))
     loss = losses[0] + losses[1] + losses[2]
-    T("loss.backward (3 x render_backward + chain rule)", lambda: loss.backward())
+    T("loss.backward (one walk + sweep for 3 fields, chain rule)", lambda: loss.backward())
     T("optimizer.step", lambda: prob.optimizer.step())
     T("params.update", lambda: prob.params.update())
 n = 5
