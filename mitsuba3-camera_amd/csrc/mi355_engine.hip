@@ -2963,7 +2963,7 @@ extern "C" int mi355_render_backward_sensors(mi355_scene *s, const mi355_render_
     if (p->integrator != MI355_INTEGRATOR_PTRACER || !(p->flags & MI355_FLAG_GEOMETRY_GRADS) || !(p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))
         return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer's geometry / IOR adjoint only (MI355_FLAG_GEOMETRY_GRADS | MI355_FLAG_SKIP_COLOUR_GRADS)");
     if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
-    if ((p->passes ? p->passes : 1u) != 1u || p->pixel_count || p->spp_count || p->pixel_tile) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: whole job, one pass");
+    if ((p->passes ? p->passes : 1u) != 1u) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: samples_per_pass is not carried");   // (a shard of the light-sample grid is fine: it is the same for every camera)
     for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
     const DScene &f = s->sensors[sensors[0]].snap;
     MultiAdjoint m; memset(&m, 0, sizeof(m)); m.set.n = n_sensors; m.set.film_w = (float) f.film_w; m.set.film_h = (float) f.film_h;
@@ -3221,7 +3221,7 @@ extern "C" int mi355_render_accumulate_sensors(mi355_scene *s, const mi355_rende
     if (!s || !p || !sensors || !d_film) return fail(MI355_ERR_INVALID, "null argument");
     if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer only");
     if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
-    if ((p->passes ? p->passes : 1u) != 1u || p->pixel_count || p->spp_count || p->pixel_tile) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: whole job, one pass");
+    if ((p->passes ? p->passes : 1u) != 1u) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: samples_per_pass is not carried");   // (a shard of the light-sample grid is fine: it is the same for every camera)
     for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
     const DScene &f = s->sensors[sensors[0]].snap;
     for (uint32_t k = 0; k < n_sensors; ++k) {                              // one lane layout, one film geometry, one filter: what the cameras must share

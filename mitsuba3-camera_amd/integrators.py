@@ -378,7 +378,7 @@ class ParticleTracerIntegrator(Integrator):
                 return False
         return True
 
-    def render_sensors(self, scene, sensors, seed=0, spp=0, develop=True, evaluate=True):
+    def render_sensors(self, scene, sensors, seed=0, spp=0, develop=True, evaluate=True, shard=None, group=None):
         """Integrator.render(scene, sensor=k, seed, spp) for every k of `sensors` from ONE pass over the light paths (mi355_render_accumulate_sensors):
         design_problem.py:525-537 renders each field with the same seed, so the fields share their light paths and differ in the sensor connection
         only.  Returns the list of images (or of RGBW accumulators), equal to the separate renders up to the order of the float additions."""
@@ -387,13 +387,18 @@ class ParticleTracerIntegrator(Integrator):
         dev = be.device(scene)
         sensors = [scene.sensor_index(k) for k in sensors]
         if not self.sensors_share_light_paths(scene, sensors):
-            return [self.render(scene, k, seed, spp, develop, evaluate) for k in sensors]
+            return [self.render(scene, k, seed, spp, develop, evaluate, shard, group) for k in sensors]
         f = scene.sensors()[sensors[0]].film
         spp = self._resolve_spp(scene, spp, sensors[0])
         pitch, x0, virt_w = C.c_uint32(), C.c_uint32(), C.c_uint32()
         abi.check(abi.lib().mi355_multi_film_layout(f.width, len(sensors), C.byref(pitch), C.byref(x0), C.byref(virt_w)))
         stack = torch.zeros((f.height, virt_w.value, 4), dtype=torch.float32, device=dev)
-        be.accumulate_sensors(scene, self._params(scene, seed, spp, sensor=sensors[0]), sensors, stack)
+        band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
+        if band is None or band[1] > 0:
+            be.accumulate_sensors(scene, self._params(scene, seed, spp, shard=band, sensor=sensors[0]), sensors, stack)
+        if shard is not None and shard[1] > 1:                               # the ranks' partial films add up in the virtual film
+            import torch.distributed as dist
+            dist.all_reduce(stack, op=dist.ReduceOp.SUM, group=group)
         out = []
         for k, sensor in enumerate(sensors):
             film = stack[:, k * pitch.value + x0.value: k * pitch.value + x0.value + f.width, :].contiguous()
@@ -406,7 +411,7 @@ class ParticleTracerIntegrator(Integrator):
             be.synchronize(dev)
         return out
 
-    def render_backward_sensors(self, scene, params, grad_ins, sensors, seed=0, spp=0):
+    def render_backward_sensors(self, scene, params, grad_ins, sensors, seed=0, spp=0, shard=None, group=None):
         """render_backward(scene, params, grad_ins[k], sensor=sensors[k], seed, spp) summed over k from ONE walk and ONE sweep over the light paths
         (mi355_render_backward_sensors) -- when the sensors share their light paths and only geometry / IOR parameters ask for a gradient (the
         lens-design step); otherwise the calls are made one after the other.  `grad_ins[k]` may be None."""
@@ -419,7 +424,7 @@ class ParticleTracerIntegrator(Integrator):
             grads = None
             for k, g in zip(sensors, grad_ins):
                 if g is not None:
-                    grads = self.render_backward(scene, params, g, k, seed=seed, spp=spp)
+                    grads = self.render_backward(scene, params, g, k, seed=seed, spp=spp, shard=shard, group=group)
             return grads if grads is not None else params.grad_buffer(be.device(scene))
         dev = be.device(scene)
         f = scene.sensors()[sensors[0]].film
@@ -432,12 +437,20 @@ class ParticleTracerIntegrator(Integrator):
             if tuple(g.shape) != (f.crop_height, f.crop_width, 3):
                 raise ValueError("grad_in must have shape (H, W, 3)")
             gs.append(g)
-        p = self._params(scene, seed, spp, sensor=sensors[0])
+        band = shard_of(f, shard[0], shard[1], grid=self.lane_grid(f)) if shard is not None else None
+        p = self._params(scene, seed, spp, shard=band, sensor=sensors[0])
         p.flags |= abi.FLAG_GEOMETRY_GRADS | abi.FLAG_SKIP_COLOUR_GRADS
         if hasattr(be, "enable_grads"):
             be.enable_grads(scene, params)
         grads = params.grad_buffer(dev)
-        be.backward_sensors(scene, p, sensors, gs, grads)
+        multi = shard is not None and shard[1] > 1
+        local = torch.zeros_like(grads) if multi else grads
+        if band is None or band[1] > 0:
+            be.backward_sensors(scene, p, sensors, gs, local)
+        if multi:
+            import torch.distributed as dist
+            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+            grads += local
         return grads
 
     def render_forward(self, *a, **k):
@@ -902,7 +915,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     return _RenderOp.apply(*[params[k] for k in diff_keys])
 
 
-def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0):
+def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0, shard=None, group=None):
     """mi.render(scene, params, sensor=k, seed=seed, ...) for every k of `sensors`, as ONE differentiable operation: the primal images come from
     one pass over the light paths when the sensors allow it (ParticleTracerIntegrator.render_sensors), the adjoint is the sum of the sensors'
     render_backward calls.  Returns the tuple of images.  (design_problem.py:525-537 renders the fields of an iteration one after the other with
@@ -912,7 +925,7 @@ def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, 
         integrator = scene.integrator()
     sensors = [scene.sensor_index(k) for k in sensors]
     if not hasattr(integrator, "render_sensors") or not integrator.sensors_share_light_paths(scene, sensors):
-        return tuple(render(scene, params, sensor=k, integrator=integrator, seed=seed, seed_grad=seed_grad, spp=spp, spp_grad=spp_grad) for k in sensors)
+        return tuple(render(scene, params, sensor=k, integrator=integrator, seed=seed, seed_grad=seed_grad, spp=spp, spp_grad=spp_grad, shard=shard, group=group) for k in sensors)
     if spp_grad == 0:
         spp_grad = spp
     if seed_grad == 0:
@@ -923,21 +936,21 @@ def render_fields(scene, params, sensors, integrator=None, seed=0, seed_grad=0, 
     if params is not None:
         params.update(skip=diff_keys)
     if not diff_keys:
-        return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False))
+        return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False, shard=shard, group=group))
 
     class _FieldsOp(torch.autograd.Function):
         @staticmethod
         def forward(ctx, *tensors):
             for k, t in zip(diff_keys, tensors):
                 params._push(k, t); params._dirty.discard(k)
-            return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False))
+            return tuple(integrator.render_sensors(scene, sensors, seed=seed, spp=spp, evaluate=False, shard=shard, group=group))
 
         @staticmethod
         def backward(ctx, *grad_outs):
             params.zero_grad()
             # the fields differentiate with ONE seed as well (util.py:517): one walk and one sweep over the light paths when only geometry / IOR
             # parameters ask for gradients, else one render_backward per field -- either way the gradient buffer ends up with the sum over the fields
-            integrator.render_backward_sensors(scene, params, [None if g is None else g.contiguous() for g in grad_outs], sensors, seed=seed_grad, spp=spp_grad)
+            integrator.render_backward_sensors(scene, params, [None if g is None else g.contiguous() for g in grad_outs], sensors, seed=seed_grad, spp=spp_grad, shard=shard, group=group)
             return tuple(params.grad(k).clone() for k in diff_keys)
 
     return _FieldsOp.apply(*[params[k] for k in diff_keys])

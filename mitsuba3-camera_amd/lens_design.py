@@ -991,14 +991,14 @@ class DesignProblem:
         loss = None; pending = []
         # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
         # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
-        # The fields of an iteration are rendered with ONE seed (:525-537), so their cameras see the same light paths: unsharded, the primal images
-        # come from one pass over those paths (integrators.render_fields; up to four cameras per pass); the adjoint stays one pass per field.
+        # The fields of an iteration are rendered (and differentiated) with ONE seed (:525-537), so their cameras see the same light paths: the images
+        # come from one pass over those paths and the gradients from one walk + sweep (integrators.render_fields; up to four cameras per pass).
         shard = getattr(self, "shard", None); images = {}
-        if shard is None and getattr(self, "share_light_paths", True):
+        if getattr(self, "share_light_paths", True) and hasattr(self.scene.integrator(), "render_sensors"):
             from .integrators import render_fields
             for first in range(0, self.num_sources, 4):
                 group_ids = list(range(first, min(first + 4, self.num_sources)))
-                for k, im in zip(group_ids, render_fields(self.scene, self.params, group_ids, seed=it, spp=2 * self.spp, spp_grad=self.spp)):
+                for k, im in zip(group_ids, render_fields(self.scene, self.params, group_ids, seed=it, spp=2 * self.spp, spp_grad=self.spp, shard=shard, group=getattr(self, "group", None))):
                     images[k] = im
         for sensor_idx in range(self.num_sources):
             image = images[sensor_idx] if sensor_idx in images else render(self.scene, self.params, seed=it, spp=2 * self.spp, spp_grad=self.spp, sensor=sensor_idx, shard=shard, group=getattr(self, "group", None))
