@@ -580,3 +580,48 @@ def test_adam_kernel_matches_the_per_variable_update(mi, torch_cuda):
     for k in init:
         assert np.allclose(outs[0][k], outs[1][k], rtol=2e-6, atol=1e-7), (k, outs[0][k], outs[1][k])
         assert not np.allclose(outs[0][k], init[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rfilter", ["gaussian", "box"])
+def test_geometry_adjoint_of_several_sensors_in_one_pass(mi, torch_cuda, rfilter):
+    """mi355_render_backward_sensors on the cap-lens arrangement watched by THREE perspective cameras from different sides (Gaussian and box
+    filters; the lens-design test covers the tent filter): gradient buffer == sum of three mi355_render_backward calls, block by block, and the
+    images of the one-pass render == the three separate renders.  Plain tensors, explicit geometry request: every vertex / IOR slot is filled."""
+    torch = torch_cuda
+    T = mi.ScalarTransform4f
+    d = _cap_lens_scene(mi, 24, rfilter=rfilter)
+    for k, origin in enumerate(([-0.25, 0.3, 0.7], [0.1, -0.35, 0.5])):
+        se = dict(d['sensor']); se['to_world'] = T.look_at(target=[0.0, 0.0, 0.0], origin=origin, up=[0, 1, 0]); se['fov'] = 50.0 + 15.0 * k
+        se['film'] = dict(d['sensor']['film'])
+        d['sensor_%d' % (k + 1)] = se
+    scene = mi.load_dict(d)
+    integ = scene.integrator()
+    assert len(scene.sensors()) == 3 and integ.sensors_share_light_paths(scene, [0, 1, 2])
+    one = integ.render_sensors(scene, [0, 1, 2], seed=3, spp=64)
+    for k in range(3):
+        sep = integ.render(scene, sensor=k, seed=3, spp=64)
+        assert float(sep.max()) > 0 and float((one[k] - sep).abs().max()) < 1e-5 * float(sep.max()), k
+    params = mi.traverse(scene)
+    for key in ("lens.vertex_positions", "lens.bsdf.int_ior"):                # ask for the geometry / IOR gradients (and for nothing else)
+        params[key] = params[key].detach().clone().requires_grad_(True)
+    params.update()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    gins = [torch.rand((24, 24, 3), device="cuda", generator=gen) for _ in range(3)]
+    params.zero_grad(); g_one = integ.render_backward_sensors(scene, params, gins, [0, 1, 2], seed=8, spp=32).clone()
+    params.zero_grad()
+    for k in range(3):
+        integ.render_backward(scene, params, gins[k], sensor=k, seed=8, spp=32)
+    g_sum = params.grad_buffer(g_one.device).clone()
+    seen = 0
+    for kind, index, off, size in scene_layout(mi, scene):
+        if kind not in (mi.abi.PARAM_VERTEX_POSITIONS, mi.abi.PARAM_BSDF_IOR):
+            continue
+        a, b = g_one[off:off + size], g_sum[off:off + size]
+        m = float(b.abs().max())
+        if m == 0:
+            assert float(a.abs().max()) == 0; continue
+        seen += 1
+        assert float((a - b).abs().max()) < 1e-3 * m, (kind, index, float((a - b).abs().max()) / m)
+    assert seen >= 2
+    scene.release()
