@@ -332,6 +332,14 @@ class LensElement:
         if ext_params is not None:
             for k, v in ext_params.items():
                 self.surface.params[k] = v
+        # A surface none of whose scalars is optimised keeps plain floats; with the same floats as at the last push its two meshes are
+        # already in place (20 of the 22 surfaces of the wide-angle design of report_nikon_exp.ipynb): no sag launch, no upload, no new
+        # normals, and the refit finds the meshes clean.
+        if all(not torch.is_tensor(v) for v in self.surface.params.values()):
+            state = tuple(sorted((k, float(v)) for k, v in self.surface.params.items()))
+            if getattr(self, "_pushed_surface", None) == state:
+                return
+            self._pushed_surface = state
         params['%s.vertex_positions' % self.lens_key] = surface_positions(self.surface, self.initial_lens_vertices).reshape(-1)
         # the baffle follows the surface's rim in z (lens.py:553-565): every baffle vertex takes z(radial_extent, 0)
         if getattr(self, "_rim_xy", None) is None or self._rim_xy.shape[0] != self.initial_baffle_vertices.shape[0] or self._rim_xy.device != self.initial_baffle_vertices.device:
@@ -439,6 +447,11 @@ class ApertureElement:
         torch = _torch()
         if self.param_keys_to_opt_keys is None:
             return
+        if all(not torch.is_tensor(v) for v in self.surface.params.values()):      # as LensElement.update: an unchanged stop stays in place
+            state = tuple(sorted((k, float(v)) for k, v in self.surface.params.items()))
+            if getattr(self, "_pushed_surface", None) == state:
+                return
+            self._pushed_surface = state
         x0 = self.initial_ap_vertices
         rim_xy = torch.tensor([self.surface.radial_extent, 0.0], dtype=torch.float32, device=x0.device).repeat(x0.shape[0], 1)
         params['%s.vertex_positions' % self.ap_key] = surface_positions(self.surface, x0, rim_xy).reshape(-1)

@@ -380,3 +380,32 @@ def test_nikon_design_matches_the_report_notebooks_stored_outputs(mi, orc):
     assert err_u > 2e-5 and err_y > 2e-5                                      # "u is close: False", "y is close: False"
     assert abs(err_u - ref_u) < 0.3 * ref_u, (err_u, ref_u)                    # measured: 5.2e-5
     assert 0.5 * ref_y < err_y < 2.0 * ref_y, (err_y, ref_y)                   # measured: 1.5e-4
+
+
+def test_a_surface_with_unchanged_scalars_is_not_pushed_again(mi):
+    """LensElement.update (lens.py:509-568) writes every surface's vertices each iteration; here a surface that keeps plain floats equal to
+    the last push is left alone (20 of the 22 surfaces of report_nikon_exp.ipynb), and one whose float is edited by hand is pushed again."""
+    import torch
+    ld = mi.lens_design
+    el = ld.LensElement(0, ld.EvenAsphericSurface(radial_extent=4.0, c=1 / 30, K=0.0, z0=10.0), ld.LensMaterial("nbk7", 1.5168, 64.17), ld.LensMaterial(), N=2)
+    el.initialize_geometry(); el.lens_key = "lens0"; el.baffle_key = "baffle0"
+
+    class Recorder(dict):
+        writes = 0
+        def __setitem__(self, k, v):
+            if k.endswith("vertex_positions"):
+                Recorder.writes += 1
+            dict.__setitem__(self, k, v)
+    params = Recorder()
+    dict.__setitem__(params, "lens0.vertex_positions", torch.tensor(el.V_lens, dtype=torch.float32).reshape(-1))
+    dict.__setitem__(params, "baffle0.vertex_positions", torch.tensor(el.V_ap, dtype=torch.float32).reshape(-1))
+    el.save_init_state(params); el.remove_all_optvars()
+    opt = {}; el.add_to_optimizer(opt, "cpu"); assert opt == {}
+    el.update(params, opt); assert Recorder.writes == 2                       # first push: the lens mesh and its baffle
+    first = params["lens0.vertex_positions"].clone()
+    el.update(params, opt); el.update(params, opt); assert Recorder.writes == 2
+    el.surface.params['z0'] = 10.5
+    el.update(params, opt); assert Recorder.writes == 4
+    assert torch.allclose(params["lens0.vertex_positions"].reshape(-1, 3)[:, 2], first.reshape(-1, 3)[:, 2] + 0.5, atol=1e-6)
+    el.surface.params['c'] = torch.tensor([1 / 30])                           # a tensor may change in place: always pushed
+    el.update(params, opt); el.update(params, opt); assert Recorder.writes == 8
