@@ -992,9 +992,9 @@ __global__ __launch_bounds__(256) void k_pt_scatter(const uint32_t *keys, uint32
 }
 
 // ---- deferred splat, steps 2-5 (step 1 = film_put_deferred inside k_ptracer) ------------------------------------------------------
-#define SPLAT_CHUNK 8192u                                                   // records per workgroup in the histogram / scatter passes
+#define SPLAT_CHUNK 8192u                                                   // records per workgroup in the histogram pass
 #define SPLAT_RUN 4096u                                                     // records per workgroup in the tile pass
-#define SPLAT_MAX_TILES 8000u                                               // LDS of the scatter pass: 3 x 4 B per tile + the 32 KB permutation = 128 KB (films up to ~1430^2; larger ones splat directly)
+#define SPLAT_MAX_TILES 8000u                                               // LDS of the scatter pass: 2 x 4 B per tile + 80 - 96 KB of records <= 159 KB (films up to ~1430^2; larger ones splat directly)
 // Tile histogram of the record queue; one LDS histogram per chunk, flushed with one global atomic per non-empty bin.
 __global__ __launch_bounds__(256) void k_splat_hist(DScene sc, SplatQueue q, uint32_t n_tiles) {
     extern __shared__ uint32_t s_bins[];
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_splat_hist(DScene sc, SplatQueue q, uin
         for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) s_bins[k] = 0u;
         __syncthreads();
         const uint32_t c1 = min(c0 + SPLAT_CHUNK, seg_end);
-        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 1024u) {            // (four loads in flight per thread: see k_splat_scatter)
+        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 1024u) {            // (four loads in flight per thread: a wave that issues them one at a time spends its life waiting for HBM)
             float4 a[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] = i + 256u * u < c1 ? q.rec_a[i + 256u * u] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1039,67 +1039,75 @@ __global__ __launch_bounds__(1024) void k_splat_scan(const uint32_t *hist, uint3
     }
     if (threadIdx.x == 0) offsets[n_tiles] = s_carry;
 }
-// Counting sort, scatter step.  Per chunk: LDS histogram -> one global cursor atomic per non-empty tile reserves the chunk's range in
-// that tile -> the chunk is sorted LOCALLY first (a permutation in LDS: tile-major, rank within the tile from an LDS cursor) and written
-// out in that order, so that consecutive lanes store to consecutive slots of a tile's reservation.  Storing each record straight to its
-// slot scattered 16 + 4 bytes per lane: WRITE_SIZE 3.3 GB for 1.3 GB of records (profiles/r03_pmc_ptracer_summary.txt, partial 32-byte
-// sectors), 2.3 ms per 67 M records; the reads that replace the scatter gather 20 bytes from a 160 KB chunk that is still in L2.
-__global__ __launch_bounds__(256) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b,
-                                                       float4 *out_c, float *out_d, uint32_t n_tiles) {
-    extern __shared__ uint32_t s_bins[];                                    // [n_tiles] counts -> global bases; [n_tiles] local cursors; [n_tiles] local starts; [SPLAT_CHUNK] permutation
-    uint32_t *s_cur = s_bins + n_tiles, *s_start = s_cur + n_tiles, *s_perm = s_start + n_tiles;
-    __shared__ uint32_t s_part[256];
-    const uint32_t cps = (q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK;
-    const uint32_t per = (n_tiles + 255u) / 256u;                           // tiles per thread in the local scan
+// Counting sort, scatter step.  A workgroup takes SPLAT_SORT records, SPLAT_SORT_R per thread, and reads them ONCE, into registers: the count
+// atomic of a record's tile in LDS returns the record's rank inside that tile; a scan of the counts gives every tile its start inside the
+// chunk, one global cursor atomic per non-empty tile reserves the chunk's range in that tile; the records go to LDS at start + rank, i.e.
+// sorted, and leave it in that order, so that consecutive lanes store to consecutive slots of a tile's reservation.
+// History (profiles/r03_pmc_ptracer_summary.txt): storing each record straight to its slot scattered 16 + 4 bytes per lane -- WRITE_SIZE 3.3 GB
+// for 1.3 GB of records, 2.3 ms per 57 M records; sorting a permutation of an 8192-record chunk in LDS and reading the chunk three times from
+// global memory cured the writes but not the reads: 768 resident chunks of 160 KB are 120 MB against 8 x 4 MB of L2, FETCH_SIZE 3.5 GB, 1.3 ms.
+// Chunk size, light tracer on the Cornell box 512^2 x 64 spp, box / Gaussian filter, ms per render (profiles/r03_splat_scatter_ab.txt): 1024 records
+// 7.70 / 9.11, 2048 4.70 / 5.92, 4096 4.18 / 5.45 (as 1024 threads x 4 records; 512 x 8: 4.29 / 5.47); the three-pass 8192-record version 5.12 / 6.21.
+// Every chunk costs one returning global atomic per tile it touches, all chunks on the same n_tiles cursor words: the fewer chunks the better, and
+// 4096 records x 20 B is what fits the LDS next to the tile tables.
+#ifndef SPLAT_SORT_T
+#define SPLAT_SORT_T 1024u
+#define SPLAT_SORT_R 4u
+#endif
+#define SPLAT_SORT (SPLAT_SORT_T * SPLAT_SORT_R)
+__global__ __launch_bounds__(SPLAT_SORT_T) void k_splat_scatter(DScene sc, SplatQueue q, const uint32_t *offsets, uint32_t *cursor, float4 *out_a, float *out_b,
+                                                                float4 *out_c, float *out_d, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_sort[];       // [n_tiles] counts -> global bases; [n_tiles] starts inside the chunk; the sorted records: float4[SORT], float[SORT] (, source index[SORT] for the second record half)
+    uint32_t *s_bins = s_sort, *s_start = s_sort + n_tiles;
+    float4 *s_a = reinterpret_cast<float4 *>(s_sort + ((2u * n_tiles + 3u) & ~3u));
+    float *s_b = reinterpret_cast<float *>(s_a + SPLAT_SORT);
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_b + SPLAT_SORT);
+    __shared__ uint32_t s_wave[SPLAT_SORT_T / 64u];
+    const uint32_t cps = (q.seg_cap + SPLAT_SORT - 1u) / SPLAT_SORT;
+    const uint32_t per = (n_tiles + SPLAT_SORT_T - 1u) / SPLAT_SORT_T;      // tiles per thread in the scan
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t w = blockIdx.x; w < MI_SPLAT_SEGS * cps; w += gridDim.x) {
-        const uint32_t seg = w / cps, c0 = seg * q.seg_cap + (w % cps) * SPLAT_CHUNK;
+        const uint32_t seg = w / cps, c0 = seg * q.seg_cap + (w % cps) * SPLAT_SORT;
         const uint32_t seg_end = seg * q.seg_cap + min(q.count[seg * MI_SPLAT_COUNTER_STRIDE], q.seg_cap);
-        if (c0 >= seg_end) continue;
-        for (uint32_t k = threadIdx.x; k < n_tiles; k += 256u) { s_bins[k] = 0u; s_cur[k] = 0u; }
+        if (c0 >= seg_end) continue;                                        // (uniform over the workgroup)
+        for (uint32_t k = threadIdx.x; k < n_tiles; k += SPLAT_SORT_T) s_bins[k] = 0u;
         __syncthreads();
-        const uint32_t c1 = min(c0 + SPLAT_CHUNK, seg_end);
-        // (four records per thread and trip: the loop is a chain of dependent global loads, and a wave that issues them one at a time spends its
-        //  life waiting for HBM -- 110 cycles per instruction at 4 waves per SIMD in the PMC pass of the one-record version)
-        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 1024u) {
-            float4 a[4];
+        const uint32_t n = min(SPLAT_SORT, seg_end - c0);
+        float4 a[SPLAT_SORT_R]; float b[SPLAT_SORT_R]; uint32_t tile[SPLAT_SORT_R], rank[SPLAT_SORT_R];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = i + 256u * u < c1 ? q.rec_a[i + 256u * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t u = 0; u < SPLAT_SORT_R; ++u) {                       // (all loads of a thread in flight together)
+            const uint32_t i = threadIdx.x + SPLAT_SORT_T * u;
+            a[u] = i < n ? q.rec_a[c0 + i] : make_float4(0.f, 0.f, 0.f, 0.f); b[u] = i < n ? q.rec_b[c0 + i] : 0.f;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + 256u * u < c1) atomicAdd(s_bins + splat_tile_of(sc, q, a[u].x, a[u].y), 1u);
+        for (uint32_t u = 0; u < SPLAT_SORT_R; ++u) if (threadIdx.x + SPLAT_SORT_T * u < n) {
+            tile[u] = splat_tile_of(sc, q, a[u].x, a[u].y); rank[u] = atomicAdd(s_bins + tile[u], 1u);
         }
         __syncthreads();
-        // local exclusive scan of the counts (thread t owns tiles [t * per, (t + 1) * per)), then the global reservations
-        uint32_t sum = 0; const uint32_t kb = threadIdx.x * per, ke = min(kb + per, n_tiles);
+        // exclusive scan of the counts (thread t owns tiles [t * per, (t + 1) * per)), then the global reservations
+        uint32_t sum = 0; const uint32_t kb = min(threadIdx.x * per, n_tiles), ke = min(kb + per, n_tiles);
         for (uint32_t k = kb; k < ke; ++k) sum += s_bins[k];
-        s_part[threadIdx.x] = sum; __syncthreads();
-        for (uint32_t d = 1; d < 256u; d <<= 1) { const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u; __syncthreads(); s_part[threadIdx.x] += v; __syncthreads(); }
-        uint32_t run = s_part[threadIdx.x] - sum;
+        uint32_t incl = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t k = 0; k < wave; ++k) run += s_wave[k];
         for (uint32_t k = kb; k < ke; ++k) { const uint32_t v = s_bins[k]; s_start[k] = run; run += v; if (v) s_bins[k] = offsets[k] + atomicAdd(cursor + k, v); }
         __syncthreads();
-        for (uint32_t i = c0 + threadIdx.x; i < c1; i += 1024u) {            // the permutation: sorted position -> record
-            float4 a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = i + 256u * u < c1 ? q.rec_a[i + 256u * u] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + 256u * u < c1) {
-                const uint32_t t = splat_tile_of(sc, q, a[u].x, a[u].y);
-                s_perm[s_start[t] + atomicAdd(s_cur + t, 1u)] = i + 256u * u - c0;
-            }
+        for (uint32_t u = 0; u < SPLAT_SORT_R; ++u) if (threadIdx.x + SPLAT_SORT_T * u < n) {
+            const uint32_t p = s_start[tile[u]] + rank[u];
+            s_a[p] = a[u]; s_b[p] = b[u];
+            if (out_c) s_src[p] = threadIdx.x + SPLAT_SORT_T * u;
         }
         __syncthreads();
-        for (uint32_t pos = threadIdx.x; pos < c1 - c0; pos += 1024u) {     // consecutive lanes -> consecutive slots of a tile's reservation
-            uint32_t src[4]; float4 a[4]; float b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) src[u] = pos + 256u * u < c1 - c0 ? c0 + s_perm[pos + 256u * u] : c0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = q.rec_a[src[u]]; b[u] = q.rec_b[src[u]]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (pos + 256u * u < c1 - c0) {
-                const uint32_t t = splat_tile_of(sc, q, a[u].x, a[u].y);
-                const uint32_t dst = s_bins[t] + (pos + 256u * u - s_start[t]);
-                out_a[dst] = a[u]; out_b[dst] = b[u];
-                if (out_c) { out_c[dst] = q.rec_c[src[u]]; out_d[dst] = q.rec_d[src[u]]; }
-            }
+        for (uint32_t pos = threadIdx.x; pos < n; pos += SPLAT_SORT_T) {    // consecutive lanes -> consecutive slots of a tile's reservation
+            const float4 ra = s_a[pos];
+            const uint32_t t = splat_tile_of(sc, q, ra.x, ra.y), dst = s_bins[t] + (pos - s_start[t]);
+            out_a[dst] = ra; out_b[dst] = s_b[pos];
+            if (out_c) { const uint32_t src = c0 + s_src[pos]; out_c[dst] = q.rec_c[src]; out_d[dst] = q.rec_d[src]; }
         }
         __syncthreads();
     }
@@ -2716,9 +2724,12 @@ static int splat_queue_flush(mi355_scene *s, const SplatQueue &q, hipStream_t st
     const uint32_t chunks = std::min<uint32_t>(MI_SPLAT_SEGS * ((q.seg_cap + SPLAT_CHUNK - 1u) / SPLAT_CHUNK), 16384u), runs = std::min<uint32_t>((q.cap + SPLAT_RUN - 1u) / SPLAT_RUN, 65536u);
     hipLaunchKernelGGL(k_splat_hist, dim3(chunks), dim3(256), n_tiles * sizeof(uint32_t), st, s->ds, q, n_tiles);
     hipLaunchKernelGGL(k_splat_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *) q.hist, offsets, cursor, n_tiles);
-    const size_t scatter_lds = (3 * (size_t) n_tiles + SPLAT_CHUNK) * sizeof(uint32_t);    // <= 128 KB at SPLAT_MAX_TILES: above the 64 KB a launch gets without asking
+    // LDS of the scatter pass: two words per tile + 20 (24 with a second record half) bytes per record: 88 KB on a 512^2 film (one 16-wave workgroup
+    // per CU), 144 - 159 KB at SPLAT_MAX_TILES -- above the 64 KB a launch gets without asking
+    const size_t scatter_lds = (((2 * (size_t) n_tiles + 3) & ~(size_t) 3) + (dual ? 6 : 5) * (size_t) SPLAT_SORT) * sizeof(uint32_t);
+    const uint32_t sorts = std::min<uint32_t>(MI_SPLAT_SEGS * ((q.seg_cap + SPLAT_SORT - 1u) / SPLAT_SORT), 16384u);
     if (scatter_lds > 65536u) HIP_TRY(hipFuncSetAttribute((const void *) k_splat_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) scatter_lds));
-    hipLaunchKernelGGL(k_splat_scatter, dim3(chunks), dim3(256), scatter_lds, st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b,
+    hipLaunchKernelGGL(k_splat_scatter, dim3(sorts), dim3(SPLAT_SORT_T), scatter_lds, st, s->ds, q, (const uint32_t *) offsets, cursor, s->d_srt_a, s->d_srt_b,
                        dual ? s->d_srt_c : (float4 *) nullptr, dual ? s->d_srt_d : (float *) nullptr, n_tiles);
     if (dual) hipLaunchKernelGGL(k_splat_tiles<true>, dim3(runs), dim3(256), 0, st, s->ds, q, (const uint32_t *) offsets, (const float4 *) s->d_srt_a, (const float *) s->d_srt_b,
                                  (const float4 *) s->d_srt_c, (const float *) s->d_srt_d, d_film_rgbw, n_tiles);
