@@ -443,11 +443,12 @@ int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_base_position
    light paths, and only the sensor connection at every vertex (ptracer.cpp:232-236, perspective.cpp:282-340) is per camera.  This call traces the paths
    once and connects every vertex to each of the `n_sensors` cameras: the same films as `n_sensors` calls of mi355_render_accumulate with that seed, up to
    the order of the float additions.  Requirements (else MI355_ERR_UNSUPPORTED): perspective sensors, one film size without a crop window, one
-   reconstruction filter, one pass (no samples_per_pass).  A shard of the light-sample grid (pixel_* / spp_* of `params`) applies to every camera alike: the
+   reconstruction filter, one pass (no samples_per_pass), 1 <= n_sensors <= MI355_MAX_SENSORS_PER_PASS (else MI355_ERR_INVALID).  A shard of the light-sample grid (pixel_* / spp_* of `params`) applies to every camera alike: the
    partial films of the ranks add up in the virtual film.
      d_film   H x virt_w x 4 floats (RGBW), zeroed by the caller: sensor k's film occupies the columns [k * pitch + x0, k * pitch + x0 + W) of every row
               (mi355_multi_film_layout: pitch = roundup(W, 16) + 32, x0 = 16, virt_w = n_sensors * pitch); the columns in between receive the filter
               taps that leave a film and are to be ignored.  Develop a film by copying its columns out and calling mi355_film_develop on the copy. */
+#define MI355_MAX_SENSORS_PER_PASS 8u
 int mi355_multi_film_layout(uint32_t film_w, uint32_t n_sensors, uint32_t *pitch, uint32_t *x0, uint32_t *virt_w);
 int mi355_render_accumulate_sensors(mi355_scene *scene, const mi355_render_params *params, uint32_t n_sensors, const uint32_t *sensors, float *d_film, void *stream);
 /* ... and its adjoint with respect to mesh vertex positions and IORs (mi355_render_backward with MI355_FLAG_GEOMETRY_GRADS | MI355_FLAG_SKIP_COLOUR_GRADS,

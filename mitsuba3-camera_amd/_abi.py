@@ -23,6 +23,7 @@ WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 FLAG_HIDE_EMITTERS, FLAG_TIMING, FLAG_REGEN, FLAG_TWO_PASS, FLAG_EMITTER_GRADS_ONLY, FLAG_DIRECT_SPLAT, FLAG_GEOMETRY_GRADS, FLAG_SKIP_COLOUR_GRADS = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_NO_LANE_SORT = 256
 MODE_FUSED, MODE_REPACK_ALWAYS, MODE_STATIC = 0, 1, 2
+MAX_SENSORS_PER_PASS = 8                     # MI355_MAX_SENSORS_PER_PASS
 MODE_WAVEFRONT = MODE_REPACK_ALWAYS          # name up to ABI v8 (one fused launch either way: nothing wavefront-formulated about it)
 INTEGRATOR_PATH, INTEGRATOR_PRB, INTEGRATOR_PTRACER = 0, 1, 2
 PARAM_BSDF_REFLECTANCE, PARAM_TEXTURE_DATA, PARAM_EMITTER_RADIANCE, PARAM_VERTEX_POSITIONS, PARAM_BSDF_IOR, PARAM_SENSOR_TO_WORLD, PARAM_SENSOR_X_FOV = 0, 1, 2, 3, 4, 5, 6

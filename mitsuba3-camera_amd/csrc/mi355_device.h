@@ -193,7 +193,7 @@ struct DScene {
 // seed and on the film SIZE only, so the fields of a lens-design scene -- same seed, same film size, one camera each -- share them; only the
 // sensor connection at every vertex is made once per camera.  The films lie side by side in one virtual film (x_offset, DSensorSet::virt_w is
 // the kernel's crop_w), so the deferred splat sorts and accumulates all of them in one go.
-#define MI_MULTI_MAX 4
+#define MI_MULTI_MAX MI355_MAX_SENSORS_PER_PASS                              // (8: the notebooks run 3, 5 and 6 field sources)
 struct DSensorView { float cam_to_world[12]; float camera_to_sample[16]; float image_rect[4]; float normalization, near_clip, far_clip, x_offset; };
 struct DSensorSet { uint32_t n; float film_w, film_h; uint32_t pad; DSensorView v[MI_MULTI_MAX]; };
 
@@ -2273,6 +2273,10 @@ MI_DEV bool sensor_sample_direction(const DScene &sc, v3 p, float sx_, float sy_
     weight = importance * inv_dist * inv_dist;
     return true;
 }
+// Film position -> position in the virtual film of a DSensorSet.  With a box filter only the pixel floor(x) matters, and x + offset may round up
+// across a pixel edge (x within 2^-16 of it, offsets up to 8 pitches): take the pixel first, so that the sample lands where the camera's own film
+// would have put it.  The other filters see the position perturbed by that rounding (< 2e-5 pixel), their weights by as much.
+MI_DEV float multi_film_x(const DScene &sc, float x, float offset) { return (sc.rfilter == MI355_RFILTER_BOX ? floorf(x) + .5f : x) + offset; }
 // The perspective branch of sensor_sample_direction for one camera of a DSensorSet (uv in that camera's own film, before its x_offset)
 MI_DEV bool sensor_view_sample_direction(const DSensorView &sv, float film_w, float film_h, v3 p, v2 &uv, v3 &ds_p, float &weight) {
     const float *tw = sv.cam_to_world;
@@ -2525,7 +2529,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
         if (MULTI) {
             for (uint32_t k = 0; k < set->n; ++k) {
                 const bool seen = lane_on && connect && sensor_view_sample_direction(set->v[k], set->film_w, set->film_h, si.p, uv, ds_p, sensor_weight);
-                uv.x += set->v[k].x_offset;
+                uv.x = multi_film_x(sc, uv.x, set->v[k].x_offset);
                 const bool cast = connect_sensor<FULL, GRAD>(sc, si, nullptr, seen, uv, ds_p, ld3(em.radiance) * (idx_weight * pos_weight * sensor_weight), sample_scale, film, stk,
                                                              V3(0.f, 0.f, 0.f), ei, sink, queue, walk == 1);
                 cnt.shadow += wave_count(cast);
@@ -2576,7 +2580,7 @@ MI_DEV void ptracer_sample(const DScene &sc, Pcg32 &rng, int32_t max_depth, int3
             if (MULTI) {
                 for (uint32_t k = 0; k < set->n; ++k) {                     // one connection per camera; the two numbers drawn above are every camera's (a pinhole ignores them)
                     seen = sensor_view_sample_direction(set->v[k], set->film_w, set->film_h, si.p, uv, ds_p, sensor_weight);
-                    uv.x += set->v[k].x_offset;
+                    uv.x = multi_film_x(sc, uv.x, set->v[k].x_offset);
                     MI_SCENE_RELOAD(sc2);
                     const bool c = connect_sensor<FULL, GRAD>(sc2, si, &bsdf, seen, uv, ds_p, throughput * sensor_weight, sample_scale, film, stk, V3(0.f, 0.f, 0.f), ei, sink, queue, walk == 1, nullptr);
                     if (c) cast_mask |= 1u << k;

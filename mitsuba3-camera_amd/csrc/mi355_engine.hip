@@ -2973,7 +2973,7 @@ extern "C" int mi355_render_backward_sensors(mi355_scene *s, const mi355_render_
     if (!s || !p || !sensors || !d_grad_in || !d_grad_params) return fail(MI355_ERR_INVALID, "null argument");
     if (p->integrator != MI355_INTEGRATOR_PTRACER || !(p->flags & MI355_FLAG_GEOMETRY_GRADS) || !(p->flags & MI355_FLAG_SKIP_COLOUR_GRADS))
         return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer's geometry / IOR adjoint only (MI355_FLAG_GEOMETRY_GRADS | MI355_FLAG_SKIP_COLOUR_GRADS)");
-    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. MI355_MAX_SENSORS_PER_PASS (8) sensors");
     if ((p->passes ? p->passes : 1u) != 1u) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: samples_per_pass is not carried");   // (a shard of the light-sample grid is fine: it is the same for every camera)
     for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
     const DScene &f = s->sensors[sensors[0]].snap;
@@ -3008,6 +3008,7 @@ static int render_backward_impl(mi355_scene *s, const mi355_render_params *p, co
         // slot on an emitter-carrying mesh would silently miss the term AD includes: refuse, like the forward design mode does.
         for (const DEmitter &e : s->emitters) if (e.shape < s->shapes.size() && s->shapes[e.shape].type == MI355_SHAPE_MESH && s->shapes[e.shape].grad_offset != 0xffffffffu)
             return fail(MI355_ERR_UNSUPPORTED, "geometry gradients: a mesh that carries an emitter cannot be differentiated (its emitted rays are treated as static)");
+        if (s->shapes.size() >= (1u << (32 - MI_TF_SHIFT))) return fail(MI355_ERR_UNSUPPORTED, "geometry gradients: the path tape packs the shape index into 20 bits");
     }
     Timed tm = { s, st, (p->flags & MI355_FLAG_TIMING) != 0, 0 };
     if ((rc = tm.begin())) return rc;
@@ -3222,7 +3223,7 @@ extern "C" int mi355_lens_sag_backward(const float *d_eval_xy, const float *d_ba
 // Several perspective sensors of equal film size in ONE light-traced pass (see DSensorSet).  d_film: H x virt_w x 4 floats, sensor k's film in the
 // columns [k * pitch + MI_SPLAT_TILE, k * pitch + MI_SPLAT_TILE + W), pitch = roundup(W, 16) + 32, virt_w = n * pitch (mi355_multi_film_layout).
 extern "C" int mi355_multi_film_layout(uint32_t film_w, uint32_t n_sensors, uint32_t *pitch, uint32_t *x0, uint32_t *virt_w) {
-    if (!film_w || !n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    if (!film_w || !n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. MI355_MAX_SENSORS_PER_PASS (8) sensors");
     const uint32_t pt = (film_w + MI_SPLAT_TILE - 1u) / MI_SPLAT_TILE * MI_SPLAT_TILE + 2u * MI_SPLAT_TILE;
     if (pitch) *pitch = pt; if (x0) *x0 = MI_SPLAT_TILE; if (virt_w) *virt_w = n_sensors * pt;
     return MI355_OK;
@@ -3231,7 +3232,7 @@ extern "C" int mi355_render_accumulate_sensors(mi355_scene *s, const mi355_rende
     Phase ph(PHASE_RENDER);
     if (!s || !p || !sensors || !d_film) return fail(MI355_ERR_INVALID, "null argument");
     if (p->integrator != MI355_INTEGRATOR_PTRACER) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: the particle tracer only");
-    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. 4 sensors");
+    if (!n_sensors || n_sensors > MI_MULTI_MAX) return fail(MI355_ERR_INVALID, "1 .. MI355_MAX_SENSORS_PER_PASS (8) sensors");
     if ((p->passes ? p->passes : 1u) != 1u) return fail(MI355_ERR_UNSUPPORTED, "several sensors in one pass: samples_per_pass is not carried");   // (a shard of the light-sample grid is fine: it is the same for every camera)
     for (uint32_t k = 0; k < n_sensors; ++k) if (sensors[k] >= s->sensors.size()) return fail(MI355_ERR_INVALID, "sensor index out of range");
     const DScene &f = s->sensors[sensors[0]].snap;

@@ -25,9 +25,10 @@
 #define MI_TF_LOBE_MASK 3u
 #define MI_TF_CONN 4u
 #define MI_TF_CONT 8u
-#define MI_TF_CONN_K(k) ((k) == 0u ? MI_TF_CONN : (8u << (k)))   // several cameras (DSensorSet): camera k's connection bit (16, 32, 64 for k = 1, 2, 3)
-#define MI_TF_CONN_ANY (MI_TF_CONN | 16u | 32u | 64u)
-#define MI_TF_SHIFT 8
+#define MI_TF_CONN_K(k) ((k) == 0u ? MI_TF_CONN : (8u << (k)))   // several cameras (DSensorSet): camera k's connection bit (16, 32, ... 1024 for k = 1 ... 7)
+#define MI_TF_CONN_ANY (MI_TF_CONN | 0x7f0u)
+#define MI_TF_SHIFT 12                                            // flags below, shape index above (< 2^20 shapes)
+static_assert(MI_MULTI_MAX <= 8, "one connection bit per camera below MI_TF_SHIFT");
 
 struct GeoTape { float *base; uint32_t stride; };      // stride = lanes of the launch; field f of vertex k of lane i at base[(k * FIELDS + f) * stride + i]
 struct GeoBwdSink {

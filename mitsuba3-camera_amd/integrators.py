@@ -366,7 +366,7 @@ class ParticleTracerIntegrator(Integrator):
     def sensors_share_light_paths(self, scene, sensors):
         """True when mi355_render_accumulate_sensors can serve `sensors` with ONE light-traced pass: perspective cameras, one film size without a
         crop window, one reconstruction filter (the light paths of AdjointIntegrator::render depend on the seed and the film size only)."""
-        if not hasattr(self.backend, "accumulate_sensors") or not (1 <= len(sensors) <= 4):
+        if not hasattr(self.backend, "accumulate_sensors") or not (1 <= len(sensors) <= abi.MAX_SENSORS_PER_PASS):
             return False
         ss = [scene.sensors()[scene.sensor_index(k)] for k in sensors]
         f0 = ss[0].film

@@ -1005,12 +1005,13 @@ class DesignProblem:
         # multi-GPU: `shard = (rank, world)` -- every rank traces its part of the light-sample grid, the film and the gradient buffer are
         # all-reduced inside render / render_backward (BASELINE configs[4]: "8-GPU RCCL grad all-reduce"), so every rank takes the same step
         # The fields of an iteration are rendered (and differentiated) with ONE seed (:525-537), so their cameras see the same light paths: the images
-        # come from one pass over those paths and the gradients from one walk + sweep (integrators.render_fields; up to four cameras per pass).
+        # come from one pass over those paths and the gradients from one walk + sweep (integrators.render_fields; up to eight cameras per pass).
         shard = getattr(self, "shard", None); images = {}
         if getattr(self, "share_light_paths", True) and hasattr(self.scene.integrator(), "render_sensors"):
             from .integrators import render_fields
-            for first in range(0, self.num_sources, 4):
-                group_ids = list(range(first, min(first + 4, self.num_sources)))
+            per_pass = int(getattr(self, "sensors_per_pass", 8))
+            for first in range(0, self.num_sources, per_pass):
+                group_ids = list(range(first, min(first + per_pass, self.num_sources)))
                 for k, im in zip(group_ids, render_fields(self.scene, self.params, group_ids, seed=it, spp=2 * self.spp, spp_grad=self.spp, shard=shard, group=getattr(self, "group", None))):
                     images[k] = im
         for sensor_idx in range(self.num_sources):

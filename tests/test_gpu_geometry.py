@@ -583,23 +583,27 @@ def test_adam_kernel_matches_the_per_variable_update(mi, torch_cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rfilter", ["gaussian", "box"])
-def test_geometry_adjoint_of_several_sensors_in_one_pass(mi, torch_cuda, rfilter):
-    """mi355_render_backward_sensors on the cap-lens arrangement watched by THREE perspective cameras from different sides (Gaussian and box
-    filters; the lens-design test covers the tent filter): gradient buffer == sum of three mi355_render_backward calls, block by block, and the
-    images of the one-pass render == the three separate renders.  Plain tensors, explicit geometry request: every vertex / IOR slot is filled."""
+@pytest.mark.parametrize("rfilter,n_cams", [("gaussian", 3), ("box", 3), ("gaussian", 7), ("box", 8)])
+def test_geometry_adjoint_of_several_sensors_in_one_pass(mi, torch_cuda, rfilter, n_cams):
+    """mi355_render_backward_sensors on the cap-lens arrangement watched by three, seven and eight (MI355_MAX_SENSORS_PER_PASS) perspective
+    cameras from different sides (Gaussian and box filters; the lens-design test covers the tent filter): gradient buffer == sum of the
+    mi355_render_backward calls, block by block, and the images of the one-pass render == the separate renders.  Plain tensors, explicit
+    geometry request: every vertex / IOR slot is filled.  A ninth camera is refused."""
     torch = torch_cuda
     T = mi.ScalarTransform4f
     d = _cap_lens_scene(mi, 24, rfilter=rfilter)
-    for k, origin in enumerate(([-0.25, 0.3, 0.7], [0.1, -0.35, 0.5])):
-        se = dict(d['sensor']); se['to_world'] = T.look_at(target=[0.0, 0.0, 0.0], origin=origin, up=[0, 1, 0]); se['fov'] = 50.0 + 15.0 * k
+    origins = ([-0.25, 0.3, 0.7], [0.1, -0.35, 0.5], [0.3, 0.3, 0.6], [-0.3, -0.2, 0.65], [0.0, 0.4, 0.55], [0.35, -0.1, 0.7], [-0.1, 0.1, 0.8], [0.2, 0.2, 0.9])
+    for k, origin in enumerate(origins[:n_cams]):
+        se = dict(d['sensor']); se['to_world'] = T.look_at(target=[0.0, 0.0, 0.0], origin=origin, up=[0, 1, 0]); se['fov'] = 50.0 + 5.0 * k
         se['film'] = dict(d['sensor']['film'])
         d['sensor_%d' % (k + 1)] = se
     scene = mi.load_dict(d)
     integ = scene.integrator()
-    assert len(scene.sensors()) == 3 and integ.sensors_share_light_paths(scene, [0, 1, 2])
-    one = integ.render_sensors(scene, [0, 1, 2], seed=3, spp=64)
-    for k in range(3):
+    cams = list(range(n_cams))
+    assert len(scene.sensors()) == n_cams + 1 and integ.sensors_share_light_paths(scene, cams)
+    assert not integ.sensors_share_light_paths(scene, list(range(9)) if n_cams == 8 else cams + [0] * (9 - n_cams))
+    one = integ.render_sensors(scene, cams, seed=3, spp=64)
+    for k in cams:
         sep = integ.render(scene, sensor=k, seed=3, spp=64)
         assert float(sep.max()) > 0 and float((one[k] - sep).abs().max()) < 1e-5 * float(sep.max()), k
     params = mi.traverse(scene)
@@ -607,11 +611,14 @@ def test_geometry_adjoint_of_several_sensors_in_one_pass(mi, torch_cuda, rfilter
         params[key] = params[key].detach().clone().requires_grad_(True)
     params.update()
     gen = torch.Generator(device="cuda"); gen.manual_seed(2)
-    gins = [torch.rand((24, 24, 3), device="cuda", generator=gen) for _ in range(3)]
-    params.zero_grad(); g_one = integ.render_backward_sensors(scene, params, gins, [0, 1, 2], seed=8, spp=32).clone()
+    gins = [torch.rand((24, 24, 3), device="cuda", generator=gen) for _ in cams]
+    if n_cams > 3:
+        gins[2] = None                                                        # a camera whose image carries no adjoint
+    params.zero_grad(); g_one = integ.render_backward_sensors(scene, params, gins, cams, seed=8, spp=32).clone()
     params.zero_grad()
-    for k in range(3):
-        integ.render_backward(scene, params, gins[k], sensor=k, seed=8, spp=32)
+    for k in cams:
+        if gins[k] is not None:
+            integ.render_backward(scene, params, gins[k], sensor=k, seed=8, spp=32)
     g_sum = params.grad_buffer(g_one.device).clone()
     seen = 0
     for kind, index, off, size in scene_layout(mi, scene):
