@@ -22,6 +22,12 @@ def test_library_exports_every_declared_symbol(mi):
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.mi355_abi_version() == mi.abi.ABI_VERSION
+    assert int(re.search(r"#define MI355_MAX_SENSORS_PER_PASS (\d+)u", hdr).group(1)) == mi.abi.MAX_SENSORS_PER_PASS
+    # mi355_multi_film_layout is host arithmetic (no device): the limit the header states is the one the library enforces
+    pitch, x0, virt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert lib.mi355_multi_film_layout(128, mi.abi.MAX_SENSORS_PER_PASS, C.byref(pitch), C.byref(x0), C.byref(virt)) == mi.abi.OK
+    assert (pitch.value, x0.value, virt.value) == (160, 16, 160 * mi.abi.MAX_SENSORS_PER_PASS)
+    assert lib.mi355_multi_film_layout(128, mi.abi.MAX_SENSORS_PER_PASS + 1, C.byref(pitch), C.byref(x0), C.byref(virt)) == mi.abi.ERR_INVALID
 
 
 def test_struct_layouts_match_header(mi):
