@@ -198,6 +198,14 @@ def algorithmic_bytes(c, n_pixels_developed):
             + 60 * n_pixels_developed)
 
 
+def leg_failed(name, exc):
+    """A secondary leg (prb, veach, ptracer, lens) raised: the traceback goes to stderr, the JSON line carries {"error": ...} in the leg's
+    place, and the headline measurement -- taken before any of these legs -- is printed as usual."""
+    import traceback
+    print("bench.py: leg %r failed" % name, file=sys.stderr); traceback.print_exc(file=sys.stderr)
+    return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,225 +394,237 @@ def main():
     # ---- PRB backward leg (config C3) ------------------------------------------------------------------
     prb = None
     if not args.no_prb:
-        d3 = mi.cornell_box()
-        d3["sensor"]["film"]["width"] = args.res; d3["sensor"]["film"]["height"] = args.res
-        rng = np.random.default_rng(12345)
-        d3["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
-                                                         "data": rng.uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
-        if not args.prb_plain:
-            d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
-        scene3 = mi.load_dict(d3)
-        prb_i = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb_i.timing = True
-        params = mi.traverse(scene3)
-        gin = torch.ones((H, W, 3), dtype=torch.float32, device=dev)
-        shard = (rank, world) if world > 1 else None
-        n_prb = max(2, args.steps // 2)
-        prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(0, 1)[0], spp=args.prb_spp, shard=shard)
-        barrier(); prb_i.counters(scene3, reset=True)
-        t0 = time.perf_counter()
-        for i in range(n_prb):
-            params.zero_grad()
-            prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(i, 1)[0], spp=args.prb_spp, shard=shard)
-        barrier()
-        dtb = time.perf_counter() - t0
-        c3 = prb_i.counters(scene3, reset=True)
-        if dist is not None:
-            tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
-        fwd_ms = None
-        if world == 1:                     # Integrator::render_forward on the same scene (timing only): tangent 1 on every parameter
-            for k_ in params._entries:
-                params.set_tangent(k_, 1.0)
-            prb_i.render_forward(scene3, params, seed=0, spp=args.prb_spp); torch.cuda.synchronize(dev)
+        try:
+            d3 = mi.cornell_box()
+            d3["sensor"]["film"]["width"] = args.res; d3["sensor"]["film"]["height"] = args.res
+            rng = np.random.default_rng(12345)
+            d3["tex"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "raw": True, "filter_type": "bilinear", "wrap_mode": "repeat",
+                                                             "data": rng.uniform(0.2, 0.8, (256, 256, 3)).astype(np.float32)}}
+            if not args.prb_plain:
+                d3["back"]["bsdf"] = {"type": "ref", "id": "tex"}
+            scene3 = mi.load_dict(d3)
+            prb_i = mi.PRBIntegrator({"max_depth": 6, "rr_depth": 5}); prb_i.timing = True
+            params = mi.traverse(scene3)
+            gin = torch.ones((H, W, 3), dtype=torch.float32, device=dev)
+            shard = (rank, world) if world > 1 else None
+            n_prb = max(2, args.steps // 2)
+            prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(0, 1)[0], spp=args.prb_spp, shard=shard)
+            barrier(); prb_i.counters(scene3, reset=True)
             t0 = time.perf_counter()
             for i in range(n_prb):
-                prb_i.render_forward(scene3, params, seed=i, spp=args.prb_spp)
-            torch.cuda.synchronize(dev); fwd_ms = round((time.perf_counter() - t0) / n_prb * 1e3, 3)
-            prb_i.counters(scene3, reset=True)
-        g = params.grad("tex.reflectance.data") if not args.prb_plain else params.grad_buffer(dev)
-        prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
-               "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
-               "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
-               "roofline": valu_roofline("k_prepare_grad + k_prb_backward_1p (+ redo)", "k_prb_backward_1p<0, false>",
-                                         c3["kernel_ms"] / max(c3["kernel_launches"], 1), c3["n_gen"] / max(c3["kernel_launches"], 1),
-                                         # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
-                                         ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
-                                         + 8 * params.grad_buffer(dev).numel()),
-               "render_forward_ms": fwd_ms, "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
-        scene3.release()
+                params.zero_grad()
+                prb_i.render_backward(scene3, params, gin, seed=mi.sample_tea_32(i, 1)[0], spp=args.prb_spp, shard=shard)
+            barrier()
+            dtb = time.perf_counter() - t0
+            c3 = prb_i.counters(scene3, reset=True)
+            if dist is not None:
+                tt = torch.tensor([dtb], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dtb = float(tt.item())
+            fwd_ms = None
+            if world == 1:                     # Integrator::render_forward on the same scene (timing only): tangent 1 on every parameter
+                for k_ in params._entries:
+                    params.set_tangent(k_, 1.0)
+                prb_i.render_forward(scene3, params, seed=0, spp=args.prb_spp); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(n_prb):
+                    prb_i.render_forward(scene3, params, seed=i, spp=args.prb_spp)
+                torch.cuda.synchronize(dev); fwd_ms = round((time.perf_counter() - t0) / n_prb * 1e3, 3)
+                prb_i.counters(scene3, reset=True)
+            g = params.grad("tex.reflectance.data") if not args.prb_plain else params.grad_buffer(dev)
+            prb = {"metric": "Msamples/s PRB backward (one-pass adjoint), Cornell %d^2 @%dspp, 256x256x3 albedo texture" % (args.res, args.prb_spp),
+                   "value": round(npix * args.prb_spp * n_prb / dtb / 1e6, 2), "steps": n_prb, "ms_per_step": round(dtb / n_prb * 1e3, 3),
+                   "kernel_ms": round(c3["kernel_ms"] / max(c3["kernel_launches"], 1), 4),
+                   "roofline": valu_roofline("k_prepare_grad + k_prb_backward_1p (+ redo)", "k_prb_backward_1p<0, false>",
+                                             c3["kernel_ms"] / max(c3["kernel_launches"], 1), c3["n_gen"] / max(c3["kernel_launches"], 1),
+                                             # one walk, shade record 220 B, 24 B of dL per lane, 8 B per gradient float
+                                             ((88 + 24) * c3["n_gen"] + 48 * c3["n_isect"] + 220 * c3["n_shade"] + 104 * c3["n_shadow"]) / max(c3["kernel_launches"], 1)
+                                             + 8 * params.grad_buffer(dev).numel()),
+                   "render_forward_ms": fwd_ms, "redo_groups": int(c3.get("n_redo_groups", 0)), "grad_abs_sum": float(g.abs().sum().item()), "finite": bool(torch.isfinite(g).all().item())}
+            scene3.release()
+        except Exception as e:                                      # a secondary leg never takes the headline line with it
+            prb = leg_failed('prb', e)
 
     # ---- optional: config C4 (FULL kernels: glossy / specular BSDFs, spheres), tile-sharded like the headline leg ----
     c4 = None
     if not args.no_veach:
-        sc4 = mi.load_dict(mi.veach_mis_scene(1024))
-        i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
-        tuned4 = i4.tune(sc4, 512)                                    # re-packing or path regeneration, whichever is faster on this scene
-        i4.timing = True
-        sh4 = mi.shard_tiles(1024, 1024, rank, world, rows=TILE_ROWS) if world > 1 else None
-        film4 = torch.zeros((1024, 1024, 4), dtype=torch.float32, device=dev)
-        h4 = sc4.handle(local_rank)
-        def step4(seed):
-            film4.zero_()
-            p = i4._params(sc4, seed, 512, shard=sh4)                 # (carries MI355_FLAG_REGEN when tune() chose it)
-            mi.abi.check(lib.mi355_render_accumulate(h4, C.byref(p), C.c_void_p(film4.data_ptr()), stream))
+        try:
+            sc4 = mi.load_dict(mi.veach_mis_scene(1024))
+            i4 = mi.PathIntegrator({"max_depth": 6, "rr_depth": 5})
+            tuned4 = i4.tune(sc4, 512)                                    # re-packing or path regeneration, whichever is faster on this scene
+            i4.timing = True
+            sh4 = mi.shard_tiles(1024, 1024, rank, world, rows=TILE_ROWS) if world > 1 else None
+            film4 = torch.zeros((1024, 1024, 4), dtype=torch.float32, device=dev)
+            h4 = sc4.handle(local_rank)
+            def step4(seed):
+                film4.zero_()
+                p = i4._params(sc4, seed, 512, shard=sh4)                 # (carries MI355_FLAG_REGEN when tune() chose it)
+                mi.abi.check(lib.mi355_render_accumulate(h4, C.byref(p), C.c_void_p(film4.data_ptr()), stream))
+                if dist is not None:
+                    dist.all_reduce(film4, op=dist.ReduceOp.SUM)
+            step4(99); barrier(); i4.counters(sc4, reset=True)
+            n4 = max(2, args.steps // 3)
+            t0 = time.perf_counter()
+            for i in range(n4):
+                step4(i)
+            barrier(); dt4 = time.perf_counter() - t0
+            k4 = i4.counters(sc4, reset=True)
             if dist is not None:
-                dist.all_reduce(film4, op=dist.ReduceOp.SUM)
-        step4(99); barrier(); i4.counters(sc4, reset=True)
-        n4 = max(2, args.steps // 3)
-        t0 = time.perf_counter()
-        for i in range(n4):
-            step4(i)
-        barrier(); dt4 = time.perf_counter() - t0
-        k4 = i4.counters(sc4, reset=True)
-        if dist is not None:
-            tt = torch.tensor([dt4], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt4 = float(tt.item())
-        c4 = {"metric": "Msamples/s forward, Veach-MIS scene 1024^2 @512spp (BASELINE configs[3])", "value": round(1024 * 1024 * 512 * n4 / dt4 / 1e6, 2),
-              "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2), "kernel_ms": round(k4["kernel_ms"] / max(k4["kernel_launches"], 1), 3),
-              "events_per_lane": {k: round(k4[k] / max(k4["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")},
-              "variant": "regen" if i4.regen else "repack", "tuned_kernel_ms": {k: round(v, 2) for k, v in tuned4.items()},
-              "finite": bool(torch.isfinite(film4).all().item())}
-        l4 = max(k4["kernel_launches"], 1)
-        c4["roofline"] = valu_roofline("k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>", "k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>",
-                                       k4["kernel_ms"] / l4, k4["n_gen"] / l4, algorithmic_bytes(k4, 1024 * 1024 * n4 / max(world, 1)) / l4, PMC_FILES["veach"],
-                                       lanes_profiled=(1024 * 1024 * 512 if i4.regen else None))  # tools/pmc.sh profiles this same workload; the regen grid is persistent
-        sc4.release()
+                tt = torch.tensor([dt4], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt4 = float(tt.item())
+            c4 = {"metric": "Msamples/s forward, Veach-MIS scene 1024^2 @512spp (BASELINE configs[3])", "value": round(1024 * 1024 * 512 * n4 / dt4 / 1e6, 2),
+                  "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2), "kernel_ms": round(k4["kernel_ms"] / max(k4["kernel_launches"], 1), 3),
+                  "events_per_lane": {k: round(k4[k] / max(k4["n_gen"], 1), 4) for k in ("n_isect", "n_shade", "n_shadow")},
+                  "variant": "regen" if i4.regen else "repack", "tuned_kernel_ms": {k: round(v, 2) for k, v in tuned4.items()},
+                  "finite": bool(torch.isfinite(film4).all().item())}
+            l4 = max(k4["kernel_launches"], 1)
+            c4["roofline"] = valu_roofline("k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>", "k_render_regen<2>" if i4.regen else "k_render_compact<0, 2>",
+                                           k4["kernel_ms"] / l4, k4["n_gen"] / l4, algorithmic_bytes(k4, 1024 * 1024 * n4 / max(world, 1)) / l4, PMC_FILES["veach"],
+                                           lanes_profiled=(1024 * 1024 * 512 if i4.regen else None))  # tools/pmc.sh profiles this same workload; the regen grid is persistent
+            sc4.release()
+        except Exception as e:                                      # a secondary leg never takes the headline line with it
+            c4 = leg_failed('veach', e)
 
     # ---- optional: particle tracer (forward part) -----------------------------------------------------
     pt = None
     if not args.no_ptracer:
-        pt = {}
-        for rf in ("box", "gaussian") + (("gaussian-direct",) if args.ptracer_direct else ()):   # gaussian: deferred tile-sorted splat (default); -direct: plain atomics (A/B)
-            dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
-            dp["sensor"]["film"]["rfilter"] = {"type": rf.split("-")[0]}
-            scp = mi.load_dict(dp)
-            ip = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 5}); ip.timing = True; ip.direct_splat = rf.endswith("-direct")
-            shard = (rank, world) if world > 1 else None
-            ip.render(scp, seed=0, spp=args.prb_spp, shard=shard); barrier(); ip.counters(scp, reset=True)
-            n_pt = max(2, args.steps // 3)
-            t0 = time.perf_counter()
-            for i in range(n_pt):
-                imgp = ip.render(scp, seed=i, spp=args.prb_spp, shard=shard, evaluate=False)
-            barrier(); dtp = time.perf_counter() - t0
-            kp = ip.counters(scp, reset=True)
-            pt[rf] = {"value": round(npix * args.prb_spp * n_pt / dtp / 1e6, 2), "unit": "Msamples/s (light paths)", "ms_per_step": round(dtp / n_pt * 1e3, 3),
-                      "kernel_ms": round(kp["kernel_ms"] / max(kp["kernel_launches"], 1), 3),
-                      "connections_per_lane": round(kp["n_shadow"] / max(kp["n_gen"], 1), 3), "finite": bool(torch.isfinite(imgp).all().item())}
-            if not rf.endswith("-direct"):
-                lp = max(kp["kernel_launches"], 1)
-                # 28 B ray + 20 B hit per intersection, 20 B per connection record written, sorted and read (x3); kernel_ms covers
-                # k_ptracer AND the four deferred-splat passes (the library brackets the whole call), the VALU count is k_ptracer's
-                pt[rf]["roofline"] = valu_roofline("k_ptracer<0, false> (+ k_splat_*)", "k_ptracer<0, false>", kp["kernel_ms"] / lp, kp["n_gen"] / lp,
-                                                   (48 * kp["n_isect"] + 60 * kp["n_shadow"]) / lp, PMC_FILES["ptracer"])
-            if rf == "gaussian" and world == 1:      # the derivative passes of the light tracer on the same scene (timings only)
-                def timed(fn, n=3):
-                    fn(); torch.cuda.synchronize(dev); t0 = time.perf_counter()
-                    for _ in range(n):
-                        fn()
-                    torch.cuda.synchronize(dev); return round((time.perf_counter() - t0) / n * 1e3, 3)
-                gin = torch.ones((args.res, args.res, 3), dtype=torch.float32, device=dev)
-                pa = mi.traverse(scp); pr = mi.traverse(scp); pr.keep(r".*\.emitter\.radiance\.value")
-                cube = [i for i, sh in enumerate(scp.shapes) if sh.id == "small-box"][0]
-                vt = torch.zeros((scp.shapes[cube].vertex_positions.shape[0], 3), dtype=torch.float32, device=dev); vt[:, 1] = 1.0
-                pt[rf]["render_backward_all_params_ms"] = timed(lambda: ip.render_backward(scp, pa, gin, seed=0, spp=args.prb_spp))
-                pt[rf]["render_backward_radiance_ms"] = timed(lambda: ip.render_backward(scp, pr, gin, seed=0, spp=args.prb_spp))
-                pt[rf]["render_forward_design_ms"] = timed(lambda: ip.render_forward_design(scp, shape=cube, vertex_tangent=vt, seed=0, spp=args.prb_spp))
-            scp.release()
+        try:
+            pt = {}
+            for rf in ("box", "gaussian") + (("gaussian-direct",) if args.ptracer_direct else ()):   # gaussian: deferred tile-sorted splat (default); -direct: plain atomics (A/B)
+                dp = mi.cornell_box(); dp["sensor"]["film"]["width"] = args.res; dp["sensor"]["film"]["height"] = args.res
+                dp["sensor"]["film"]["rfilter"] = {"type": rf.split("-")[0]}
+                scp = mi.load_dict(dp)
+                ip = mi.ParticleTracerIntegrator({"max_depth": 6, "rr_depth": 5}); ip.timing = True; ip.direct_splat = rf.endswith("-direct")
+                shard = (rank, world) if world > 1 else None
+                ip.render(scp, seed=0, spp=args.prb_spp, shard=shard); barrier(); ip.counters(scp, reset=True)
+                n_pt = max(2, args.steps // 3)
+                t0 = time.perf_counter()
+                for i in range(n_pt):
+                    imgp = ip.render(scp, seed=i, spp=args.prb_spp, shard=shard, evaluate=False)
+                barrier(); dtp = time.perf_counter() - t0
+                kp = ip.counters(scp, reset=True)
+                pt[rf] = {"value": round(npix * args.prb_spp * n_pt / dtp / 1e6, 2), "unit": "Msamples/s (light paths)", "ms_per_step": round(dtp / n_pt * 1e3, 3),
+                          "kernel_ms": round(kp["kernel_ms"] / max(kp["kernel_launches"], 1), 3),
+                          "connections_per_lane": round(kp["n_shadow"] / max(kp["n_gen"], 1), 3), "finite": bool(torch.isfinite(imgp).all().item())}
+                if not rf.endswith("-direct"):
+                    lp = max(kp["kernel_launches"], 1)
+                    # 28 B ray + 20 B hit per intersection, 20 B per connection record written, sorted and read (x3); kernel_ms covers
+                    # k_ptracer AND the four deferred-splat passes (the library brackets the whole call), the VALU count is k_ptracer's
+                    pt[rf]["roofline"] = valu_roofline("k_ptracer<0, false> (+ k_splat_*)", "k_ptracer<0, false>", kp["kernel_ms"] / lp, kp["n_gen"] / lp,
+                                                       (48 * kp["n_isect"] + 60 * kp["n_shadow"]) / lp, PMC_FILES["ptracer"])
+                if rf == "gaussian" and world == 1:      # the derivative passes of the light tracer on the same scene (timings only)
+                    def timed(fn, n=3):
+                        fn(); torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                        for _ in range(n):
+                            fn()
+                        torch.cuda.synchronize(dev); return round((time.perf_counter() - t0) / n * 1e3, 3)
+                    gin = torch.ones((args.res, args.res, 3), dtype=torch.float32, device=dev)
+                    pa = mi.traverse(scp); pr = mi.traverse(scp); pr.keep(r".*\.emitter\.radiance\.value")
+                    cube = [i for i, sh in enumerate(scp.shapes) if sh.id == "small-box"][0]
+                    vt = torch.zeros((scp.shapes[cube].vertex_positions.shape[0], 3), dtype=torch.float32, device=dev); vt[:, 1] = 1.0
+                    pt[rf]["render_backward_all_params_ms"] = timed(lambda: ip.render_backward(scp, pa, gin, seed=0, spp=args.prb_spp))
+                    pt[rf]["render_backward_radiance_ms"] = timed(lambda: ip.render_backward(scp, pr, gin, seed=0, spp=args.prb_spp))
+                    pt[rf]["render_forward_design_ms"] = timed(lambda: ip.render_forward_design(scp, shape=cube, vertex_tangent=vt, seed=0, spp=args.prb_spp))
+                scp.release()
+        except Exception as e:                                      # a secondary leg never takes the headline line with it
+            pt = leg_failed('ptracer', e)
 
     # ---- BASELINE configs[4]: the lens doublet of notebooks/doublet_full_optim.ipynb -- ptracer + reverse-mode geometry adjoint -----------
     lens = None
     if not args.no_lens:
-        ld = mi.lens_design
-        surfs = [{'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 140, 'z0': 48}, {'radial_extent': 8.0, 'K': 0.0, 'c': -1 / 24, 'z0': 49}, {'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 24, 'z0': 52}]
-        mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
-        t0 = time.perf_counter()
-        system = ld.LensSystem([ld.EvenAsphericSurface(**sf) for sf in surfs], mats, subdiv_levels=args.lens_subdiv); system.disable_all_materials()
-        # cell 5 of the notebook: the rear surface constrained to a 50 mm focal length focused on the film; cell 7: three field sources
-        s1 = system.get_rear_surface_params(50.0)
-        system.elements[0].surface.params['c'] = float(s1['c']); system.elements[0].surface.params['z0'] = float(s1['z0']); system.compute_paraxial_quantities()
-        n_src = 3
-        prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, num_sources=n_src, max_field_angle=5.0, init_camera_z=0.1, fov=100.0).prepare()
-        build_s = time.perf_counter() - t0
-        scl, pl = prob.scene, prob.params
-        lshard = (rank, world) if world > 1 else None
-        prob.shard = lshard                                        # N > 1: sharded light-sample grid, film + gradient all-reduce inside the calls
-        il = scl.integrator(); il.timing = True
-        system.update(pl, prob.optimizer); pl.update()
-        gin_l = torch.ones((128, 128, 3), dtype=torch.float32, device=dev)
+        try:
+            ld = mi.lens_design
+            surfs = [{'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 140, 'z0': 48}, {'radial_extent': 8.0, 'K': 0.0, 'c': -1 / 24, 'z0': 49}, {'radial_extent': 8.0, 'K': 0.0, 'c': 1 / 24, 'z0': 52}]
+            mats = [ld.LensMaterial("sf11", 1.6447, 0.2 * 64.17), ld.LensMaterial("nbk7", 1.5168, 0.2 * 64.17)]
+            t0 = time.perf_counter()
+            system = ld.LensSystem([ld.EvenAsphericSurface(**sf) for sf in surfs], mats, subdiv_levels=args.lens_subdiv); system.disable_all_materials()
+            # cell 5 of the notebook: the rear surface constrained to a 50 mm focal length focused on the film; cell 7: three field sources
+            s1 = system.get_rear_surface_params(50.0)
+            system.elements[0].surface.params['c'] = float(s1['c']); system.elements[0].surface.params['z0'] = float(s1['z0']); system.compute_paraxial_quantities()
+            n_src = 3
+            prob = ld.DesignProblem(system, resolution=(128, 128), spp=128, learning_rate=3e-5, iters=300, num_sources=n_src, max_field_angle=5.0, init_camera_z=0.1, fov=100.0).prepare()
+            build_s = time.perf_counter() - t0
+            scl, pl = prob.scene, prob.params
+            lshard = (rank, world) if world > 1 else None
+            prob.shard = lshard                                        # N > 1: sharded light-sample grid, film + gradient all-reduce inside the calls
+            il = scl.integrator(); il.timing = True
+            system.update(pl, prob.optimizer); pl.update()
+            gin_l = torch.ones((128, 128, 3), dtype=torch.float32, device=dev)
 
-        def timed_l(fn, n=3):
-            fn(); torch.cuda.synchronize(dev); il.counters(scl, reset=True); t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize(dev); ms = (time.perf_counter() - t0) / n * 1e3
-            c = il.counters(scl, reset=True)
-            timed_l.last = c
-            return round(ms, 3), round(c["kernel_ms"] / max(c["kernel_launches"], 1), 3)
+            def timed_l(fn, n=3):
+                fn(); torch.cuda.synchronize(dev); il.counters(scl, reset=True); t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize(dev); ms = (time.perf_counter() - t0) / n * 1e3
+                c = il.counters(scl, reset=True)
+                timed_l.last = c
+                return round(ms, 3), round(c["kernel_ms"] / max(c["kernel_launches"], 1), 3)
 
-        def upd():
-            for e in system.elements:                   # SceneParameters.update of the six meshes: refit + normals on the device
-                for key in (e.lens_key, e.baffle_key):
-                    pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
-            pl.update(); il.render(scl, seed=0, spp=1, shard=lshard)
-        per_sensor = []; lens_roof = {}
-        import itertools
-        fresh = itertools.count(1000)                   # a new seed per call: the lane order (pt_sort_lanes) is computed inside every timed call, as for the
-                                                        # first field of an iteration; the other two fields of an iteration reuse it ("lane_order_reused" below)
-        for sidx in range(n_src):                       # every field's camera: the iteration renders and differentiates all three
-            rs_ms, rs_k = timed_l(lambda: il.render(scl, sensor=sidx, seed=next(fresh), spp=256, shard=lshard))
-            cr = timed_l.last
-            bs_ms, bs_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=sidx, seed=next(fresh), spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
-            if sidx == 0:
-                # kernel_ms brackets the whole call: lane sort (k_pt_keys / _scan / _scatter) + the tracing kernel (+ the deferred splat); the VALU
-                # count and the HBM bytes are the tracing kernel's.  Algorithmic bytes: render = 28 B ray + 20 B hit per
-                # intersection + 3 x 20 B per connection record; adjoint = 144 B of path tape (write + read) + 36 B of scattered triangle adjoint per vertex
-                lr_ = max(cr["kernel_launches"], 1); lanes_r = cr["n_gen"] / lr_
-                lens_roof["render"] = valu_roofline("k_ptracer<1, false> (+ k_pt_*, k_splat_*)", "k_ptracer<1, false>", rs_k, lanes_r, (48 * cr["n_isect"] + 60 * cr["n_shadow"]) / lr_, PMC_FILES["lens"])
-                lanes_b = 128 * 128 * 128 / max(world, 1)
-                lens_roof["geometry_adjoint"] = valu_roofline("k_ptracer_geo_bwd<1, false> (+ k_pt_*, k_vertex_normals_bwd)", "k_ptracer_geo_bwd<1, false>", bs_k, lanes_b,
-                                                              180.0 * cr["n_shade"] / max(cr["n_gen"], 1) * lanes_b, PMC_FILES["lens"])
-            per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
-        r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)
-        b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
-        rr_ms, rr_k = timed_l(lambda: il.render(scl, sensor=1, seed=0, spp=256, shard=lshard))          # same seed as the previous call: the sorted lane list is reused
-        br_ms, br_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=1, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
-        # the three fields from ONE pass over the light paths (mi355_render_accumulate_sensors): what DesignProblem.step calls when unsharded
-        rm_ms = rm_k = None
-        if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):
-            rm_ms, rm_k = timed_l(lambda: il.render_sensors(scl, list(range(n_src)), seed=next(fresh), spp=256))
-        bm_ms = bm_k = None
-        if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):       # ... and their geometry adjoints from one walk and one sweep (mi355_render_backward_sensors)
-            bm_ms, bm_k = timed_l(lambda: (pl.zero_grad(), il.render_backward_sensors(scl, pl, [gin_l] * n_src, list(range(n_src)), seed=next(fresh), spp=128)))
-        ru_ms = ru_k = bu_ms = bu_k = None
-        if not args.no_ab:
-            il.no_lane_sort = True                      # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
-            ru_ms, ru_k = timed_l(lambda: il.render(scl, sensor=0, seed=0, spp=256, shard=lshard))
-            bu_ms, bu_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=0, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
-            il.no_lane_sort = False
-        a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances (sensor 0)
-        c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False, shard=lshard))
-        u_ms, _ = timed_l(upd)
-        m_tw = np.ascontiguousarray(scl.sensors()[1].to_world.affine12(), dtype=np.float32)          # what moving a camera costs: host-side only
-        t0 = time.perf_counter()
-        for _ in range(200):
-            lib.mi355_scene_set_param(scl.handle(), mi.abi.PARAM_SENSOR_TO_WORLD, 1, m_tw.ctypes.data_as(mi.abi.f32p), 12)
-        edit_us = (time.perf_counter() - t0) / 200 * 1e6
-        losses = [prob.step(it)[0] for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
-        t0 = time.perf_counter(); losses += [prob.step(it)[0] for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
-        info = scl.info()
-        if dist is not None:                            # (host timers: the slowest rank's)
-            tt = torch.tensor([r_ms, b_ms, a_ms, c_ms, u_ms, it_ms], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
-        lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
-                "sensors": per_sensor, "roofline": lens_roof, "sensor_edit_us": round(edit_us, 2),
-                "render_all_sensors_one_pass_ms": rm_ms, "render_all_sensors_one_pass_kernels_ms": rm_k,
-                "render_backward_all_sensors_one_pass_ms": bm_ms, "render_backward_all_sensors_one_pass_kernels_ms": bm_k,
-                "lane_order_reused_sensor1": {"render_256spp_ms": rr_ms, "render_kernels_ms": rr_k, "render_backward_geometry_ms": br_ms, "render_backward_kernels_ms": br_k},
-                "unsorted_lanes_sensor0": {"render_256spp_ms": ru_ms, "render_kernels_ms": ru_k, "render_backward_geometry_ms": bu_ms, "render_backward_kernels_ms": bu_k}, "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
-                "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",
-                "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
-                "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
-                "render_backward_geometry_and_colour_ms": a_ms, "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
-                "light_paths_per_s_backward": round(n_src * 128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
-        scl.release()
+            def upd():
+                for e in system.elements:                   # SceneParameters.update of the six meshes: refit + normals on the device
+                    for key in (e.lens_key, e.baffle_key):
+                        pl["%s.vertex_positions" % key] = pl["%s.vertex_positions" % key].detach() * 1.0
+                pl.update(); il.render(scl, seed=0, spp=1, shard=lshard)
+            per_sensor = []; lens_roof = {}
+            import itertools
+            fresh = itertools.count(1000)                   # a new seed per call: the lane order (pt_sort_lanes) is computed inside every timed call, as for the
+                                                            # first field of an iteration; the other two fields of an iteration reuse it ("lane_order_reused" below)
+            for sidx in range(n_src):                       # every field's camera: the iteration renders and differentiates all three
+                rs_ms, rs_k = timed_l(lambda: il.render(scl, sensor=sidx, seed=next(fresh), spp=256, shard=lshard))
+                cr = timed_l.last
+                bs_ms, bs_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=sidx, seed=next(fresh), spp=128, geometry=True, colour=False, shard=lshard))   # what a design step asks for
+                if sidx == 0:
+                    # kernel_ms brackets the whole call: lane sort (k_pt_keys / _scan / _scatter) + the tracing kernel (+ the deferred splat); the VALU
+                    # count and the HBM bytes are the tracing kernel's.  Algorithmic bytes: render = 28 B ray + 20 B hit per
+                    # intersection + 3 x 20 B per connection record; adjoint = 144 B of path tape (write + read) + 36 B of scattered triangle adjoint per vertex
+                    lr_ = max(cr["kernel_launches"], 1); lanes_r = cr["n_gen"] / lr_
+                    lens_roof["render"] = valu_roofline("k_ptracer<1, false> (+ k_pt_*, k_splat_*)", "k_ptracer<1, false>", rs_k, lanes_r, (48 * cr["n_isect"] + 60 * cr["n_shadow"]) / lr_, PMC_FILES["lens"])
+                    lanes_b = 128 * 128 * 128 / max(world, 1)
+                    lens_roof["geometry_adjoint"] = valu_roofline("k_ptracer_geo_bwd<1, false> (+ k_pt_*, k_vertex_normals_bwd)", "k_ptracer_geo_bwd<1, false>", bs_k, lanes_b,
+                                                                  180.0 * cr["n_shade"] / max(cr["n_gen"], 1) * lanes_b, PMC_FILES["lens"])
+                per_sensor.append({"sensor": scl.sensors()[sidx].id, "render_256spp_ms": rs_ms, "render_kernels_ms": rs_k, "render_backward_geometry_ms": bs_ms, "render_backward_kernels_ms": bs_k})
+            r_ms = round(sum(q["render_256spp_ms"] for q in per_sensor), 3); r_k = round(sum(q["render_kernels_ms"] for q in per_sensor), 3)
+            b_ms = round(sum(q["render_backward_geometry_ms"] for q in per_sensor), 3); b_k = round(sum(q["render_backward_kernels_ms"] for q in per_sensor), 3)
+            rr_ms, rr_k = timed_l(lambda: il.render(scl, sensor=1, seed=0, spp=256, shard=lshard))          # same seed as the previous call: the sorted lane list is reused
+            br_ms, br_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=1, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
+            # the three fields from ONE pass over the light paths (mi355_render_accumulate_sensors): what DesignProblem.step calls when unsharded
+            rm_ms = rm_k = None
+            if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):
+                rm_ms, rm_k = timed_l(lambda: il.render_sensors(scl, list(range(n_src)), seed=next(fresh), spp=256))
+            bm_ms = bm_k = None
+            if lshard is None and il.sensors_share_light_paths(scl, list(range(n_src))):       # ... and their geometry adjoints from one walk and one sweep (mi355_render_backward_sensors)
+                bm_ms, bm_k = timed_l(lambda: (pl.zero_grad(), il.render_backward_sensors(scl, pl, [gin_l] * n_src, list(range(n_src)), seed=next(fresh), spp=128)))
+            ru_ms = ru_k = bu_ms = bu_k = None
+            if not args.no_ab:
+                il.no_lane_sort = True                      # A/B: the natural order of the light samples (MI355_FLAG_NO_LANE_SORT), sensor 0
+                ru_ms, ru_k = timed_l(lambda: il.render(scl, sensor=0, seed=0, spp=256, shard=lshard))
+                bu_ms, bu_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, sensor=0, seed=1, spp=128, geometry=True, colour=False, shard=lshard))
+                il.no_lane_sort = False
+            a_ms, a_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=True, colour=True, shard=lshard))    # + reflectances / radiances (sensor 0)
+            c_ms, c_k = timed_l(lambda: il.render_backward(scl, pl, gin_l, seed=1, spp=128, geometry=False, shard=lshard))
+            u_ms, _ = timed_l(upd)
+            m_tw = np.ascontiguousarray(scl.sensors()[1].to_world.affine12(), dtype=np.float32)          # what moving a camera costs: host-side only
+            t0 = time.perf_counter()
+            for _ in range(200):
+                lib.mi355_scene_set_param(scl.handle(), mi.abi.PARAM_SENSOR_TO_WORLD, 1, m_tw.ctypes.data_as(mi.abi.f32p), 12)
+            edit_us = (time.perf_counter() - t0) / 200 * 1e6
+            losses = [prob.step(it)[0] for it in range(2)]; torch.cuda.synchronize(dev)            # (first iterations: torch allocator / autograd warm-up)
+            t0 = time.perf_counter(); losses += [prob.step(it)[0] for it in range(2, 6)]; torch.cuda.synchronize(dev); it_ms = (time.perf_counter() - t0) / 4 * 1e3
+            info = scl.info()
+            if dist is not None:                            # (host timers: the slowest rank's)
+                tt = torch.tensor([r_ms, b_ms, a_ms, c_ms, u_ms, it_ms], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                r_ms, b_ms, a_ms, c_ms, u_ms, it_ms = [round(float(v), 3) for v in tt.tolist()]
+            lens = {"metric": "lens doublet (BASELINE configs[4], notebooks/doublet_full_optim.ipynb cell 7): 3 field sources / 3 sensors, ptracer 128^2; per iteration 3 x (render @256 spp + render_backward @128 spp over all vertices and IORs)",
+                    "sensors": per_sensor, "roofline": lens_roof, "sensor_edit_us": round(edit_us, 2),
+                    "render_all_sensors_one_pass_ms": rm_ms, "render_all_sensors_one_pass_kernels_ms": rm_k,
+                    "render_backward_all_sensors_one_pass_ms": bm_ms, "render_backward_all_sensors_one_pass_kernels_ms": bm_k,
+                    "lane_order_reused_sensor1": {"render_256spp_ms": rr_ms, "render_kernels_ms": rr_k, "render_backward_geometry_ms": br_ms, "render_backward_kernels_ms": br_k},
+                    "unsorted_lanes_sensor0": {"render_256spp_ms": ru_ms, "render_kernels_ms": ru_k, "render_backward_geometry_ms": bu_ms, "render_backward_kernels_ms": bu_k}, "geo_tracer_check": {"max_abs_err_y_mm": prob.geo_check[0], "max_abs_err_u": prob.geo_check[1], "reference_reports": [0.0003799945116043091, 8.578179404139519e-06]},
+                    "n_gpus": world, "sharding": "light-sample grid in 16-row tiles per rank, film + gradient all-reduce (RCCL) inside render / render_backward" if world > 1 else "none",
+                    "triangles": info["triangles"], "bvh_nodes": info["bvh_nodes"], "scene_build_s": round(build_s, 2),
+                    "render_256spp_ms": r_ms, "render_kernels_ms": r_k, "render_backward_geometry_ms": b_ms, "render_backward_kernels_ms": b_k,
+                    "render_backward_geometry_and_colour_ms": a_ms, "render_backward_colour_only_ms": c_ms, "update_refit_plus_1spp_ms": u_ms, "design_iteration_ms": round(it_ms, 2),
+                    "light_paths_per_s_backward": round(n_src * 128 * 128 * 128 / (b_ms * 1e-3) / 1e6, 2), "losses": [round(v, 3) for v in losses]}
+            scl.release()
+        except Exception as e:                                      # a secondary leg never takes the headline line with it
+            lens = leg_failed('lens', e)
 
     # ---- CPU baseline (oracle) on a bounded sample of the same workload --------------------------------
     cpu = None
