@@ -247,6 +247,15 @@ class LensMaterial:
             self.params[var_key] = optimizer[opt_key]
 
 
+def _pushed_states(params):
+    """mesh key -> the surface scalars its vertices were last computed from, stored ON the scene's parameter object: the record lives and dies
+    with the scene it describes (a second DesignProblem over the same LensSystem starts from its own freshly built meshes)."""
+    try:
+        return params.__dict__.setdefault("_pushed_surface_states", {})
+    except AttributeError:                                                    # a plain dict stands in for SceneParameters in some host tests
+        return {}
+
+
 class LensElement:
     """lens.py:343-581: ONE refracting surface as a mesh (`dispersive` interface between two media) plus its black baffle mesh."""
 
@@ -337,9 +346,10 @@ class LensElement:
         # normals, and the refit finds the meshes clean.
         if all(not torch.is_tensor(v) for v in self.surface.params.values()):
             state = tuple(sorted((k, float(v)) for k, v in self.surface.params.items()))
-            if getattr(self, "_pushed_surface", None) == state:
+            pushed = _pushed_states(params)                                   # (kept with the scene's parameters: another scene starts from its own vertices)
+            if pushed.get(self.lens_key) == state:
                 return
-            self._pushed_surface = state
+            pushed[self.lens_key] = state
         params['%s.vertex_positions' % self.lens_key] = surface_positions(self.surface, self.initial_lens_vertices).reshape(-1)
         # the baffle follows the surface's rim in z (lens.py:553-565): every baffle vertex takes z(radial_extent, 0)
         if getattr(self, "_rim_xy", None) is None or self._rim_xy.shape[0] != self.initial_baffle_vertices.shape[0] or self._rim_xy.device != self.initial_baffle_vertices.device:
@@ -449,9 +459,10 @@ class ApertureElement:
             return
         if all(not torch.is_tensor(v) for v in self.surface.params.values()):      # as LensElement.update: an unchanged stop stays in place
             state = tuple(sorted((k, float(v)) for k, v in self.surface.params.items()))
-            if getattr(self, "_pushed_surface", None) == state:
+            pushed = _pushed_states(params)
+            if pushed.get(self.ap_key) == state:
                 return
-            self._pushed_surface = state
+            pushed[self.ap_key] = state
         x0 = self.initial_ap_vertices
         rim_xy = torch.tensor([self.surface.radial_extent, 0.0], dtype=torch.float32, device=x0.device).repeat(x0.shape[0], 1)
         params['%s.vertex_positions' % self.ap_key] = surface_positions(self.surface, x0, rim_xy).reshape(-1)

@@ -409,3 +409,8 @@ def test_a_surface_with_unchanged_scalars_is_not_pushed_again(mi):
     assert torch.allclose(params["lens0.vertex_positions"].reshape(-1, 3)[:, 2], first.reshape(-1, 3)[:, 2] + 0.5, atol=1e-6)
     el.surface.params['c'] = torch.tensor([1 / 30])                           # a tensor may change in place: always pushed
     el.update(params, opt); el.update(params, opt); assert Recorder.writes == 8
+    el.surface.params['c'] = 1 / 30
+    el.update(params, opt); writes = Recorder.writes; el.update(params, opt); assert Recorder.writes == writes
+    other = Recorder()                                                        # the parameters of ANOTHER scene over the same element: pushed afresh
+    dict.__setitem__(other, "lens0.vertex_positions", first.clone()); dict.__setitem__(other, "baffle0.vertex_positions", params["baffle0.vertex_positions"].clone())
+    el.update(other, opt); assert Recorder.writes == writes + 2
